@@ -1,0 +1,230 @@
+"""Synthetic workloads for BASELINE.json's configs (no dataset / checkpoint is available).
+
+Everything is generated procedurally from integer seeds with numpy's counter-based Philox
+generator, so the same tensors come out in the build container and on the GPU box
+(SURVEY.md section 8d).  Model blocks restate the reference's HOCON files:
+  physg.conf  code/confs_sg/physg.conf:33-78   (configs 1-2: closed-form SG shading, indirect OFF)
+  conf.conf   code/confs_sg/conf.conf:36-94    (configs 3, 5: MC direct + near-field indirect)
+  conf_neus   code/confs_sg/conf_neus.conf     (config 4: NeuS geometry, 8x256, d_out 257)
+"""
+import copy
+import math
+
+import numpy as np
+import torch
+
+RAY_TRACER = dict(object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=3,
+                  sphere_tracing_iters=10, n_steps=100, n_rootfind_steps=32)
+
+PHYSG_MODEL = dict(
+    feature_vector_size=0,
+    implicit_network=dict(d_in=3, d_out=1, dims=[512] * 8, geometric_init=True, bias=0.6, skip_in=[4],
+                          weight_norm=True, multires=6),
+    envmap_material_network=dict(multires=10, dims=[512] * 4, white_specular=True, white_light=False,
+                                 num_lgt_sgs=128, num_base_materials=1, upper_hemi=False,
+                                 fix_specular_albedo=False, specular_albedo=[0.3, 0.3, 0.3]),
+    rendering_network=dict(mode='idr', d_in=9, d_out=3, dims=[512] * 4, weight_norm=True, multires_view=4,
+                           multires_xyz=10),
+    ray_tracer=dict(RAY_TRACER),
+)
+PHYSG_LOSS = dict(idr_rgb_weight=0.0, sg_rgb_weight=1.0, eikonal_weight=0.1, mask_weight=100.0, alpha=50.0,
+                  normalsmooth_weight=1.0, r_patch=1.0, loss_type='L1')
+
+CONF_MODEL = dict(
+    render_type='pt_render_indirect_mlp',
+    feature_vector_size=512,
+    fast_multi_ray=False,
+    render_background=True,
+    implicit_network=dict(d_in=3, d_out=1, dims=[512] * 8, geometric_init=True, bias=0.6, skip_in=[4],
+                          weight_norm=True, multires=6, use_last_as_f=True),
+    envmap_material_network=dict(multires=10, dims=[512] * 8, white_specular=True, white_light=False,
+                                 num_lgt_sgs=128, num_base_materials=1, upper_hemi=False,
+                                 fix_specular_albedo=True, specular_albedo=[0.5, 0.5, 0.5],
+                                 init_specular_reflectance=0.1, roughness_mlp=True, specular_mlp=True,
+                                 dims_roughness=[512] * 4, dims_specular=[512] * 4, same_mlp=True),
+    rendering_network=dict(mode='idr', d_in=9, d_out=3, dims=[512] * 4, weight_norm=True, multires_view=4,
+                           multires_xyz=10, normalize_output=False, clip_output=True, clip_method='pow2',
+                           weight_init=True),
+    ray_tracer=dict(RAY_TRACER),
+)
+CONF_LOSS = dict(idr_rgb_weight=1.0, sg_rgb_weight=1.0, eikonal_weight=0.1, mask_weight=100.0, alpha=50.0,
+                 normalsmooth_weight=1.0, r_patch=1.0, loss_type='L1', env_loss_type='L2',
+                 background_rgb_weight=1.0)
+
+NEUS_MODEL = copy.deepcopy(CONF_MODEL)
+NEUS_MODEL['feature_vector_size'] = 256
+NEUS_MODEL['implicit_network'].update(dims=[256] * 8, bias=0.5, use_last_as_f=False)
+
+
+def model_conf(name, hidden=None):
+    """'physg' | 'conf' | 'neus'; ``hidden`` shrinks every MLP width (small parity-test nets)."""
+    m = copy.deepcopy({'physg': PHYSG_MODEL, 'conf': CONF_MODEL, 'neus': NEUS_MODEL}[name])
+    if hidden is not None:
+        for blk in ('implicit_network', 'envmap_material_network', 'rendering_network'):
+            m[blk]['dims'] = [hidden] * len(m[blk]['dims'])
+        if m['feature_vector_size'] > 0:
+            m['feature_vector_size'] = hidden
+    return m
+
+
+def loss_conf(name):
+    return copy.deepcopy(PHYSG_LOSS if name == 'physg' else CONF_LOSS)
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.Philox(int(seed)))
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def sdf_layer_dims(cfg, feature_vector_size):
+    dims = list(cfg['dims'])
+    d0 = 3 + 6 * cfg.get('multires', 0)
+    if cfg.get('use_last_as_f', False):
+        full = [d0] + dims + [cfg['d_out']]
+    else:
+        full = [d0] + dims + [cfg['d_out'] + feature_vector_size]
+    skip = tuple(cfg.get('skip_in', ()))
+    shapes = []
+    for l in range(len(full) - 1):
+        out = full[l + 1] - full[0] if (l + 1) in skip else full[l + 1]
+        shapes.append((out, full[l]))
+    return shapes
+
+
+def fibonacci_sphere(n):
+    i = np.arange(n, dtype=np.float64)
+    y = 1 - (i / float(n - 1)) * 2
+    r = np.sqrt(1 - y * y)
+    th = math.pi * (3. - math.sqrt(5.)) * i
+    return np.stack([np.cos(th) * r, y, np.sin(th) * r], -1)
+
+
+def make_state_dict(model, seed=0, radius=None, bumpy=0.0):
+    """Procedural weights with the reference's state-dict keys.
+
+    ``bumpy`` > 0 puts N(0, bumpy) weights on the sin/cos columns of the first SDF layer: a
+    bumpy, non-exact distance field that exercises the tracer's back-off line search,
+    sampler and bisection.
+
+    SDF: geometric-init statistics (implicit_differentiable_renderer.py:62-76) -> roughly a
+    sphere of radius ``bias``; weight_g = row norm of weight_v.  Radiance / material nets:
+    He-normal hidden layers.  lgtSGs as sg_envmap_material.py:134-149."""
+    g = _rng(seed)
+    F = int(model['feature_vector_size'])
+    sd = {}
+    ic = model['implicit_network']
+    shapes = sdf_layer_dims(ic, F)
+    d0 = shapes[0][1]
+    bias = ic['bias'] if radius is None else radius
+    nl = len(shapes)
+    for l, (o, i) in enumerate(shapes):
+        if l == nl - 1:
+            w = g.normal(math.sqrt(math.pi) / math.sqrt(i), 1e-4, size=(o, i))
+            b = np.full((o,), -bias)
+            if o > 1:          # NeuS-style feature outputs: small random rows, zero bias
+                w[1:] = g.normal(0.0, math.sqrt(2) / math.sqrt(i), size=(o - 1, i))
+                b[1:] = 0.0
+        else:
+            w = g.normal(0.0, math.sqrt(2) / math.sqrt(o), size=(o, i))
+            b = np.zeros((o,))
+            if l == 0 and d0 > 3:
+                w[:, 3:] = g.normal(0.0, bumpy, size=(o, d0 - 3)) if bumpy > 0 else 0.0
+            if l in tuple(ic.get('skip_in', ())) and d0 > 3:
+                w[:, -(d0 - 3):] = 0.0
+        sd['implicit_network.lin%d.weight_v' % l] = _t(w)
+        sd['implicit_network.lin%d.weight_g' % l] = _t(np.linalg.norm(w.astype(np.float32), axis=1, keepdims=True))
+        sd['implicit_network.lin%d.bias' % l] = _t(b)
+    rc = model['rendering_network']
+    din = rc['d_in'] + F + 6 * rc.get('multires_view', 0) + 6 * rc.get('multires_xyz', 0)
+    dims = [din] + list(rc['dims']) + [rc['d_out']]
+    for l in range(len(dims) - 1):
+        std = math.sqrt(2.0 / dims[l]) if l < len(dims) - 2 else 1.0 / math.sqrt(dims[l])
+        w = g.normal(0.0, std, size=(dims[l + 1], dims[l]))
+        sd['rendering_network.lin%d.weight_v' % l] = _t(w)
+        sd['rendering_network.lin%d.weight_g' % l] = _t(np.linalg.norm(w.astype(np.float32), axis=1, keepdims=True))
+        sd['rendering_network.lin%d.bias' % l] = _t(g.normal(0.0, 0.05, size=(dims[l + 1],)))
+    mc = model['envmap_material_network']
+    din = 3 + 6 * mc.get('multires', 0) + F
+    dout = 3 + (1 if (mc.get('roughness_mlp') and mc.get('same_mlp')) else 0)
+    dims = [din] + list(mc['dims']) + [dout]
+    for l in range(len(dims) - 1):
+        std = math.sqrt(2.0 / dims[l]) if l < len(dims) - 2 else 2.0 / math.sqrt(dims[l])
+        sd['envmap_material_network.diffuse_albedo_layers.%d.weight' % (2 * l)] = _t(
+            g.normal(0.0, std, size=(dims[l + 1], dims[l])))
+        sd['envmap_material_network.diffuse_albedo_layers.%d.bias' % (2 * l)] = _t(
+            g.normal(0.0, 0.05, size=(dims[l + 1],)))
+    M = mc['num_lgt_sgs']
+    lgt = g.normal(size=(M, 7))
+    lgt[:, -2:] = lgt[:, -3:-2]
+    lgt[:, 3:4] = 20. + np.abs(lgt[:, 3:4] * 100.)
+    energy = np.abs(lgt[:, 4:]) * 2.0 * math.pi / lgt[:, 3:4] * (1.0 - np.exp(-2.0 * lgt[:, 3:4]))
+    lgt[:, 4:] = np.abs(lgt[:, 4:]) / energy.sum(0, keepdims=True) * 2. * math.pi
+    lgt[:, :3] = fibonacci_sphere(M)
+    sd['envmap_material_network.lgtSGs'] = _t(lgt)
+    if mc.get('fix_specular_albedo'):
+        sd['envmap_material_network.specular_reflectance'] = _t(np.array(mc['specular_albedo']).reshape(1, 3))
+    else:
+        sd['envmap_material_network.specular_reflectance'] = _t(np.abs(g.normal(size=(1, 1 if mc.get('white_specular') else 3))))
+    if not mc.get('roughness_mlp'):
+        sd['envmap_material_network.roughness'] = _t(g.uniform(1.5, 2.0, size=(1, 1)))
+    return sd
+
+
+def look_at_origin_pose(cam_pos):
+    """OpenCV-style cam-to-world (x right, y down, z forward) looking at the origin."""
+    c = np.asarray(cam_pos, dtype=np.float64)
+    z = -c / np.linalg.norm(c)
+    up = np.array([0., 1., 0.]) if abs(z[1]) < 0.99 else np.array([1., 0., 0.])
+    x = np.cross(z, up)          # right-handed with y pointing down
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    p = np.eye(4)
+    p[:3, 0], p[:3, 1], p[:3, 2], p[:3, 3] = x, y, z, c
+    return p
+
+
+def make_inputs(num_pixels, image_hw=(800, 800), focal=1111.0, cam_pos=(0.0, 0.0, 2.4), num_rays=-1, seed=1,
+                mask_all=True, rank=0, world_size=1):
+    """One training batch: random 2x2 patches (scene_dataset.py:224-251), optional sub-pixel jitter
+    shared across pixels (:212-216), contiguous per-rank slice of the patch list (:268-279).
+
+    Returns (model_input dict, ground-truth rgb [1,S,3])."""
+    H, W = image_hw
+    g = _rng(seed)
+    n_patch = num_pixels // 4
+    py = g.integers(0, H - 1, size=n_patch)
+    px = g.integers(0, W - 1, size=n_patch)
+    per = n_patch // world_size
+    lo = rank * per
+    hi = n_patch if rank == world_size - 1 else lo + per
+    py, px = py[lo:hi], px[lo:hi]
+    ys = np.stack([py, py, py + 1, py + 1], 1).reshape(-1)
+    xs = np.stack([px, px + 1, px, px + 1], 1).reshape(-1)
+    uv = np.stack([xs, ys], -1).astype(np.float64)                      # (u=x, v=y)
+    S = uv.shape[0]
+    if num_rays > 0:
+        jit = g.uniform(-0.5, 0.5, size=(1, num_rays, 2))
+        uv = uv[:, None, :] + jit
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = focal
+    K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+    rgb = g.uniform(0.0, 1.0, size=(1, S, 3))
+    if mask_all:
+        mask = np.ones((1, S), dtype=bool)
+    else:
+        mask = (g.uniform(size=(1, S)) < 0.7)
+    inp = {'uv': _t(uv)[None], 'intrinsics': _t(K)[None], 'pose': _t(look_at_origin_pose(cam_pos))[None],
+           'object_mask': torch.from_numpy(mask)}
+    return inp, _t(rgb)
+
+
+WORKLOADS = {
+    # BASELINE.json configs (1-based index in SURVEY.md section 8d)
+    'cfg1': dict(model='physg', num_pixels=512, image_hw=(64, 64), focal=137.0, cam_pos=(0., 0., 3.0), num_rays=-1),
+    'cfg2': dict(model='physg', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=-1),
+    'cfg3': dict(model='conf', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64),
+    'cfg4': dict(model='neus', num_pixels=8192, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64),
+}
