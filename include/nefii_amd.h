@@ -1,0 +1,155 @@
+/*
+ * nefii_amd.h - C ABI of the MI355X (gfx950) hot-path library  libnefii_hip.so
+ *
+ * The reference (FuxiComputerVision/Nefii) has no FFI/plugin boundary: its hot path is eager
+ * PyTorch.  This header is the boundary a maintainer would bind instead
+ * (ctypes stub in INTEGRATION.md).  Each entry point names the reference code it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is called h_* (host);
+ *   - all tensors are contiguous float32 unless stated; masks are uint8 (0/1);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - nothing allocates, frees or synchronises: the caller owns every buffer including the
+ *     workspaces, whose sizes come from the *_workspace_bytes() helpers (hipGraph-capturable);
+ *   - return value: 0 = ok, negative = NEFII_E_* (bad argument), positive = hipError_t.
+ */
+#ifndef NEFII_AMD_H
+#define NEFII_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEFII_ABI_VERSION 1
+#define NEFII_MAX_LAYERS 12
+#define NEFII_TILE_ROWS 32          /* points per workgroup tile */
+#define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
+#define NEFII_MAX_ENC 96            /* widest encoded-input block (padded) */
+
+enum { NEFII_ACT_RELU = 0, NEFII_ACT_ELU = 1, NEFII_ACT_SOFTPLUS100 = 2 };
+enum { NEFII_HEAD_NONE = 0, NEFII_HEAD_TANH01 = 1, NEFII_HEAD_POW2 = 2, NEFII_HEAD_SIGMOID = 3,
+       NEFII_HEAD_RELU = 4, NEFII_HEAD_ABS = 5, NEFII_HEAD_RELU_INIT = 6 };
+enum { NEFII_E_ARG = -1, NEFII_E_SHAPE = -2, NEFII_E_UNSUPPORTED = -3 };
+
+/* One linear layer of a fused MLP.  Inputs of a layer are the concatenation
+ *   [ hidden/feature block (k_x wide, lives in the LDS "X" buffer) | encoded-input block (k_e wide, LDS "E" buffer) ]
+ * which covers the reference's three concat patterns:
+ *   ImplicitNetwork skip layer   cat[x, PE(p)]/sqrt(2)         implicit_differentiable_renderer.py:97-98
+ *   RenderingNetwork layer 0     cat[PE(p), PE(v), n, feat]    implicit_differentiable_renderer.py:205
+ *   EnvmapMaterialNetwork lyr 0  cat[PE(p), feat]              sg_envmap_material.py:362-365
+ * All widths are padded to multiples of 32 (pad weights are zero).  w_fwd / w_bwd are in the MFMA
+ * fragment order produced by nefii_pack_linear(). */
+typedef struct nefii_layer {
+    int32_t k_x, k_e;        /* padded input widths (multiples of 32; either may be 0) */
+    int32_t n_out;           /* true output width */
+    int32_t n_pad;           /* padded output width (multiple of 32, <= 512) */
+    const float *w_fwd;      /* packed [ (k_x+k_e)/8 ][ n_pad/32 ][64][4] */
+    const float *w_bwd;      /* packed transpose for input gradients, or NULL */
+    const float *bias;       /* [n_pad] */
+} nefii_layer;
+
+typedef struct nefii_mlp {
+    int32_t n_layers;
+    int32_t act;             /* NEFII_ACT_* applied after every layer but the last */
+    int32_t head;            /* NEFII_HEAD_* applied to the last layer's output */
+    int32_t enc_freqs[3];    /* positional-encoding octaves of raw inputs a,b,c; -1 = input absent
+                                (embedder.py:38-50: x, sin(2^k x), cos(2^k x), k < L) */
+    int32_t feat_width;      /* per-point feature vector loaded into X before layer 0 (0 = none) */
+    int32_t reserved;
+    nefii_layer layer[NEFII_MAX_LAYERS];
+} nefii_mlp;
+
+int nefii_abi_version(void);
+
+/* Re-order one layer's effective weight W [n_out][k_in] (PyTorch nn.Linear layout, after weight-norm)
+ * into MFMA fragment order, multiplying by `scale` (1/sqrt(2) for skip layers).
+ * Input columns [x_src0, x_src0+x_len) feed the X block, [e_src0, e_src0+e_len) the E block
+ * (block widths are padded up to multiples of 32 with zeros).  Writes w_fwd ( (kx+ke)*n_pad floats ),
+ * optionally w_bwd ( n_pad*(kx+ke) floats ) and bias_pad ( n_pad floats, from bias or zeros ). */
+int nefii_pack_linear(const float *W, const float *bias, int n_out, int k_in,
+                      int x_src0, int x_len, int e_src0, int e_len, float scale,
+                      float *w_fwd, float *w_bwd, float *bias_pad, void *stream);
+
+/* Fused MLP forward over n points (replaces ImplicitNetwork.forward :85-108, RenderingNetwork.forward
+ * :196-241 and EnvmapMaterialNetwork's diffuse_albedo_layers sg_envmap_material.py:369).
+ *   in_a/in_b/in_c : raw [n,3] inputs to be positional-encoded (NULL when enc_freqs[i] < 0)
+ *   feat           : [n, feat_width] or NULL
+ *   out            : [n, out_stride] receives the last layer's n_out columns (head applied)
+ *   hidden_out     : optional [n, hid_stride]: activation entering the last layer (use_last_as_f feature)
+ *   stash          : optional training stash [n_layers][n][stash_stride]: slot l < L-1 holds the
+ *                    post-activation output of layer l (= input of layer l+1), slot L-1 the last layer's
+ *                    pre-head output; consumed by nefii_mlp_backward and the weight-gradient GEMMs.
+ *                    stash_stride >= widest n_pad. */
+int nefii_mlp_forward(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
+                      const float *feat, int64_t n, float *out, int out_stride,
+                      float *hidden_out, int hid_stride, float *stash, int stash_stride, void *stream);
+
+/* Backward of nefii_mlp_forward wrt the hidden activations (the MLP inputs are not differentiated: geometry
+ * is frozen in Step-2).  d_out [n, out_stride] is dL/d(head output).  Writes dz [n_layers][n][dz_stride]:
+ * the gradient wrt every layer's pre-activation.  Parameter gradients follow as plain GEMMs
+ * dW_l = dz_l^T * input_l, db_l = column sums of dz_l (input_0 from nefii_encode_inputs, input_l = stash[l-1]). */
+int nefii_mlp_backward(const nefii_mlp *h_mlp, const float *d_out, int out_stride, const float *stash,
+                       int stash_stride, int64_t n, float *dz, int dz_stride, void *stream);
+
+/* The reference's layer-0 concatenation [PE(a) | PE(b) | PE(c) | feat] as a dense [n, width] matrix. */
+int nefii_encode_inputs(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
+                        const float *feat, int64_t n, float *out, int width, void *stream);
+
+/* SDF value, optional last-hidden feature, and d sdf / d x in one pass
+ * (replaces implicit_network(points) + ImplicitNetwork.gradient, implicit_differentiable_renderer.py:110-123,
+ * 533-540; the reference runs three SDF passes on the same points).  `ws` holds n*(n_layers-1)*512 floats. */
+int nefii_sdf_value_grad(const nefii_mlp *h_mlp, const float *x, int64_t n, float *sdf_out, int out_stride,
+                         float *feat_out, int feat_stride, float *grad_out, float *ws, void *stream);
+size_t nefii_sdf_value_grad_workspace_bytes(const nefii_mlp *h_mlp, int64_t n);
+
+/* RayTracing.forward (ray_tracing.py:29-101) for rays with per-ray origins: bounding-sphere intersection
+ * (rend_util.py:200-221), both-ends sphere tracing with back-off (:104-193), 100-sample bracket search +
+ * bisection for rays that did not converge (:195-280) and, when `training`, the min-SDF search for rays
+ * that miss (:309-337).  Bisection stops per ray (documented difference, <=1e-6 in t). */
+typedef struct nefii_tracer_params {
+    float object_bounding_sphere, sdf_threshold, line_search_step;
+    int32_t line_step_iters, sphere_tracing_iters, n_steps, n_rootfind_steps;
+    int32_t training;
+} nefii_tracer_params;
+
+size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *h_params);
+int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
+/* lin_steps: the n_steps values of torch.linspace(0,1,n_steps); minsdf_steps: the n_steps uniforms of
+ * minimal_sdf_points (only read when training).  counters (optional, int32 [max_rounds][4]) receives the
+ * number of single / dense queries per round: counters[r][0] singles, [r][1] dense rays. */
+int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
+                     const float *origins, const float *dirs, const uint8_t *object_mask, int64_t n_rays,
+                     const float *lin_steps, const float *minsdf_steps,
+                     float *out_points, uint8_t *out_hit, float *out_dists,
+                     void *workspace, size_t workspace_bytes, int32_t *counters, void *stream);
+
+/* rend_util.get_camera_params + lift (rend_util.py:90-142): uv [B,S,2], pose [B,4,4], intrinsics [B,4,4]
+ * -> unit ray dirs [B,S,3] and per-ray origins [B,S,3] (camera centre broadcast). */
+int nefii_camera_rays(const float *uv, const float *pose, const float *intrinsics, int batch, int64_t samples,
+                      float *out_dirs, float *out_origins, void *stream);
+
+/* render_with_sg (sg_render.py:164-295) for one base material (K=1) with global roughness [1] and
+ * specular [3]: outputs rgb / specular / diffuse [n,3]. */
+int nefii_sg_render_forward(const float *lgtSGs, int n_lobes, const float *specular, const float *roughness,
+                            const float *albedo, const float *normal, const float *view, int64_t n,
+                            float *rgb, float *spec_rgb, float *diff_rgb, void *stream);
+/* Gradients of sum(d_rgb*rgb + d_spec*spec_rgb + d_diff*diff_rgb) wrt albedo [n,3], roughness [1], specular [3]
+ * and lgtSGs [n_lobes,7] (the last three accumulated atomically into zero-initialised buffers). */
+int nefii_sg_render_backward(const float *lgtSGs, int n_lobes, const float *specular, const float *roughness,
+                             const float *albedo, const float *normal, const float *view, int64_t n,
+                             const float *d_rgb, const float *d_spec, const float *d_diff,
+                             float *g_albedo, float *g_roughness, float *g_specular, float *g_lgtSGs, void *stream);
+
+/* IDRNetwork.get_background_rgb (implicit_differentiable_renderer.py:646-663): sum of light SGs along dirs. */
+int nefii_env_radiance_forward(const float *lgtSGs, int n_lobes, const float *dirs, int64_t n, float eps,
+                               float *rgb, void *stream);
+int nefii_env_radiance_backward(const float *lgtSGs, int n_lobes, const float *dirs, int64_t n, float eps,
+                                const float *d_rgb, float *g_lgtSGs, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEFII_AMD_H */

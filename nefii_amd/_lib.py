@@ -1,0 +1,105 @@
+"""ctypes binding of libnefii_hip.so (the C ABI declared in include/nefii_amd.h).
+
+The product path has NO fallback: if the shared library is missing or cannot be loaded this
+module raises, and every op built on it fails loudly.  Build with ``python -m nefii_amd.build``
+(or ``__graft_entry__.build()``); the .so is kept in-tree next to the sources.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'csrc', 'libnefii_hip.so')
+
+MAX_LAYERS = 12
+TILE_ROWS = 32
+MAX_WIDTH = 512
+MAX_ENC = 96
+ABI_VERSION = 1
+
+ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
+HEAD_NONE, HEAD_TANH01, HEAD_POW2, HEAD_SIGMOID, HEAD_RELU, HEAD_ABS, HEAD_RELU_INIT = range(7)
+
+c_float_p = ctypes.c_void_p     # device pointers travel as integers
+
+
+class Layer(ctypes.Structure):
+    _fields_ = [('k_x', ctypes.c_int32), ('k_e', ctypes.c_int32), ('n_out', ctypes.c_int32),
+                ('n_pad', ctypes.c_int32), ('w_fwd', ctypes.c_void_p), ('w_bwd', ctypes.c_void_p),
+                ('bias', ctypes.c_void_p)]
+
+
+class Mlp(ctypes.Structure):
+    _fields_ = [('n_layers', ctypes.c_int32), ('act', ctypes.c_int32), ('head', ctypes.c_int32),
+                ('enc_freqs', ctypes.c_int32 * 3), ('feat_width', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('layer', Layer * MAX_LAYERS)]
+
+
+class TracerParams(ctypes.Structure):
+    _fields_ = [('object_bounding_sphere', ctypes.c_float), ('sdf_threshold', ctypes.c_float),
+                ('line_search_step', ctypes.c_float), ('line_step_iters', ctypes.c_int32),
+                ('sphere_tracing_iters', ctypes.c_int32), ('n_steps', ctypes.c_int32),
+                ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32)]
+
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+I64 = ctypes.c_int64
+F = ctypes.c_float
+
+# name -> (restype, argtypes); every symbol include/nefii_amd.h declares
+SIGNATURES = {
+    'nefii_abi_version': (I, []),
+    'nefii_pack_linear': (I, [P, P, I, I, I, I, I, I, F, P, P, P, P]),
+    'nefii_mlp_forward': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P]),
+    'nefii_mlp_backward': (I, [ctypes.POINTER(Mlp), P, I, P, I, I64, P, I, P]),
+    'nefii_encode_inputs': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P]),
+    'nefii_sdf_value_grad': (I, [ctypes.POINTER(Mlp), P, I64, P, I, P, I, P, P, P]),
+    'nefii_sdf_value_grad_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp), I64]),
+    'nefii_trace_workspace_bytes': (ctypes.c_size_t, [I64, ctypes.POINTER(TracerParams)]),
+    'nefii_trace_max_rounds': (I, [ctypes.POINTER(TracerParams)]),
+    'nefii_trace_rays': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(TracerParams), P, P, P, I64, P, P, P, P, P, P,
+                             ctypes.c_size_t, P, P]),
+    'nefii_camera_rays': (I, [P, P, P, I, I64, P, P, P]),
+    'nefii_sg_render_forward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P]),
+    'nefii_sg_render_backward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P, P, P, P, P]),
+    'nefii_env_radiance_forward': (I, [P, I, P, I64, F, P, P]),
+    'nefii_env_radiance_backward': (I, [P, I, P, I64, F, P, P, P]),
+}
+
+_lib = None
+
+
+class NefiiLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library with typed entry points."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NefiiLibraryError(
+            'libnefii_hip.so is not built (%s missing). Run `python -m nefii_amd.build`. '
+            'There is no CPU/PyTorch fallback for the hot path.' % LIB_PATH)
+    try:
+        handle = ctypes.CDLL(LIB_PATH)
+    except OSError as e:          # e.g. libamdhip64 absent
+        raise NefiiLibraryError('cannot load %s: %s' % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError:
+            raise NefiiLibraryError('%s does not export %s' % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if handle.nefii_abi_version() != ABI_VERSION:
+        raise NefiiLibraryError('ABI version mismatch')
+    _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError('%s failed with status %d (%s)' % (
+            what, rc, {-1: 'bad argument', -2: 'bad shape', -3: 'unsupported'}.get(rc, 'hipError_t')))

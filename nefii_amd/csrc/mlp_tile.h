@@ -1,0 +1,187 @@
+// mlp_tile.h - workgroup-level fused-MLP building blocks for gfx950 (MI355X, CDNA4).
+//
+// One workgroup = 256 threads = 4 wave64 = one tile of 32 points.  A layer is the GEMM
+//     Y[32 x n_pad] = [ X[32 x k_x] | E[32 x k_e] ] * W^T
+// done on the f32-input matrix core (v_mfma_f32_32x32x2_f32: exact fp32 fma chains - the SDF
+// decides ray/surface intersections against a 5e-5 threshold, so the tracer cannot afford
+// 16-bit operands; BASELINE.md precision table).  Data placement:
+//   * activations live in LDS ("X": hidden/feature block, row stride 516 floats; "E": encoded raw
+//     inputs, row stride 100 floats).  Strides are 4*odd so that the ds_read_b128 A-fragment
+//     reads (row = lane&31, 4 consecutive k) are bank-conflict free (MI355X_MICROARCH.md, LDS);
+//   * weights are NOT staged in LDS: each wave owns its own 32-column output tiles, so a weight
+//     element is used by exactly one wave - it is streamed L2 -> VGPR as one coalesced
+//     global_load_dwordx4 per lane (1 KiB per wave instruction) from a host-packed fragment order,
+//     double-buffered in registers against the 64-cycle MFMAs;
+//   * accumulators: up to 4 tiles x 16 VGPR per wave.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/nefii_amd.h"
+
+namespace nefii {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TILE = NEFII_TILE_ROWS;   // 32 rows
+constexpr int XS = 516;                 // X row stride (floats): 4*129
+constexpr int ES = 100;                 // E row stride (floats): 4*25
+constexpr int WG = 256;
+
+struct Lds {
+    float X[TILE * XS];
+    float E[TILE * ES];
+};
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == NEFII_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == NEFII_ACT_ELU) return v > 0.f ? v : expm1f(v);
+    // Softplus(beta=100, threshold=20): torch.nn.Softplus as used at implicit_differentiable_renderer.py:83
+    float z = v * 100.f;
+    return z > 20.f ? v : log1pf(expf(z)) / 100.f;
+}
+
+// derivative of the activation expressed through its OUTPUT h (what the stash keeps)
+__device__ __forceinline__ float act_bwd_from_out(float h, int act) {
+    if (act == NEFII_ACT_RELU) return h > 0.f ? 1.f : 0.f;
+    if (act == NEFII_ACT_ELU) return h > 0.f ? 1.f : h + 1.f;
+    // softplus: h = log1p(e^{100 z})/100  =>  sigmoid(100 z) = 1 - e^{-100 h}
+    return -expm1f(-100.f * h);
+}
+
+__device__ __forceinline__ float head_fwd(float v, int head) {
+    switch (head) {
+        case NEFII_HEAD_TANH01: return (tanhf(v) + 1.f) / 2.f;
+        case NEFII_HEAD_POW2: return v * v;
+        case NEFII_HEAD_SIGMOID: return 1.f / (1.f + expf(-v));
+        case NEFII_HEAD_RELU: return v > 0.f ? v : 0.f;
+        case NEFII_HEAD_ABS: return fabsf(v);
+        case NEFII_HEAD_RELU_INIT: return (v > 0.f ? v : 0.f) + 0.5f;
+        default: return v;
+    }
+}
+
+// d head / d pre-activation, from the head OUTPUT y (and, where y is not enough, the sign convention below)
+__device__ __forceinline__ float head_bwd_from_out(float y, float pre, int head) {
+    switch (head) {
+        case NEFII_HEAD_TANH01: { float t = 2.f * y - 1.f; return 0.5f * (1.f - t * t); }
+        case NEFII_HEAD_POW2: return 2.f * pre;
+        case NEFII_HEAD_SIGMOID: return y * (1.f - y);
+        case NEFII_HEAD_RELU: return pre > 0.f ? 1.f : 0.f;
+        case NEFII_HEAD_ABS: return pre > 0.f ? 1.f : (pre < 0.f ? -1.f : 0.f);
+        case NEFII_HEAD_RELU_INIT: return pre > 0.f ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ int enc_width(int L) { return L < 0 ? 0 : 3 + 6 * L; }
+
+// value of column c of the positional encoding of v (embedder.py:21-31 order: x, sin f0, cos f0, sin f1, ...)
+__device__ __forceinline__ float enc_value(const float v[3], int c) {
+    if (c < 3) return v[c];
+    int q = c - 3;
+    int k = q / 6, rem = q - 6 * k;
+    int fn = rem / 3, comp = rem - 3 * fn;
+    float a = v[comp] * (float)(1 << k);
+    return fn ? cosf(a) : sinf(a);
+}
+
+// derivative of column c wrt its own component (and which component it is)
+__device__ __forceinline__ float enc_deriv(const float v[3], int c, int &comp) {
+    if (c < 3) { comp = c; return 1.f; }
+    int q = c - 3;
+    int k = q / 6, rem = q - 6 * k;
+    int fn = rem / 3;
+    comp = rem - 3 * fn;
+    float f = (float)(1 << k);
+    float a = v[comp] * f;
+    return fn ? -f * sinf(a) : f * cosf(a);
+}
+
+// Fill E[32][k_e] from up to three raw [n,3] inputs already staged in LDS `raw` ([32][9]).
+__device__ __forceinline__ void encode_tile(const nefii_mlp &m, const float *raw, float *E, int k_e) {
+    const int tid = threadIdx.x;
+    const int p = tid & 31, part = tid >> 5;
+    const int w0 = enc_width(m.enc_freqs[0]), w1 = enc_width(m.enc_freqs[1]), w2 = enc_width(m.enc_freqs[2]);
+    for (int c = part; c < k_e; c += 8) {
+        float val = 0.f;
+        if (c < w0) {
+            val = enc_value(raw + p * 9, c);
+        } else if (c < w0 + w1) {
+            val = enc_value(raw + p * 9 + 3, c - w0);
+        } else if (c < w0 + w1 + w2) {
+            val = enc_value(raw + p * 9 + 6, c - w0 - w1);
+        }
+        E[p * ES + c] = val;
+    }
+}
+
+// ---- GEMM core -------------------------------------------------------------------------------
+// acc[j] += A[32 x 8*kgroups] * Wfrag for this wave's tiles t = wave + 4*j (j < ntw).
+// A fragment: lane (r = lane&31, h = lane>>5) reads A[r][8g + 4h .. +3] with one ds_read_b128;
+// MFMA step s multiplies k = 8g+4h+s: over h (the MFMA's own K=2) and s = 0..3 all 8 k of the group.
+// wp points at group 0 of this layer block: float4 index ((g*NT + t)*64 + lane).
+__device__ __forceinline__ void gemm_block(const float *A, int a_stride, int kgroups, const float4 *__restrict__ wp,
+                                           int NT, int wave, int lane, int ntw, f32x16 (&acc)[4]) {
+    if (kgroups <= 0 || ntw <= 0) return;
+    const int r = lane & 31, h = lane >> 5;
+    const float *arow = A + r * a_stride + 4 * h;
+    float4 bc[4], bn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < ntw) bc[j] = wp[(size_t)(wave + 4 * j) * 64 + lane];
+    }
+    for (int g = 0; g < kgroups; ++g) {
+        if (g + 1 < kgroups) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < ntw) bn[j] = wp[((size_t)(g + 1) * NT + wave + 4 * j) * 64 + lane];
+        }
+        const float4 a = *reinterpret_cast<const float4 *>(arow + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < ntw) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bc[j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bc[j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bc[j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bc[j].w, acc[j], 0, 0, 0);
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bc[j] = bn[j];
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+}
+
+// One layer's matrix product for the whole workgroup: acc = [X | E] * W.  Caller does the epilogue.
+__device__ __forceinline__ void layer_gemm(const nefii_layer &L, const float *X, const float *E, const float *w,
+                                           int n_tiles, f32x16 (&acc)[4], int &ntw) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    ntw = (n_tiles - wave + 3) >> 2;
+    if (ntw < 0) ntw = 0;
+    zero_acc(acc);
+    const float4 *wp = reinterpret_cast<const float4 *>(w);
+    gemm_block(X, XS, L.k_x >> 3, wp, n_tiles, wave, lane, ntw, acc);
+    gemm_block(E, ES, L.k_e >> 3, wp + (size_t)(L.k_x >> 3) * n_tiles * 64, n_tiles, wave, lane, ntw, acc);
+}
+
+// accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
+#define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \
+    {                                                                                     \
+        const int _wave = threadIdx.x >> 6, _lane = threadIdx.x & 63;                     \
+        _Pragma("unroll") for (int _j = 0; _j < 4; ++_j) if (_j < (ntw)) {                \
+            const int col = 32 * (_wave + 4 * _j) + (_lane & 31);                         \
+            _Pragma("unroll") for (int _i = 0; _i < 16; ++_i) {                           \
+                const int row = (_i & 3) + 8 * (_i >> 2) + 4 * (_lane >> 5);              \
+                const float val = (acc)[_j][_i];                                               \
+                BODY                                                                      \
+            }                                                                             \
+        }                                                                                 \
+    }
+
+}  // namespace nefii

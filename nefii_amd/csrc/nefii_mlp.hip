@@ -1,0 +1,401 @@
+// nefii_mlp.hip - fused MLP kernels (forward, hidden-gradient backward, SDF value+gradient) and the
+// weight packer, for gfx950.  Tile machinery in mlp_tile.h.
+#include "mlp_tile.h"
+
+using namespace nefii;
+
+#define HIP_CHECK_LAUNCH()                       \
+    do {                                         \
+        hipError_t _e = hipGetLastError();       \
+        if (_e != hipSuccess) return (int)_e;    \
+    } while (0)
+
+static inline int round32(int v) { return (v + 31) & ~31; }
+
+extern "C" int nefii_abi_version(void) { return NEFII_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int src_col(int kk, int kx, int x_src0, int x_len, int e_src0, int e_len) {
+    if (kk < kx) return kk < x_len ? x_src0 + kk : -1;
+    int e = kk - kx;
+    return e < e_len ? e_src0 + e : -1;
+}
+
+__global__ void pack_linear_kernel(const float *__restrict__ W, const float *__restrict__ bias, int n_out, int k_in,
+                                   int kx, int ke, int n_pad, int x_src0, int x_len, int e_src0, int e_len, float scale,
+                                   float *__restrict__ w_fwd, float *__restrict__ w_bwd, float *__restrict__ bias_pad) {
+    const int K = kx + ke;
+    const int total = K * n_pad;
+    const int NT = n_pad >> 5, KT = K >> 5;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int s = idx & 3, lane = (idx >> 2) & 63, blk = idx >> 8;
+        {   // forward fragment: blk = g*NT + t ; element W[n = 32t + (lane&31)][k = 8g + 4(lane>>5) + s]
+            const int t = blk % NT, g = blk / NT;
+            const int n = 32 * t + (lane & 31), kk = 8 * g + 4 * (lane >> 5) + s;
+            const int c = src_col(kk, kx, x_src0, x_len, e_src0, e_len);
+            w_fwd[idx] = (n < n_out && c >= 0) ? W[(size_t)n * k_in + c] * scale : 0.f;
+        }
+        if (w_bwd) {   // backward fragment: contraction over n, output column kk: blk = g*KT + t
+            const int t = blk % KT, g = blk / KT;
+            const int kk = 32 * t + (lane & 31), n = 8 * g + 4 * (lane >> 5) + s;
+            const int c = src_col(kk, kx, x_src0, x_len, e_src0, e_len);
+            w_bwd[idx] = (n < n_out && c >= 0) ? W[(size_t)n * k_in + c] * scale : 0.f;
+        }
+        if (idx < n_pad) bias_pad[idx] = (bias && idx < n_out) ? bias[idx] : 0.f;
+    }
+}
+
+extern "C" int nefii_pack_linear(const float *W, const float *bias, int n_out, int k_in, int x_src0, int x_len,
+                                 int e_src0, int e_len, float scale, float *w_fwd, float *w_bwd, float *bias_pad,
+                                 void *stream) {
+    if (!W || !w_fwd || !bias_pad || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
+    const int kx = round32(x_len), ke = round32(e_len), n_pad = round32(n_out);
+    if (n_pad > NEFII_MAX_WIDTH || kx > NEFII_MAX_WIDTH || ke > NEFII_MAX_ENC || kx + ke == 0) return NEFII_E_SHAPE;
+    if (x_src0 + x_len > k_in || e_src0 + e_len > k_in) return NEFII_E_SHAPE;
+    const int total = (kx + ke) * n_pad;
+    int blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pack_linear_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, bias, n_out, k_in, kx, ke,
+                       n_pad, x_src0, x_len, e_src0, e_len, scale, w_fwd, w_bwd, bias_pad);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared prologue: stage raw inputs + features of one 32-point tile, encode into E
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_tile_inputs(const nefii_mlp &m, const float *in_a, const float *in_b,
+                                                 const float *in_c, const float *feat, int64_t base, int64_t n,
+                                                 float *raw, Lds &lds) {
+    const int tid = threadIdx.x;
+    if (tid < TILE * 9) {
+        const int p = tid / 9, c = tid - 9 * p, which = c / 3;
+        const float *src = which == 0 ? in_a : (which == 1 ? in_b : in_c);
+        int64_t idx = base + p;
+        if (idx >= n) idx = n - 1;
+        raw[tid] = (src && m.enc_freqs[which] >= 0) ? src[idx * 3 + (c - 3 * which)] : 0.f;
+    }
+    const int F = m.feat_width;
+    const int kx0 = m.layer[0].k_x;
+    if (kx0 > 0) {
+        for (int i = tid; i < TILE * kx0; i += WG) {
+            const int p = i / kx0, f = i - p * kx0;
+            int64_t idx = base + p;
+            if (idx >= n) idx = n - 1;
+            lds.X[p * XS + f] = (feat && f < F) ? feat[idx * F + f] : 0.f;
+        }
+    }
+    __syncthreads();
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    encode_tile(m, raw, lds.E, ke);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void mlp_forward_kernel(nefii_mlp m, const float *__restrict__ in_a,
+                                                             const float *__restrict__ in_b,
+                                                             const float *__restrict__ in_c,
+                                                             const float *__restrict__ feat, int64_t n,
+                                                             float *__restrict__ out, int out_stride,
+                                                             float *__restrict__ hidden_out, int hid_stride,
+                                                             float *__restrict__ stash, int stash_stride) {
+    __shared__ Lds lds;
+    __shared__ float raw[TILE * 9];
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * TILE;
+        load_tile_inputs(m, in_a, in_b, in_c, feat, base, n, raw, lds);
+        for (int l = 0; l < m.n_layers; ++l) {
+            const nefii_layer &L = m.layer[l];
+            f32x16 acc[4];
+            int ntw;
+            layer_gemm(L, lds.X, lds.E, L.w_fwd, L.n_pad >> 5, acc, ntw);
+            __syncthreads();
+            const bool last = (l == m.n_layers - 1);
+            const bool pre_last = (l == m.n_layers - 2);
+            NEFII_FOR_ACC(acc, ntw, {
+                const float z = val + L.bias[col];
+                const bool live = (base + row) < n;
+                if (!last) {
+                    const float hval = act_fwd(z, m.act);
+                    lds.X[row * XS + col] = hval;
+                    if (stash && live) stash[((size_t)l * n + base + row) * stash_stride + col] = hval;
+                    if (pre_last && hidden_out && live && col < L.n_out)
+                        hidden_out[(size_t)(base + row) * hid_stride + col] = hval;
+                } else {
+                    if (stash && live) stash[((size_t)l * n + base + row) * stash_stride + col] = z;
+                    if (live && col < L.n_out) out[(size_t)(base + row) * out_stride + col] = head_fwd(z, m.head);
+                }
+            })
+            __syncthreads();
+        }
+    }
+}
+
+static int check_mlp(const nefii_mlp *m) {
+    if (!m || m->n_layers < 1 || m->n_layers > NEFII_MAX_LAYERS) return NEFII_E_ARG;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const nefii_layer &L = m->layer[l];
+        if ((L.k_x & 31) || (L.k_e & 31) || (L.n_pad & 31) || L.k_x + L.k_e <= 0) return NEFII_E_SHAPE;
+        if (L.k_x > NEFII_MAX_WIDTH || L.k_e > NEFII_MAX_ENC || L.n_pad > NEFII_MAX_WIDTH || L.n_out > L.n_pad)
+            return NEFII_E_SHAPE;
+        if (!L.w_fwd || !L.bias) return NEFII_E_ARG;
+        if (l > 0 && L.k_x != m->layer[l - 1].n_pad) return NEFII_E_SHAPE;
+    }
+    int ew = 0;
+    for (int i = 0; i < 3; ++i)
+        if (m->enc_freqs[i] >= 0) ew += 3 + 6 * m->enc_freqs[i];
+    if (ew > NEFII_MAX_ENC) return NEFII_E_SHAPE;
+    if (m->feat_width > m->layer[0].k_x) return NEFII_E_SHAPE;
+    return 0;
+}
+
+static int grid_for(int64_t n_tiles, int per_cu) {
+    int64_t cap = 256 * per_cu * 2;   // 256 CUs; tiles beyond the cap are grid-strided
+    return (int)(n_tiles < cap ? (n_tiles > 0 ? n_tiles : 1) : cap);
+}
+
+extern "C" int nefii_mlp_forward(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
+                                 const float *feat, int64_t n, float *out, int out_stride, float *hidden_out,
+                                 int hid_stride, float *stash, int stash_stride, void *stream) {
+    int rc = check_mlp(h_mlp);
+    if (rc) return rc;
+    if (n <= 0) return 0;
+    if (!out) return NEFII_E_ARG;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid_for(n_tiles, 2)), dim3(WG), 0, (hipStream_t)stream, *h_mlp, in_a,
+                       in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash, stash_stride);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encode only: the reference's layer-0 concatenation [PE(a) | PE(b) | PE(c) | feat] as a dense matrix
+// (operand of the layer-0 weight-gradient GEMM)
+// ------------------------------------------------------------------------------------------------
+__global__ void encode_kernel(nefii_mlp m, const float *__restrict__ in_a, const float *__restrict__ in_b,
+                              const float *__restrict__ in_c, const float *__restrict__ feat, int64_t n,
+                              float *__restrict__ out, int width) {
+    const int w0 = enc_width(m.enc_freqs[0]), w1 = enc_width(m.enc_freqs[1]), w2 = enc_width(m.enc_freqs[2]);
+    const int we = w0 + w1 + w2, F = m.feat_width;
+    const int64_t total = n * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i / width;
+        const int c = (int)(i - p * width);
+        float v[3];
+        float val;
+        if (c < we) {
+            const float *src = c < w0 ? in_a : (c < w0 + w1 ? in_b : in_c);
+            const int cc = c < w0 ? c : (c < w0 + w1 ? c - w0 : c - w0 - w1);
+            v[0] = src[p * 3], v[1] = src[p * 3 + 1], v[2] = src[p * 3 + 2];
+            val = enc_value(v, cc);
+        } else {
+            val = (c - we) < F ? feat[p * F + (c - we)] : 0.f;
+        }
+        out[i] = val;
+    }
+}
+
+extern "C" int nefii_encode_inputs(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
+                                   const float *feat, int64_t n, float *out, int width, void *stream) {
+    if (!h_mlp || !out) return NEFII_E_ARG;
+    if (n <= 0) return 0;
+    int64_t total = n * width;
+    int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(encode_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *h_mlp, in_a, in_b, in_c, feat,
+                       n, out, width);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward wrt hidden activations (parameters get their gradients from dz via a GEMM per layer)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void mlp_backward_kernel(nefii_mlp m, const float *__restrict__ d_out,
+                                                              int out_stride, const float *__restrict__ stash,
+                                                              int stash_stride, int64_t n, float *__restrict__ dz,
+                                                              int dz_stride) {
+    __shared__ Lds lds;
+    const int tid = threadIdx.x;
+    const int Lm1 = m.n_layers - 1;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * TILE;
+        {   // seed: dz_{L-1} = d_out * head'(pre)
+            const nefii_layer &L = m.layer[Lm1];
+            for (int i = tid; i < TILE * L.n_pad; i += WG) {
+                const int p = i / L.n_pad, c = i - p * L.n_pad;
+                float v = 0.f;
+                if (base + p < n && c < L.n_out) {
+                    const float pre = stash[((size_t)Lm1 * n + base + p) * stash_stride + c];
+                    const float y = head_fwd(pre, m.head);
+                    v = d_out[(size_t)(base + p) * out_stride + c] * head_bwd_from_out(y, pre, m.head);
+                }
+                lds.X[p * XS + c] = v;
+                if (base + p < n) dz[((size_t)Lm1 * n + base + p) * dz_stride + c] = v;
+            }
+        }
+        __syncthreads();
+        for (int l = Lm1; l >= 1; --l) {
+            const nefii_layer &L = m.layer[l];
+            // dH_{l-1}[32 x k_x] = dZ_l[32 x n_pad] * W_l   (only the hidden block of the inputs)
+            f32x16 acc[4];
+            int ntw;
+            const int wave = tid >> 6, lane = tid & 63;
+            const int NTs = (L.k_x + L.k_e) >> 5, ntc = L.k_x >> 5;
+            ntw = (ntc - wave + 3) >> 2;
+            if (ntw < 0) ntw = 0;
+            zero_acc(acc);
+            gemm_block(lds.X, XS, L.n_pad >> 3, reinterpret_cast<const float4 *>(L.w_bwd), NTs, wave, lane, ntw, acc);
+            __syncthreads();
+            NEFII_FOR_ACC(acc, ntw, {
+                const bool live = (base + row) < n;
+                float v = 0.f;
+                if (live) {
+                    const float hprev = stash[((size_t)(l - 1) * n + base + row) * stash_stride + col];
+                    v = val * act_bwd_from_out(hprev, m.act);
+                    dz[((size_t)(l - 1) * n + base + row) * dz_stride + col] = v;
+                }
+                lds.X[row * XS + col] = v;
+            })
+            __syncthreads();
+        }
+    }
+}
+
+extern "C" int nefii_mlp_backward(const nefii_mlp *h_mlp, const float *d_out, int out_stride, const float *stash,
+                                  int stash_stride, int64_t n, float *dz, int dz_stride, void *stream) {
+    int rc = check_mlp(h_mlp);
+    if (rc) return rc;
+    if (n <= 0) return 0;
+    if (!d_out || !stash || !dz) return NEFII_E_ARG;
+    for (int l = 1; l < h_mlp->n_layers; ++l)
+        if (!h_mlp->layer[l].w_bwd) return NEFII_E_ARG;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    hipLaunchKernelGGL(mlp_backward_kernel, dim3(grid_for(n_tiles, 2)), dim3(WG), 0, (hipStream_t)stream, *h_mlp, d_out,
+                       out_stride, stash, stash_stride, n, dz, dz_stride);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SDF value + d sdf / d x  (forward keeps the hidden activations in a workspace; the backward
+// sweep runs in the same workgroup right after, so the workspace lines are still in L2)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void sdf_value_grad_kernel(nefii_mlp m, const float *__restrict__ x, int64_t n,
+                                                                float *__restrict__ sdf_out, int out_stride,
+                                                                float *__restrict__ feat_out, int feat_stride,
+                                                                float *__restrict__ grad_out, float *__restrict__ ws,
+                                                                int ws_stride) {
+    __shared__ Lds lds;
+    __shared__ float GE[TILE * ES];
+    __shared__ float raw[TILE * 9];
+    const int tid = threadIdx.x;
+    const int Lm1 = m.n_layers - 1;
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * TILE;
+        load_tile_inputs(m, x, nullptr, nullptr, nullptr, base, n, raw, lds);
+        for (int i = tid; i < TILE * ES; i += WG) GE[i] = 0.f;
+        // ---- forward
+        for (int l = 0; l <= Lm1; ++l) {
+            const nefii_layer &L = m.layer[l];
+            f32x16 acc[4];
+            int ntw;
+            layer_gemm(L, lds.X, lds.E, L.w_fwd, L.n_pad >> 5, acc, ntw);
+            __syncthreads();
+            NEFII_FOR_ACC(acc, ntw, {
+                const float z = val + L.bias[col];
+                const bool live = (base + row) < n;
+                if (l < Lm1) {
+                    const float hval = act_fwd(z, m.act);
+                    lds.X[row * XS + col] = hval;
+                    if (live) ws[((size_t)l * n + base + row) * ws_stride + col] = hval;
+                    if (l == Lm1 - 1 && feat_out && live && col < L.n_out)
+                        feat_out[(size_t)(base + row) * feat_stride + col] = hval;
+                } else {
+                    if (live && col < L.n_out) sdf_out[(size_t)(base + row) * out_stride + col] = z;
+                    lds.X[row * XS + col] = (col == 0) ? 1.f : 0.f;   // seed d sdf / d z_{L-1}
+                }
+            })
+            __syncthreads();
+        }
+        // ---- backward to the encoded input
+        for (int l = Lm1; l >= 0; --l) {
+            const nefii_layer &L = m.layer[l];
+            const int wave = tid >> 6, lane = tid & 63;
+            const int NTs = (L.k_x + L.k_e) >> 5;
+            int ntw = (NTs - wave + 3) >> 2;
+            if (ntw < 0) ntw = 0;
+            f32x16 acc[4];
+            zero_acc(acc);
+            gemm_block(lds.X, XS, L.n_pad >> 3, reinterpret_cast<const float4 *>(L.w_bwd), NTs, wave, lane, ntw, acc);
+            __syncthreads();
+            NEFII_FOR_ACC(acc, ntw, {
+                if (col < L.k_x) {
+                    const bool live = (base + row) < n;
+                    float v = 0.f;
+                    if (live && l > 0) {
+                        const float hprev = ws[((size_t)(l - 1) * n + base + row) * ws_stride + col];
+                        v = val * act_bwd_from_out(hprev, m.act);
+                    }
+                    lds.X[row * XS + col] = v;
+                } else {
+                    GE[row * ES + (col - L.k_x)] += val;
+                }
+            })
+            __syncthreads();
+        }
+        // ---- chain through the positional encoding
+        if (tid < TILE * 3) {
+            const int p = tid / 3, c = tid - 3 * p;
+            if (base + p < n) {
+                const float *v = raw + p * 9;
+                const int w0 = enc_width(m.enc_freqs[0]);
+                float g = 0.f;
+                for (int col = 0; col < w0; ++col) {
+                    int comp;
+                    const float d = enc_deriv(v, col, comp);
+                    if (comp == c) g += GE[p * ES + col] * d;
+                }
+                grad_out[(size_t)(base + p) * 3 + c] = g;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static int sdf_ws_stride(const nefii_mlp *m) {
+    int s = 32;
+    for (int l = 0; l < m->n_layers - 1; ++l) s = m->layer[l].n_pad > s ? m->layer[l].n_pad : s;
+    return s;
+}
+
+extern "C" size_t nefii_sdf_value_grad_workspace_bytes(const nefii_mlp *h_mlp, int64_t n) {
+    if (!h_mlp || n <= 0) return 0;
+    return (size_t)(h_mlp->n_layers - 1) * (size_t)n * sdf_ws_stride(h_mlp) * sizeof(float);
+}
+
+extern "C" int nefii_sdf_value_grad(const nefii_mlp *h_mlp, const float *x, int64_t n, float *sdf_out, int out_stride,
+                                    float *feat_out, int feat_stride, float *grad_out, float *ws, void *stream) {
+    int rc = check_mlp(h_mlp);
+    if (rc) return rc;
+    if (n <= 0) return 0;
+    if (!x || !sdf_out || !grad_out || !ws) return NEFII_E_ARG;
+    if (h_mlp->enc_freqs[0] < 0 || h_mlp->enc_freqs[1] >= 0 || h_mlp->enc_freqs[2] >= 0 || h_mlp->feat_width != 0)
+        return NEFII_E_UNSUPPORTED;
+    for (int l = 0; l < h_mlp->n_layers; ++l)
+        if (!h_mlp->layer[l].w_bwd) return NEFII_E_ARG;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    hipLaunchKernelGGL(sdf_value_grad_kernel, dim3(grid_for(n_tiles, 1)), dim3(WG), 0, (hipStream_t)stream, *h_mlp, x,
+                       n, sdf_out, out_stride, feat_out, feat_stride, grad_out, ws, sdf_ws_stride(h_mlp));
+    HIP_CHECK_LAUNCH();
+    return 0;
+}

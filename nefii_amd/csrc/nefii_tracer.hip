@@ -1,0 +1,566 @@
+// nefii_tracer.hip - SDF ray tracer for gfx950: RayTracing.forward of the reference
+// (code/model/ray_tracing.py:29-337) restated as a per-ray state machine driven in ROUNDS.
+//
+// Every round is two launches on one stream, with no host synchronisation:
+//   advance : one thread per ray.  Consumes the SDF values its ray asked for in the previous round,
+//             moves the ray's state machine (sphere tracing both ends + back-off line search ->
+//             100-sample bracket search -> bisection -> min-SDF search) and appends the ray's next
+//             SDF queries to a compacted work list (wave ballot + prefix popcount, one atomic per block).
+//   eval    : the fused SDF MLP (mlp_tile.h) over dense 32-query tiles of that list - rays in different
+//             phases share tiles, so the matrix cores only ever see live queries.
+// Ray state is a few floats per ray in global memory (L2 resident); all heavy traffic is the MLP.
+// Arithmetic order follows the reference exactly (separate multiply and add for o + t*d etc.); the
+// only semantic difference is that bisection stops per ray instead of when the whole batch converged.
+#include "mlp_tile.h"
+
+using namespace nefii;
+
+#define HIP_CHECK_LAUNCH()                       \
+    do {                                         \
+        hipError_t _e = hipGetLastError();       \
+        if (_e != hipSuccess) return (int)_e;    \
+    } while (0)
+
+namespace {
+
+enum Phase : int { PH_DONE = 0, PH_TRACE = 1, PH_SAMPLER = 2, PH_BISECT = 3, PH_MINSDF = 4 };
+enum Kind : int { Q_START = 0, Q_END = 1, Q_MID = 2 };
+
+struct RayState {            // SoA views into the workspace
+    float *t_s, *t_e, *cur_s, *cur_e, *nxt_s, *nxt_e, *t_min, *t_max, *res_s, *res_e, *lo, *hi, *mid;
+    int *flags;              // phase | live/pending bits | counters (packed, see below)
+    float *big;              // [n][n_steps] dense query results
+    unsigned *singles;       // [2n]  (ray << 2 | kind)
+    unsigned *dense;         // [n]   (ray << 1 | which)  which: 0 sampler, 1 min-sdf
+};
+
+// flags layout
+constexpr int F_PHASE = 0x7;          // bits 0-2
+constexpr int F_LIVE_S = 1 << 3, F_LIVE_E = 1 << 4, F_PEND_S = 1 << 5, F_PEND_E = 1 << 6;
+constexpr int F_STEPPED = 1 << 7;     // results belong to a step / back-off (not the initial evaluation)
+constexpr int F_SPH = 1 << 8, F_SAMP = 1 << 9, F_HIT = 1 << 10;
+constexpr int F_IT_SHIFT = 12, F_IT_MASK = 0xFF;     // sphere-tracing iteration / bisection step
+constexpr int F_K_SHIFT = 20, F_K_MASK = 0xF;        // back-off count
+
+__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+
+struct Params {
+    nefii_tracer_params p;
+    int64_t n;
+    const float *o, *d;
+    const uint8_t *obj;
+    const float *lin, *steps;
+    float *out_pts, *out_dist;
+    uint8_t *out_hit;
+    int *counters;           // [rounds][4]
+    RayState s;
+};
+
+// ---- work-list append: block-aggregated ------------------------------------------------------
+// each thread contributes n_single (0..2) single queries and n_dense (0..1) dense rays.
+__device__ __forceinline__ void append_queries(const Params &P, int round, bool qs, bool qe, bool qm, bool qd,
+                                               unsigned ray, unsigned dense_which) {
+    __shared__ int wtot[2][4];
+    __shared__ int base[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long bs = __ballot(qs), be = __ballot(qe), bm = __ballot(qm), bd = __ballot(qd);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int tot_single = __popcll(bs) + __popcll(be) + __popcll(bm);
+    const int tot_dense = __popcll(bd);
+    if (lane == 0) {
+        wtot[0][wave] = tot_single;
+        wtot[1][wave] = tot_dense;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int a = wtot[0][0] + wtot[0][1] + wtot[0][2] + wtot[0][3];
+        int b = wtot[1][0] + wtot[1][1] + wtot[1][2] + wtot[1][3];
+        base[0] = a ? atomicAdd(&P.counters[round * 4 + 0], a) : 0;
+        base[1] = b ? atomicAdd(&P.counters[round * 4 + 1], b) : 0;
+    }
+    __syncthreads();
+    int off_s = base[0], off_d = base[1];
+    for (int w = 0; w < wave; ++w) {
+        off_s += wtot[0][w];
+        off_d += wtot[1][w];
+    }
+    if (qs) P.s.singles[off_s + __popcll(bs & lt)] = (ray << 2) | Q_START;
+    if (qe) P.s.singles[off_s + __popcll(bs) + __popcll(be & lt)] = (ray << 2) | Q_END;
+    if (qm) P.s.singles[off_s + __popcll(bs) + __popcll(be) + __popcll(bm & lt)] = (ray << 2) | Q_MID;
+    if (qd) P.s.dense[off_d + __popcll(bd & lt)] = (ray << 1) | dense_which;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void finish(const Params &P, int64_t r, float dist, bool hit) {
+    const float ox = P.o[r * 3], oy = P.o[r * 3 + 1], oz = P.o[r * 3 + 2];
+    const float dx = P.d[r * 3], dy = P.d[r * 3 + 1], dz = P.d[r * 3 + 2];
+    P.out_dist[r] = dist;
+    P.out_hit[r] = hit ? 1 : 0;
+    P.out_pts[r * 3] = fadd(ox, fmul(dist, dx));
+    P.out_pts[r * 3 + 1] = fadd(oy, fmul(dist, dy));
+    P.out_pts[r * 3 + 2] = fadd(oz, fmul(dist, dz));
+}
+
+// ---- the per-ray state machine ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = r < P.n;
+    bool qs = false, qe = false, qm = false, qd = false;
+    unsigned dense_which = 0;
+    const nefii_tracer_params &tp = P.p;
+    const float thr = tp.sdf_threshold;
+    int fl = 0;
+    if (valid) fl = P.s.flags[r];
+    int ph = fl & F_PHASE;
+
+    if (valid && round == 0) {
+        // bounding-sphere intersection (rend_util.py:200-221) and state initialisation (:107-134)
+        const float ox = P.o[r * 3], oy = P.o[r * 3 + 1], oz = P.o[r * 3 + 2];
+        const float dx = P.d[r * 3], dy = P.d[r * 3 + 1], dz = P.d[r * 3 + 2];
+        const float b = fadd(fadd(fmul(dx, ox), fmul(dy, oy)), fmul(dz, oz));
+        const float nrm = sqrtf(fadd(fadd(fmul(ox, ox), fmul(oy, oy)), fmul(oz, oz)));
+        const float rad = tp.object_bounding_sphere;
+        const float under = fsub(fmul(b, b), fsub(fmul(nrm, nrm), fmul(rad, rad)));
+        const bool sph = under > 0.f;
+        float t0 = 0.f, t1 = 0.f;
+        if (sph) {
+            const float sq = sqrtf(under);
+            t0 = fmaxf(fsub(-sq, b), 0.01f);
+            t1 = fmaxf(fsub(sq, b), 0.01f);
+        }
+        P.s.t_s[r] = t0;
+        P.s.t_e[r] = t1;
+        P.s.t_min[r] = t0;
+        P.s.t_max[r] = t1;
+        P.s.nxt_s[r] = 0.f;
+        P.s.nxt_e[r] = 0.f;
+        P.s.cur_s[r] = 0.f;
+        P.s.cur_e[r] = 0.f;
+        fl = PH_TRACE;
+        if (sph) {
+            fl |= F_SPH | F_LIVE_S | F_LIVE_E | F_PEND_S | F_PEND_E;
+            qs = qe = true;
+        }
+        ph = PH_TRACE;
+        if (sph) {
+            P.s.flags[r] = fl;
+            ph = -1;     // wait for the first evaluation
+        }
+    }
+
+    if (valid && ph == PH_TRACE) {
+        float t_s = P.s.t_s[r], t_e = P.s.t_e[r];
+        float cur_s = P.s.cur_s[r], cur_e = P.s.cur_e[r];
+        float nxt_s = P.s.nxt_s[r], nxt_e = P.s.nxt_e[r];
+        bool live_s = fl & F_LIVE_S, live_e = fl & F_LIVE_E;
+        int it = (fl >> F_IT_SHIFT) & F_IT_MASK, k = (fl >> F_K_SHIFT) & F_K_MASK;
+        if (fl & F_PEND_S) nxt_s = P.s.res_s[r];
+        if (fl & F_PEND_E) nxt_e = P.s.res_e[r];
+        bool wait = false;
+        if (fl & F_STEPPED) {
+            // back-off line search for ends that crossed the surface (ray_tracing.py:170-188)
+            const bool bad_s = nxt_s < 0.f, bad_e = nxt_e < 0.f;
+            if ((bad_s || bad_e) && k < tp.line_step_iters) {
+                const float back = (1.f - tp.line_search_step) / (float)(1 << k);
+                fl &= ~(F_PEND_S | F_PEND_E);
+                if (bad_s) {
+                    t_s = fsub(t_s, fmul(back, cur_s));
+                    qs = true;
+                    fl |= F_PEND_S;
+                }
+                if (bad_e) {
+                    t_e = fadd(t_e, fmul(back, cur_e));
+                    qe = true;
+                    fl |= F_PEND_E;
+                }
+                ++k;
+                wait = true;
+            } else {
+                live_s = live_s && (t_s < t_e);
+                live_e = live_e && (t_s < t_e);
+            }
+        }
+        if (!wait) {
+            // loop top (ray_tracing.py:136-157)
+            cur_s = live_s ? nxt_s : 0.f;
+            if (cur_s <= thr) cur_s = 0.f;
+            cur_e = live_e ? nxt_e : 0.f;
+            if (cur_e <= thr) cur_e = 0.f;
+            live_s = live_s && (cur_s > thr);
+            live_e = live_e && (cur_e > thr);
+            if (it == tp.sphere_tracing_iters || !(live_s || live_e)) {
+                // tracing finished for this ray (ray_tracing.py:43-64)
+                const bool hit = t_s < t_e;
+                fl = (fl & F_SPH) | (hit ? F_HIT : 0) | (live_s ? F_SAMP : 0);
+                P.s.t_s[r] = t_s;
+                P.s.t_e[r] = t_e;
+                if (live_s) {
+                    fl |= PH_SAMPLER;
+                    qd = true;
+                    dense_which = 0;
+                    P.s.flags[r] = fl;
+                    ph = -1;
+                } else {
+                    P.s.mid[r] = t_s;      // dist so far
+                    ph = PH_MINSDF + 1;    // falls through to the post-sampler stage below
+                }
+            } else {
+                ++it;
+                t_s = fadd(t_s, cur_s);
+                t_e = fsub(t_e, cur_e);
+                nxt_s = 0.f;
+                nxt_e = 0.f;
+                k = 0;
+                fl &= ~(F_PEND_S | F_PEND_E);
+                if (live_s) {
+                    qs = true;
+                    fl |= F_PEND_S;
+                }
+                if (live_e) {
+                    qe = true;
+                    fl |= F_PEND_E;
+                }
+                fl |= F_STEPPED;
+                wait = true;
+            }
+        }
+        if (wait) {
+            fl &= ~(F_LIVE_S | F_LIVE_E | (F_IT_MASK << F_IT_SHIFT) | (F_K_MASK << F_K_SHIFT));
+            fl |= (live_s ? F_LIVE_S : 0) | (live_e ? F_LIVE_E : 0) | (it << F_IT_SHIFT) | (k << F_K_SHIFT);
+            P.s.t_s[r] = t_s;
+            P.s.t_e[r] = t_e;
+            P.s.cur_s[r] = cur_s;
+            P.s.cur_e[r] = cur_e;
+            P.s.nxt_s[r] = nxt_s;
+            P.s.nxt_e[r] = nxt_e;
+            P.s.flags[r] = fl;
+            ph = -1;
+        }
+    }
+
+    if (valid && ph == PH_SAMPLER) {
+        // first sign change among the n_steps samples, argmin fallback, bracket (ray_tracing.py:203-255)
+        const int ns = tp.n_steps;
+        const float a = P.s.t_s[r], rng = fsub(P.s.t_e[r], a);
+        const float *v = P.s.big + (size_t)r * ns;
+        int ind = -1, zero = -1, amin = 0;
+        float vmin = v[0];
+        for (int i = 0; i < ns; ++i) {
+            const float x = v[i];
+            if (x < 0.f && ind < 0) ind = i;
+            if (x == 0.f && zero < 0) zero = i;
+            if (x < vmin) {
+                vmin = x;
+                amin = i;
+            }
+        }
+        if (ind < 0) ind = zero >= 0 ? zero : ns - 1;
+        const bool net_hit = v[ind] < 0.f;
+        const bool obj = P.obj[r] != 0;
+        float dist = fadd(a, fmul(P.lin[ind], rng));
+        if (!(obj && net_hit)) dist = fadd(a, fmul(P.lin[amin], rng));
+        fl = (fl & ~F_HIT) | (net_hit ? F_HIT : 0);
+        const bool root = tp.training ? (net_hit && obj) : net_hit;
+        bool go = false;
+        if (root) {
+            const int im = ind > 0 ? ind - 1 : ns - 1;
+            const float hi = fadd(a, fmul(P.lin[ind], rng)), f_hi = v[ind];
+            const float lo = fadd(a, fmul(P.lin[im], rng)), f_lo = v[im];
+            const float mid = fmul(fadd(lo, hi), 0.5f);
+            const bool work = (f_lo > 0.f) && (f_hi < 0.f) && (hi > lo);
+            dist = mid;
+            if (work && tp.n_rootfind_steps > 0) {
+                P.s.lo[r] = lo;
+                P.s.hi[r] = hi;
+                P.s.mid[r] = mid;
+                fl = (fl & ~(F_PHASE | (F_IT_MASK << F_IT_SHIFT))) | PH_BISECT;
+                qm = true;
+                go = true;
+            }
+        }
+        if (go) {
+            P.s.flags[r] = fl;
+            ph = -1;
+        } else {
+            P.s.mid[r] = dist;
+            ph = PH_MINSDF + 1;
+        }
+    }
+
+    if (valid && ph == PH_BISECT) {
+        // one bisection step (ray_tracing.py:264-277), per ray
+        float lo = P.s.lo[r], hi = P.s.hi[r], mid = P.s.mid[r];
+        const float f_mid = P.s.res_s[r];
+        int it = (fl >> F_IT_SHIFT) & F_IT_MASK;
+        if (f_mid > 0.f) lo = mid; else hi = mid;
+        mid = fmul(fadd(lo, hi), 0.5f);
+        ++it;
+        const bool work = fsub(hi, lo) > 1e-6f;
+        P.s.mid[r] = mid;
+        if (work && it < tp.n_rootfind_steps) {
+            P.s.lo[r] = lo;
+            P.s.hi[r] = hi;
+            fl = (fl & ~(F_IT_MASK << F_IT_SHIFT)) | (it << F_IT_SHIFT);
+            P.s.flags[r] = fl;
+            qm = true;
+            ph = -1;
+        } else {
+            ph = PH_MINSDF + 1;
+        }
+    }
+
+    if (valid && ph == PH_MINSDF + 1) {
+        // after tracing / sampler: eval mode returns; training mode handles rays that miss (:71-97)
+        float dist = P.s.mid[r];
+        const bool hit = fl & F_HIT, samp = fl & F_SAMP, sph = fl & F_SPH;
+        const bool obj = P.obj[r] != 0;
+        bool done = true;
+        if (tp.training) {
+            const bool in_m = !hit && obj && !samp, out_m = !obj && !samp;
+            if (in_m || out_m) {
+                if (!sph) {
+                    const float ox = P.o[r * 3], oy = P.o[r * 3 + 1], oz = P.o[r * 3 + 2];
+                    const float dx = P.d[r * 3], dy = P.d[r * 3 + 1], dz = P.d[r * 3 + 2];
+                    dist = -fadd(fadd(fmul(dx, ox), fmul(dy, oy)), fmul(dz, oz));
+                } else {
+                    if (hit && out_m) P.s.t_min[r] = dist;
+                    fl = (fl & ~F_PHASE) | PH_MINSDF;
+                    P.s.flags[r] = fl;
+                    qd = true;
+                    dense_which = 1;
+                    done = false;
+                }
+            }
+        }
+        if (done) {
+            finish(P, r, dist, hit);
+            P.s.flags[r] = (fl & ~F_PHASE) | PH_DONE;
+        }
+        ph = -1;
+    }
+
+    if (valid && ph == PH_MINSDF) {
+        const int ns = tp.n_steps;
+        const float *v = P.s.big + (size_t)r * ns;
+        int amin = 0;
+        float vmin = v[0];
+        for (int i = 1; i < ns; ++i)
+            if (v[i] < vmin) {
+                vmin = v[i];
+                amin = i;
+            }
+        const float tmin = P.s.t_min[r], tmax = P.s.t_max[r];
+        const float dist = fadd(fmul(P.steps[amin], fsub(tmax, tmin)), tmin);
+        finish(P, r, dist, fl & F_HIT);
+        P.s.flags[r] = (fl & ~F_PHASE) | PH_DONE;
+    }
+
+    append_queries(P, round, qs, qe, qm, qd, (unsigned)r, dense_which);
+}
+
+// ---- SDF evaluation of one round's work list -------------------------------------------------
+__global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int round) {
+    __shared__ Lds lds;
+    __shared__ float raw[TILE * 9];
+    __shared__ float *dest[TILE];
+    const int tid = threadIdx.x;
+    const int n_single = P.counters[round * 4 + 0];
+    const int n_dense = P.counters[round * 4 + 1];
+    const int ns = P.p.n_steps;
+    const int64_t total = (int64_t)n_single + (int64_t)n_dense * ns;
+    const int64_t n_tiles = (total + TILE - 1) / TILE;
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    const int Lm1 = m.n_layers - 1;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (tid < TILE) {
+            int64_t q = tile * TILE + tid;
+            float *dst = nullptr;
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (q < total) {
+                int64_t r;
+                float t;
+                if (q < n_single) {
+                    const unsigned e = P.s.singles[q];
+                    r = e >> 2;
+                    const int kind = e & 3;
+                    t = kind == Q_START ? P.s.t_s[r] : (kind == Q_END ? P.s.t_e[r] : P.s.mid[r]);
+                    dst = kind == Q_END ? &P.s.res_e[r] : &P.s.res_s[r];
+                } else {
+                    const int64_t qq = q - n_single;
+                    const int64_t di = qq / ns;
+                    const int i = (int)(qq - di * ns);
+                    const unsigned e = P.s.dense[di];
+                    r = e >> 1;
+                    if (e & 1) {   // min-SDF search depths: steps * (max - min) + min   (ray_tracing.py:319)
+                        const float tmin = P.s.t_min[r], tmax = P.s.t_max[r];
+                        t = fadd(fmul(P.steps[i], fsub(tmax, tmin)), tmin);
+                    } else {       // sampler depths: min + lin * (max - min)            (ray_tracing.py:205)
+                        const float a = P.s.t_s[r];
+                        t = fadd(a, fmul(P.lin[i], fsub(P.s.t_e[r], a)));
+                    }
+                    dst = &P.s.big[(size_t)r * ns + i];
+                }
+                px = fadd(P.o[r * 3], fmul(t, P.d[r * 3]));
+                py = fadd(P.o[r * 3 + 1], fmul(t, P.d[r * 3 + 1]));
+                pz = fadd(P.o[r * 3 + 2], fmul(t, P.d[r * 3 + 2]));
+            }
+            dest[tid] = dst;
+            float *rw = raw + tid * 9;
+            rw[0] = px, rw[1] = py, rw[2] = pz;
+            rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
+        }
+        __syncthreads();
+        encode_tile(m, raw, lds.E, ke);
+        __syncthreads();
+        for (int l = 0; l <= Lm1; ++l) {
+            const nefii_layer &L = m.layer[l];
+            f32x16 acc[4];
+            int ntw;
+            layer_gemm(L, lds.X, lds.E, L.w_fwd, L.n_pad >> 5, acc, ntw);
+            __syncthreads();
+            if (l < Lm1) {
+                NEFII_FOR_ACC(acc, ntw, { lds.X[row * XS + col] = act_fwd(val + L.bias[col], m.act); })
+            } else {
+                NEFII_FOR_ACC(acc, ntw, {
+                    if (col == 0 && dest[row]) *dest[row] = val + L.bias[0];
+                })
+            }
+            __syncthreads();
+        }
+    }
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t carve(RayState &s, char *base, int64_t n, int ns) {
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *p = base ? base + off : nullptr;
+        off += align256(bytes);
+        return p;
+    };
+    float **fl[] = {&s.t_s, &s.t_e, &s.cur_s, &s.cur_e, &s.nxt_s, &s.nxt_e, &s.t_min,
+                    &s.t_max, &s.res_s, &s.res_e, &s.lo, &s.hi, &s.mid};
+    for (auto f : fl) *f = (float *)take(sizeof(float) * n);
+    s.flags = (int *)take(sizeof(int) * n);
+    s.big = (float *)take(sizeof(float) * (size_t)n * ns);
+    s.singles = (unsigned *)take(sizeof(unsigned) * 2 * n);
+    s.dense = (unsigned *)take(sizeof(unsigned) * n);
+    return off;
+}
+
+}  // namespace
+
+extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
+    if (!p) return 0;
+    // initial eval + iters*(step + back-offs) -> sampler -> bisection steps -> min-SDF -> final bookkeeping
+    return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + p->n_rootfind_steps + 1 + 2;
+}
+
+extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *p) {
+    if (!p || n_rays <= 0) return 0;
+    RayState s;
+    size_t bytes = carve(s, nullptr, n_rays, p->n_steps);
+    bytes += align256(sizeof(int) * 4 * (size_t)nefii_trace_max_rounds(p));
+    return bytes;
+}
+
+extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params, const float *origins,
+                                const float *dirs, const uint8_t *object_mask, int64_t n_rays, const float *lin_steps,
+                                const float *minsdf_steps, float *out_points, uint8_t *out_hit, float *out_dists,
+                                void *workspace, size_t workspace_bytes, int32_t *counters, void *stream) {
+    if (!h_sdf || !h_params || !origins || !dirs || !object_mask || !lin_steps || !out_points || !out_hit ||
+        !out_dists || !workspace)
+        return NEFII_E_ARG;
+    if (n_rays <= 0) return 0;
+    if (n_rays >= (1ll << 29)) return NEFII_E_SHAPE;
+    if (h_params->training && !minsdf_steps) return NEFII_E_ARG;
+    if (h_params->n_steps < 2 || h_params->sphere_tracing_iters > 250 || h_params->line_step_iters > 15 ||
+        h_params->n_rootfind_steps > 250)
+        return NEFII_E_SHAPE;
+    if (h_sdf->enc_freqs[0] < 0 || h_sdf->enc_freqs[1] >= 0 || h_sdf->enc_freqs[2] >= 0 || h_sdf->feat_width != 0 ||
+        h_sdf->layer[0].k_x != 0)
+        return NEFII_E_UNSUPPORTED;
+    if (workspace_bytes < nefii_trace_workspace_bytes(n_rays, h_params)) return NEFII_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int rounds = nefii_trace_max_rounds(h_params);
+    Params P;
+    P.p = *h_params;
+    P.n = n_rays;
+    P.o = origins;
+    P.d = dirs;
+    P.obj = object_mask;
+    P.lin = lin_steps;
+    P.steps = minsdf_steps ? minsdf_steps : lin_steps;
+    P.out_pts = out_points;
+    P.out_dist = out_dists;
+    P.out_hit = out_hit;
+    size_t off = carve(P.s, (char *)workspace, n_rays, h_params->n_steps);
+    P.counters = (int *)((char *)workspace + off);
+    hipError_t e = hipMemsetAsync(P.counters, 0, sizeof(int) * 4 * rounds, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(P.s.flags, 0, sizeof(int) * n_rays, st);
+    if (e != hipSuccess) return (int)e;
+    const int adv_blocks = (int)((n_rays + 255) / 256);
+    // eval grid: enough workgroups for the largest possible round, capped at 2 per CU (grid-stride beyond)
+    int64_t max_q = 2 * n_rays > n_rays * h_params->n_steps ? 2 * n_rays : n_rays * (int64_t)h_params->n_steps;
+    int64_t max_tiles = (max_q + TILE - 1) / TILE;
+    const int eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(advance_kernel, dim3(adv_blocks), dim3(256), 0, st, P, r);
+        HIP_CHECK_LAUNCH();
+        if (r + 1 < rounds) {
+            hipLaunchKernelGGL(eval_kernel, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);
+            HIP_CHECK_LAUNCH();
+        }
+    }
+    if (counters) {
+        e = hipMemcpyAsync(counters, P.counters, sizeof(int) * 4 * rounds, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// camera rays (rend_util.py:90-142)
+// ------------------------------------------------------------------------------------------------
+__global__ void camera_rays_kernel(const float *__restrict__ uv, const float *__restrict__ pose,
+                                   const float *__restrict__ K, int batch, int64_t samples, float *__restrict__ dirs,
+                                   float *__restrict__ origins) {
+    const int64_t total = (int64_t)batch * samples;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(i / samples);
+        const float *Kb = K + b * 16, *Pb = pose + b * 16;
+        const float fx = Kb[0], sk = Kb[1], cx = Kb[2], fy = Kb[5], cy = Kb[6];
+        const float u = uv[i * 2], v = uv[i * 2 + 1];
+        // x = (u - cx + cy*sk/fy - sk*v/fy) / fx * z ; y = (v - cy)/fy * z ; z = 1   (lift, :129-142)
+        const float x = __fdiv_rn(fsub(fadd(fsub(u, cx), __fdiv_rn(fmul(cy, sk), fy)), __fdiv_rn(fmul(sk, v), fy)), fx);
+        const float y = __fdiv_rn(fsub(v, cy), fy);
+        float w[3];
+        for (int c = 0; c < 3; ++c) {
+            // world = pose * [x, y, 1, 1]; dirs = world - cam
+            const float wc = fadd(fadd(fadd(fmul(Pb[c * 4], x), fmul(Pb[c * 4 + 1], y)), Pb[c * 4 + 2]), Pb[c * 4 + 3]);
+            w[c] = fsub(wc, Pb[c * 4 + 3]);
+        }
+        const float nrm = fmaxf(sqrtf(fadd(fadd(fmul(w[0], w[0]), fmul(w[1], w[1])), fmul(w[2], w[2]))), 1e-12f);
+        for (int c = 0; c < 3; ++c) {
+            dirs[i * 3 + c] = __fdiv_rn(w[c], nrm);
+            origins[i * 3 + c] = Pb[c * 4 + 3];
+        }
+    }
+}
+
+extern "C" int nefii_camera_rays(const float *uv, const float *pose, const float *intrinsics, int batch,
+                                 int64_t samples, float *out_dirs, float *out_origins, void *stream) {
+    if (!uv || !pose || !intrinsics || !out_dirs || !out_origins) return NEFII_E_ARG;
+    const int64_t total = (int64_t)batch * samples;
+    if (total <= 0) return 0;
+    int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(camera_rays_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, uv, pose, intrinsics, batch,
+                       samples, out_dirs, out_origins);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,374 @@
+"""Tensor-level wrappers and autograd glue over the C ABI (include/nefii_amd.h).
+
+PyTorch is plumbing here: it owns device memory, the stream and the autograd graph between the
+HIP kernels; every hot op below runs in libnefii_hip.so.  There is no eager fallback - without the
+library (or without a GPU tensor) these functions raise.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_ELU, ACT_RELU, ACT_SOFTPLUS100, HEAD_ABS, HEAD_NONE, HEAD_POW2, HEAD_RELU, HEAD_RELU_INIT,
+                   HEAD_SIGMOID, HEAD_TANH01, Mlp, TracerParams)
+
+
+def _round32(v):
+    return (v + 31) // 32 * 32
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('nefii_amd ops need GPU tensors (the hot path has no CPU fallback)')
+    if not t.is_contiguous():
+        raise RuntimeError('tensor must be contiguous')
+    return t.data_ptr()
+
+
+def _f32(t):
+    if t is None:
+        return None
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class LayerSpec:
+    """How one nn.Linear [n_out, k_in] maps onto the kernel's [X | E] input blocks."""
+
+    def __init__(self, n_out, k_in, x_src0=0, x_len=0, e_src0=0, e_len=0, scale=1.0):
+        self.n_out, self.k_in = n_out, k_in
+        self.x_src0, self.x_len, self.e_src0, self.e_len, self.scale = x_src0, x_len, e_src0, e_len, scale
+        self.k_x, self.k_e, self.n_pad = _round32(x_len), _round32(e_len), _round32(n_out)
+
+
+class PackedMLP:
+    """Device-resident packed weights + the nefii_mlp descriptor of one fused MLP."""
+
+    def __init__(self, specs, act, head, enc_freqs, feat_width, device, need_bwd=True):
+        assert 1 <= len(specs) <= _lib.MAX_LAYERS
+        self.specs = specs
+        self.act, self.head = act, head
+        self.enc_freqs = list(enc_freqs)
+        self.feat_width = feat_width
+        self.device = device
+        self.need_bwd = need_bwd
+        self.w_fwd, self.w_bwd, self.bias = [], [], []
+        m = Mlp()
+        m.n_layers, m.act, m.head, m.feat_width = len(specs), act, head, feat_width
+        for i in range(3):
+            m.enc_freqs[i] = self.enc_freqs[i]
+        for l, s in enumerate(specs):
+            k = s.k_x + s.k_e
+            self.w_fwd.append(torch.zeros(k * s.n_pad, device=device, dtype=torch.float32))
+            self.w_bwd.append(torch.zeros(k * s.n_pad, device=device, dtype=torch.float32) if need_bwd else None)
+            self.bias.append(torch.zeros(s.n_pad, device=device, dtype=torch.float32))
+            L = m.layer[l]
+            L.k_x, L.k_e, L.n_out, L.n_pad = s.k_x, s.k_e, s.n_out, s.n_pad
+            L.w_fwd = self.w_fwd[l].data_ptr()
+            L.w_bwd = self.w_bwd[l].data_ptr() if need_bwd else None
+            L.bias = self.bias[l].data_ptr()
+        self.struct = m
+        self.hidden_stride = max(s.n_pad for s in specs)
+        self.packed_version = None
+
+    @property
+    def n_layers(self):
+        return len(self.specs)
+
+    @property
+    def in_width(self):
+        return self.specs[0].k_in
+
+    def pack(self, weights, biases):
+        """weights[l]: effective [n_out, k_in] fp32 GPU tensors (after weight-norm), biases[l]: [n_out]."""
+        lib = _lib.lib()
+        st = _stream()
+        for l, s in enumerate(self.specs):
+            w = _f32(weights[l])
+            b = _f32(biases[l])
+            assert tuple(w.shape) == (s.n_out, s.k_in), (tuple(w.shape), s.n_out, s.k_in)
+            _lib.check(lib.nefii_pack_linear(_ptr(w), _ptr(b), s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0, s.e_len,
+                                             s.scale, _ptr(self.w_fwd[l]),
+                                             _ptr(self.w_bwd[l]) if self.need_bwd else None, _ptr(self.bias[l]), st),
+                       'nefii_pack_linear')
+
+
+def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False):
+    lib = _lib.lib()
+    n = in_a.shape[0]
+    dev = in_a.device
+    n_out = pm.specs[-1].n_out
+    out = torch.empty(n, n_out, device=dev, dtype=torch.float32)
+    hidden = None
+    if want_hidden:
+        hidden = torch.empty(n, pm.specs[-2].n_out, device=dev, dtype=torch.float32)
+    stash = None
+    if want_stash:
+        stash = torch.empty(pm.n_layers, n, pm.hidden_stride, device=dev, dtype=torch.float32)
+    if n > 0:
+        _lib.check(lib.nefii_mlp_forward(ctypes.byref(pm.struct), _ptr(in_a), _ptr(in_b), _ptr(in_c), _ptr(feat), n,
+                                         _ptr(out), n_out, _ptr(hidden), hidden.shape[1] if hidden is not None else 0,
+                                         _ptr(stash), pm.hidden_stride, _stream()), 'nefii_mlp_forward')
+    return out, hidden, stash
+
+
+def mlp_backward(pm, d_out, stash):
+    lib = _lib.lib()
+    n = d_out.shape[0]
+    dz = torch.empty(pm.n_layers, n, pm.hidden_stride, device=d_out.device, dtype=torch.float32)
+    if n > 0:
+        _lib.check(lib.nefii_mlp_backward(ctypes.byref(pm.struct), _ptr(d_out), d_out.shape[1], _ptr(stash),
+                                          pm.hidden_stride, n, _ptr(dz), pm.hidden_stride, _stream()),
+                   'nefii_mlp_backward')
+    return dz
+
+
+def encode_inputs(pm, in_a, in_b, in_c, feat):
+    lib = _lib.lib()
+    n = in_a.shape[0]
+    out = torch.empty(n, pm.in_width, device=in_a.device, dtype=torch.float32)
+    if n > 0:
+        _lib.check(lib.nefii_encode_inputs(ctypes.byref(pm.struct), _ptr(in_a), _ptr(in_b), _ptr(in_c), _ptr(feat), n,
+                                           _ptr(out), pm.in_width, _stream()), 'nefii_encode_inputs')
+    return out
+
+
+class FusedMLPFn(torch.autograd.Function):
+    """y = MLP(PE(a), PE(b), PE(c), feat); differentiable wrt the layer weights and biases only
+    (the raw inputs come from frozen geometry: IDRNetwork.freeze_geometry, Step-2)."""
+
+    @staticmethod
+    def forward(ctx, pm, in_a, in_b, in_c, feat, *wb):
+        L = pm.n_layers
+        ws, bs = wb[:L], wb[L:]
+        pm.pack(ws, bs)
+        need = any(t.requires_grad for t in wb)
+        out, _, stash = mlp_forward(pm, in_a, in_b, in_c, feat, want_stash=need)
+        ctx.pm = pm
+        ctx.save_for_backward(in_a, in_b if in_b is not None else in_a.new_empty(0),
+                              in_c if in_c is not None else in_a.new_empty(0),
+                              feat if feat is not None else in_a.new_empty(0),
+                              stash if stash is not None else in_a.new_empty(0))
+        ctx.has = (in_b is not None, in_c is not None, feat is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        pm = ctx.pm
+        in_a, in_b, in_c, feat, stash = ctx.saved_tensors
+        in_b = in_b if ctx.has[0] else None
+        in_c = in_c if ctx.has[1] else None
+        feat = feat if ctx.has[2] else None
+        L = pm.n_layers
+        d_out = d_out.contiguous()
+        dz = mlp_backward(pm, d_out, stash)
+        x0 = encode_inputs(pm, in_a, in_b, in_c, feat)
+        gw, gb = [], []
+        for l, s in enumerate(pm.specs):
+            dzl = dz[l, :, :s.n_out]
+            if l == 0:
+                xin = x0
+            else:
+                if s.e_len:
+                    raise NotImplementedError('weight gradients of skip layers (geometry is frozen in Step-2)')
+                xin = stash[l - 1, :, :s.k_in]
+            # plain library GEMM (rocBLAS): dW = dZ^T X ; db = column sums
+            g = dzl.t().mm(xin)
+            if s.scale != 1.0:
+                g = g * s.scale
+            gw.append(g)
+            gb.append(dzl.sum(0))
+        return (None, None, None, None, None) + tuple(gw) + tuple(gb)
+
+
+def sdf_value_grad(pm, x, want_feat=False):
+    """(sdf_out [n, n_out_last], feature [n, hidden] or None, d sdf/dx [n,3])."""
+    lib = _lib.lib()
+    n = x.shape[0]
+    dev = x.device
+    n_out = pm.specs[-1].n_out
+    out = torch.empty(n, n_out, device=dev, dtype=torch.float32)
+    grad = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    feat = torch.empty(n, pm.specs[-2].n_out, device=dev, dtype=torch.float32) if want_feat else None
+    if n > 0:
+        nbytes = lib.nefii_sdf_value_grad_workspace_bytes(ctypes.byref(pm.struct), n)
+        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        _lib.check(lib.nefii_sdf_value_grad(ctypes.byref(pm.struct), _ptr(x), n, _ptr(out), n_out, _ptr(feat),
+                                            feat.shape[1] if feat is not None else 0, _ptr(grad), _ptr(ws), _stream()),
+                   'nefii_sdf_value_grad')
+    return out, feat, grad
+
+
+def make_tracer_params(cfg, training):
+    p = TracerParams()
+    p.object_bounding_sphere = cfg.get('object_bounding_sphere', 1.0)
+    p.sdf_threshold = cfg.get('sdf_threshold', 5.0e-5)
+    p.line_search_step = cfg.get('line_search_step', 0.5)
+    p.line_step_iters = cfg.get('line_step_iters', 1)
+    p.sphere_tracing_iters = cfg.get('sphere_tracing_iters', 10)
+    p.n_steps = cfg.get('n_steps', 100)
+    p.n_rootfind_steps = cfg.get('n_rootfind_steps', 8)
+    p.training = 1 if training else 0
+    return p
+
+
+def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_steps=None, want_counters=False):
+    """RayTracing.forward for per-ray origins.  Returns points [n,3], hit (bool [n]), dists [n] (+ counters)."""
+    lib = _lib.lib()
+    n = origins.shape[0]
+    dev = origins.device
+    pts = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    hit = torch.empty(n, device=dev, dtype=torch.uint8)
+    dist = torch.empty(n, device=dev, dtype=torch.float32)
+    rounds = lib.nefii_trace_max_rounds(ctypes.byref(params))
+    counters = torch.zeros(rounds, 4, device=dev, dtype=torch.int32) if want_counters else None
+    if n > 0:
+        nbytes = lib.nefii_trace_workspace_bytes(n, ctypes.byref(params))
+        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        om = object_mask.to(torch.uint8).contiguous()
+        _lib.check(lib.nefii_trace_rays(ctypes.byref(pm_sdf.struct), ctypes.byref(params), _ptr(origins), _ptr(dirs),
+                                        _ptr(om), n, _ptr(lin_steps), _ptr(minsdf_steps), _ptr(pts), _ptr(hit),
+                                        _ptr(dist), _ptr(ws), nbytes, _ptr(counters), _stream()), 'nefii_trace_rays')
+    if want_counters:
+        return pts, hit.bool(), dist, counters
+    return pts, hit.bool(), dist
+
+
+def camera_rays(uv, pose, intrinsics):
+    """uv [B,S,2], pose [B,4,4], K [B,4,4] -> dirs [B,S,3], per-ray origins [B,S,3]."""
+    lib = _lib.lib()
+    B, S, _ = uv.shape
+    dirs = torch.empty(B, S, 3, device=uv.device, dtype=torch.float32)
+    orig = torch.empty(B, S, 3, device=uv.device, dtype=torch.float32)
+    _lib.check(lib.nefii_camera_rays(_ptr(_f32(uv)), _ptr(_f32(pose)), _ptr(_f32(intrinsics)), B, S, _ptr(dirs),
+                                     _ptr(orig), _stream()), 'nefii_camera_rays')
+    return dirs, orig
+
+
+class SGRenderFn(torch.autograd.Function):
+    """render_with_sg for one base material; differentiable wrt lgtSGs, specular, roughness, albedo."""
+
+    @staticmethod
+    def forward(ctx, lgt, spec, rough, albedo, normal, view):
+        lib = _lib.lib()
+        n = normal.shape[0]
+        lgt_c, spec_c, rough_c = _f32(lgt), _f32(spec.expand(1, 3)), _f32(rough)
+        albedo_c, normal_c, view_c = _f32(albedo), _f32(normal), _f32(view)
+        rgb = torch.empty(n, 3, device=normal.device, dtype=torch.float32)
+        srgb, drgb = torch.empty_like(rgb), torch.empty_like(rgb)
+        _lib.check(lib.nefii_sg_render_forward(_ptr(lgt_c), lgt_c.shape[0], _ptr(spec_c), _ptr(rough_c), _ptr(albedo_c),
+                                               _ptr(normal_c), _ptr(view_c), n, _ptr(rgb), _ptr(srgb), _ptr(drgb),
+                                               _stream()), 'nefii_sg_render_forward')
+        ctx.save_for_backward(lgt_c, spec_c, rough_c, albedo_c, normal_c, view_c)
+        ctx.spec_shape = tuple(spec.shape)
+        return rgb, srgb, drgb
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_s, d_d):
+        lib = _lib.lib()
+        lgt, spec, rough, albedo, normal, view = ctx.saved_tensors
+        n = normal.shape[0]
+        g_alb = torch.empty_like(albedo)
+        g_rough = torch.zeros(1, 1, device=albedo.device, dtype=torch.float32)
+        g_spec = torch.zeros(1, 3, device=albedo.device, dtype=torch.float32)
+        g_lgt = torch.zeros_like(lgt)
+        _lib.check(lib.nefii_sg_render_backward(_ptr(lgt), lgt.shape[0], _ptr(spec), _ptr(rough), _ptr(albedo),
+                                                _ptr(normal), _ptr(view), n, _ptr(_f32(d_rgb)), _ptr(_f32(d_s)),
+                                                _ptr(_f32(d_d)), _ptr(g_alb), _ptr(g_rough), _ptr(g_spec), _ptr(g_lgt),
+                                                _stream()), 'nefii_sg_render_backward')
+        if ctx.spec_shape[-1] == 1:
+            g_spec = g_spec.sum(-1, keepdim=True)
+        return g_lgt, g_spec, g_rough, g_alb, None, None
+
+
+class EnvRadianceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lgt, dirs, eps):
+        lib = _lib.lib()
+        lgt_c, dirs_c = _f32(lgt), _f32(dirs)
+        n = dirs_c.shape[0]
+        rgb = torch.empty(n, 3, device=dirs.device, dtype=torch.float32)
+        _lib.check(lib.nefii_env_radiance_forward(_ptr(lgt_c), lgt_c.shape[0], _ptr(dirs_c), n, eps, _ptr(rgb),
+                                                  _stream()), 'nefii_env_radiance_forward')
+        ctx.save_for_backward(lgt_c, dirs_c)
+        ctx.eps = eps
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        lib = _lib.lib()
+        lgt, dirs = ctx.saved_tensors
+        g = torch.zeros_like(lgt)
+        _lib.check(lib.nefii_env_radiance_backward(_ptr(lgt), lgt.shape[0], _ptr(dirs), dirs.shape[0], ctx.eps,
+                                                   _ptr(_f32(d_rgb)), _ptr(g), _stream()), 'nefii_env_radiance_backward')
+        return g, None, None
+
+
+# ---- descriptors of the reference's three networks ------------------------------------------------
+def sdf_specs(cfg, feature_vector_size):
+    """LayerSpec list for ImplicitNetwork (implicit_differentiable_renderer.py:18-83)."""
+    dims = list(cfg['dims'])
+    L = int(cfg.get('multires', 0))
+    d0 = 3 + 6 * L
+    if cfg.get('use_last_as_f', False):
+        full = [d0] + dims + [cfg['d_out']]
+    else:
+        full = [d0] + dims + [cfg['d_out'] + feature_vector_size]
+    skip = tuple(cfg.get('skip_in', ()))
+    specs = []
+    prev_out = None
+    for l in range(len(full) - 1):
+        n_out = full[l + 1] - d0 if (l + 1) in skip else full[l + 1]
+        if l == 0:
+            specs.append(LayerSpec(n_out, d0, e_src0=0, e_len=d0))
+        elif l in skip:
+            specs.append(LayerSpec(n_out, prev_out + d0, x_src0=0, x_len=prev_out, e_src0=prev_out, e_len=d0,
+                                   scale=1.0 / math.sqrt(2)))
+        else:
+            specs.append(LayerSpec(n_out, prev_out, x_src0=0, x_len=prev_out))
+        prev_out = n_out
+    return specs, [L, -1, -1]
+
+
+def radiance_specs(cfg, feature_vector_size):
+    """RenderingNetwork (implicit_differentiable_renderer.py:126-241): layer 0 eats cat[PE(x), PE(v), n, feat]."""
+    mode = cfg.get('mode', 'idr')
+    Lv, Lx = int(cfg.get('multires_view', 0)), int(cfg.get('multires_xyz', 0))
+    if mode == 'idr':
+        enc = [Lx, Lv, 0]
+    elif mode == 'no_view_dir':
+        enc = [Lx, 0, -1]
+    elif mode == 'no_normal':
+        enc = [Lx, Lv, -1]
+    else:
+        raise ValueError(mode)
+    ew = sum(3 + 6 * e for e in enc if e >= 0)
+    dims = [ew + feature_vector_size] + list(cfg['dims']) + [cfg['d_out']]
+    specs = [LayerSpec(dims[1], dims[0], x_src0=ew, x_len=feature_vector_size, e_src0=0, e_len=ew)]
+    for l in range(1, len(dims) - 1):
+        specs.append(LayerSpec(dims[l + 1], dims[l], x_src0=0, x_len=dims[l]))
+    if cfg.get('normalize_output', True):
+        head = HEAD_TANH01
+    elif not cfg.get('clip_output', False):
+        head = HEAD_NONE
+    else:
+        head = {'relu': HEAD_RELU, 'abs': HEAD_ABS, 'relu_init': HEAD_RELU_INIT, 'pow2': HEAD_POW2}[
+            cfg.get('clip_method', 'relu')]
+    return specs, enc, head
+
+
+def material_specs(cfg, feature_vector_size, dim_out):
+    """EnvmapMaterialNetwork.diffuse_albedo_layers (sg_envmap_material.py:92-103): cat[PE(x), feat] -> ELU MLP."""
+    Lx = int(cfg.get('multires', 0))
+    ew = 3 + 6 * Lx
+    dims = [ew + feature_vector_size] + list(cfg['dims']) + [dim_out]
+    specs = [LayerSpec(dims[1], dims[0], x_src0=ew, x_len=feature_vector_size, e_src0=0, e_len=ew)]
+    for l in range(1, len(dims) - 1):
+        specs.append(LayerSpec(dims[l + 1], dims[l], x_src0=0, x_len=dims[l]))
+    return specs, [Lx, -1, -1]

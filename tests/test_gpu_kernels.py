@@ -1,0 +1,299 @@
+"""GPU parity tests, kernel level: every HIP entry point (called through the C ABI via nefii_amd.ops)
+against the CPU oracle on the same seeded inputs, and against the reference-generated golden vectors.
+
+Tolerances: the kernels compute in fp32 (f32-input MFMA = exact fma chains) - differences to the CPU
+oracle are summation-order / libm rounding only; the north-star tolerance (1e-3 relative L2 on RGB and
+albedo) is asserted in tests/test_gpu_renderer.py."""
+import math
+
+import pytest
+import torch
+
+from nefii_amd import synthetic as syn
+from oracle import nets, renderer as orr, shading, tracer
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def ball_points(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, generator=g)
+    return x / x.norm(dim=-1, keepdim=True) * torch.rand(n, 1, generator=g) ** (1 / 3)
+
+
+def build_sdf(mc, sd):
+    from nefii_amd import ops
+    specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
+    pm = ops.PackedMLP(specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, enc, 0, DEV)
+    ws, bs = [], []
+    for l in range(len(specs)):
+        w, b = nets.linear_params(sd, 'implicit_network.lin%d' % l)
+        ws.append(w.to(DEV))
+        bs.append(b.to(DEV))
+    pm.pack(ws, bs)
+    return pm
+
+
+@pytest.mark.parametrize('name,hidden,n', [('physg', 64, 1000), ('conf', 64, 333), ('neus', 64, 257), ('physg', 512, 512),
+                                           ('conf', 512, 100), ('neus', None, 96)])
+def test_sdf_forward_and_gradient(name, hidden, n):
+    from nefii_amd import ops
+    mc = syn.model_conf(name, hidden=hidden)
+    sd = syn.make_state_dict(mc, seed=0, bumpy=0.02 if hidden == 64 else 0.004)
+    pm = build_sdf(mc, sd)
+    x = ball_points(n, 3)
+    ref = nets.sdf_forward(sd, mc['implicit_network'], x)
+    gref = nets.sdf_gradient(sd, mc['implicit_network'], x)
+    xd = x.to(DEV)
+    out, hid, _ = ops.mlp_forward(pm, xd, None, None, None, want_hidden=True)
+    nout = pm.specs[-1].n_out
+    assert (out.cpu() - ref[:, :nout]).abs().max().item() < 2e-5
+    assert rel_l2(out, ref[:, :nout]) < 1e-5
+    if mc['implicit_network'].get('use_last_as_f'):
+        assert rel_l2(hid, ref[:, 1:]) < 1e-5
+    out2, feat, grad = ops.sdf_value_grad(pm, xd, want_feat=True)
+    assert torch.equal(out2, out)
+    assert rel_l2(grad, gref) < 2e-5
+    assert rel_l2(feat, hid) < 1e-7
+
+
+@pytest.mark.parametrize('name,hidden,n', [('physg', 64, 500), ('conf', 64, 301), ('conf', 512, 200), ('physg', 512, 64)])
+def test_radiance_and_material_mlp(name, hidden, n):
+    from nefii_amd import ops
+    mc = syn.model_conf(name, hidden=hidden)
+    sd = syn.make_state_dict(mc, seed=1)
+    F = mc['feature_vector_size']
+    g = torch.Generator().manual_seed(5)
+    x = ball_points(n, 7)
+    v = torch.randn(n, 3, generator=g)
+    v = v / v.norm(dim=-1, keepdim=True)
+    nrm = torch.randn(n, 3, generator=g)
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+    feat = torch.randn(n, F, generator=g) * 0.3 if F > 0 else None
+    w1 = torch.rand(n, 3, generator=g)
+    # ---- radiance
+    keys = [k for k in sd if k.startswith('rendering_network')]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    rgb_ref = nets.radiance_forward(sd, mc['rendering_network'], x, nrm, v, feat)
+    (rgb_ref * w1).sum().backward()
+    specs, enc, head = ops.radiance_specs(mc['rendering_network'], F)
+    pm = ops.PackedMLP(specs, ops.ACT_RELU, head, enc, F, DEV)
+    L = len(specs)
+    gv = [sd['rendering_network.lin%d.weight_v' % l].detach().to(DEV).requires_grad_(True) for l in range(L)]
+    gg = [sd['rendering_network.lin%d.weight_g' % l].detach().to(DEV).requires_grad_(True) for l in range(L)]
+    gb = [sd['rendering_network.lin%d.bias' % l].detach().to(DEV).requires_grad_(True) for l in range(L)]
+    ws = [torch._weight_norm(gv[l], gg[l], 0) for l in range(L)]
+    rgb = ops.FusedMLPFn.apply(pm, x.to(DEV), v.to(DEV), nrm.to(DEV), feat.to(DEV) if F else None, *ws, *gb)
+    assert rel_l2(rgb, rgb_ref) < 2e-5
+    (rgb * w1.to(DEV)).sum().backward()
+    for l in range(L):
+        assert rel_l2(gv[l].grad, sd['rendering_network.lin%d.weight_v' % l].grad) < 2e-4, l
+        assert rel_l2(gg[l].grad, sd['rendering_network.lin%d.weight_g' % l].grad) < 2e-4, l
+        assert rel_l2(gb[l].grad, sd['rendering_network.lin%d.bias' % l].grad) < 2e-4, l
+    # ---- material
+    mcfg = mc['envmap_material_network']
+    lp = 'envmap_material_network.diffuse_albedo_layers'
+    keys = [k for k in sd if k.startswith(lp)]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    mat = nets.material_forward(sd, mcfg, x, feat)
+    tgt = (mat['sg_diffuse_albedo'] * w1).sum()
+    if mat['sg_roughness'].shape[0] == n:
+        tgt = tgt + mat['sg_roughness'].sum()
+    tgt.backward()
+    dim_out = 4 if mcfg.get('roughness_mlp') else 3
+    specs, enc = ops.material_specs(mcfg, F, dim_out)
+    pm = ops.PackedMLP(specs, ops.ACT_ELU, ops.HEAD_SIGMOID, enc, F, DEV)
+    L = len(specs)
+    W = [sd['%s.%d.weight' % (lp, 2 * l)].detach().to(DEV).requires_grad_(True) for l in range(L)]
+    Bz = [sd['%s.%d.bias' % (lp, 2 * l)].detach().to(DEV).requires_grad_(True) for l in range(L)]
+    y = ops.FusedMLPFn.apply(pm, x.to(DEV), None, None, feat.to(DEV) if F else None, *W, *Bz)
+    assert rel_l2(y[:, :3], mat['sg_diffuse_albedo']) < 2e-5
+    t2 = (y[:, :3] * w1.to(DEV)).sum()
+    if dim_out == 4:
+        rough = (1 - 0.089) * y[:, 3:4] + 0.089
+        assert rel_l2(rough, mat['sg_roughness']) < 2e-5
+        t2 = t2 + rough.sum()
+    t2.backward()
+    for l in range(L):
+        assert rel_l2(W[l].grad, sd['%s.%d.weight' % (lp, 2 * l)].grad) < 2e-4, l
+        assert rel_l2(Bz[l].grad, sd['%s.%d.bias' % (lp, 2 * l)].grad) < 2e-4, l
+
+
+def test_camera_rays(golden):
+    from nefii_amd import ops
+    g = golden('camera')
+    dirs, orig = ops.camera_rays(g['uv'].to(DEV), g['pose'].to(DEV), g['intrinsics'].to(DEV))
+    assert (dirs.cpu() - g['dirs']).abs().max().item() < 3e-7
+    assert torch.equal(orig.cpu()[0, 0], g['cam'][0])
+    # multi-batch
+    inp, _ = syn.make_inputs(64, image_hw=(64, 64), focal=90.0, cam_pos=(1.0, 0.5, -2.0), seed=9)
+    uv = torch.cat([g['uv'][:, :64], inp['uv']], 0)
+    pose = torch.cat([g['pose'], inp['pose']], 0)
+    K = torch.cat([g['intrinsics'], inp['intrinsics']], 0)
+    d_ref, c_ref = orr.camera_rays(uv, pose, K)
+    d, o = ops.camera_rays(uv.to(DEV), pose.to(DEV), K.to(DEV))
+    assert (d.cpu() - d_ref).abs().max().item() < 3e-7
+    assert torch.equal(o.cpu()[:, 0], c_ref)
+
+
+def run_gpu_trace(mc, sd, o, d, om, training, steps):
+    from nefii_amd import ops
+    pm = build_sdf(mc, sd)
+    tp = ops.make_tracer_params(mc['ray_tracer'], training)
+    lin = torch.linspace(0, 1, steps=tp.n_steps).to(DEV)
+    st = steps.to(DEV) if steps is not None else torch.rand(tp.n_steps).to(DEV)
+    return ops.trace_rays(pm, tp, o.to(DEV).contiguous(), d.to(DEV).contiguous(), om.to(DEV), lin, st,
+                          want_counters=True)
+
+
+def compare_trace(sdf, o, d, got, ref_hit, ref_dists, what):
+    pts, hit, dist, _ = got
+    hit, dist, pts = hit.cpu(), dist.cpu(), pts.cpu()
+    # knife-edge rays may flip on fp32 summation-order noise; bound them
+    flips = (hit != ref_hit).sum().item()
+    assert flips <= max(1, int(0.004 * hit.numel())), (what, flips)
+    same = hit == ref_hit
+    h = ref_hit & same
+    if h.any():
+        err = (dist[h] - ref_dists[h]).abs()
+        assert err.max().item() < 2e-5, (what, err.max().item())
+        assert err.median().item() < 2e-6, (what, err.median().item())
+    m = (~ref_hit) & same
+    if m.any():   # miss rays: argmin over a flat minimum - compare the SDF value reached
+        a = sdf(o[m] + dist[m].unsqueeze(-1) * d[m])
+        b = sdf(o[m] + ref_dists[m].unsqueeze(-1) * d[m])
+        assert (a - b).abs().max().item() < 2e-5, what
+        assert ((dist[m] - ref_dists[m]).abs() < 2e-5).float().mean().item() > 0.95, what
+    assert (pts - (o + dist.unsqueeze(-1) * d)).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize('tag,name,hidden,bumpy', [('smooth_h64', 'physg', 64, 0.0), ('bumpy_h64', 'physg', 64, 0.03),
+                                                   ('bumpy_h512', 'physg', 512, 0.004), ('neus_h64', 'neus', 64, 0.02)])
+def test_tracer_golden(golden, tag, name, hidden, bumpy):
+    g = golden('tracer_' + tag)
+    mc = syn.model_conf(name, hidden=hidden)
+    sd = syn.make_state_dict(mc, seed=0, bumpy=bumpy)
+    sdf = lambda x: nets.sdf_forward(sd, mc['implicit_network'], x)[:, 0]
+    d = g['dirs'][0]
+    o = g['cam'].expand(d.shape[0], 3).contiguous()
+    for mode in ('eval', 'train'):
+        got = run_gpu_trace(mc, sd, o, d, g['object_mask'], mode == 'train', g.get('minsdf_steps'))
+        compare_trace(sdf, o, d, got, g[mode + '_hit'], g[mode + '_dists'], (tag, mode))
+    steps2 = g['minsdf_steps2'] if g['minsdf_steps2'].numel() else torch.rand(100)
+    got = run_gpu_trace(mc, sd, g['o2'], g['d2'], torch.ones(g['o2'].shape[0], dtype=torch.bool), True, steps2)
+    compare_trace(sdf, g['o2'], g['d2'], got, g['sec_hit'], g['sec_dists'], (tag, 'secondary'))
+
+
+@pytest.mark.parametrize('hidden,bumpy,n', [(64, 0.03, 5000), (64, 0.0, 3000), (512, 0.004, 1500)])
+def test_tracer_vs_oracle_and_counts(hidden, bumpy, n):
+    """Larger seeded batches incl. rays that miss the bounding sphere, ragged tile counts, masked-out rays;
+    the kernel's per-round query counters must equal the oracle's SDF evaluation counts."""
+    mc = syn.model_conf('physg', hidden=hidden)
+    sd = syn.make_state_dict(mc, seed=2, bumpy=bumpy)
+    sdf = lambda x: nets.sdf_forward(sd, mc['implicit_network'], x)[:, 0]
+    g = torch.Generator().manual_seed(11)
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * (1.5 + torch.rand(n, 1, generator=g))
+    tgt = torch.randn(n, 3, generator=g) * 0.45
+    d = tgt - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    om = torch.rand(n, generator=g) < 0.8
+    steps = torch.rand(100, generator=g)
+    for training in (False, True):
+        ref = tracer.trace(sdf, o, d, om, mc['ray_tracer'], training, steps)
+        got = run_gpu_trace(mc, sd, o, d, om, training, steps)
+        compare_trace(sdf, o, d, got, ref['hit'], ref['dists'], (hidden, bumpy, training))
+        cnt = got[3].cpu().long()
+        gpu_evals = (cnt[:, 0] + cnt[:, 1] * 100).sum().item()
+        c = ref['counters']
+        cpu_evals = sum(c.get(k, 0) for k in ('sphere_trace', 'sampler', 'bisect', 'min_sdf'))
+        assert abs(gpu_evals - cpu_evals) <= 0.01 * cpu_evals, (gpu_evals, cpu_evals)
+
+
+def test_tracer_empty_and_tiny():
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=0)
+    o = torch.tensor([[0., 0., 3.]])
+    d = torch.tensor([[0., 0., -1.]])
+    pts, hit, dist, _ = run_gpu_trace(mc, sd, o, d, torch.ones(1, dtype=torch.bool), False, None)
+    assert hit.item() and abs(pts[0, 2].item() - (3 - dist.item())) < 1e-6
+    e = torch.zeros(0, 3)
+    pts, hit, dist, _ = run_gpu_trace(mc, sd, e, e, torch.ones(0, dtype=torch.bool), False, None)
+    assert pts.shape == (0, 3) and hit.numel() == 0
+
+
+def test_sg_render_golden(golden):
+    from nefii_amd import ops
+    g = golden('sg_render')
+    t = {k: v.to(DEV) for k, v in g.items()}
+    albedo = t['albedo'].clone().requires_grad_(True)
+    rough = t['rough'].clone().requires_grad_(True)
+    spec = t['spec'].clone().requires_grad_(True)
+    lgt = t['lgt'].clone().requires_grad_(True)
+    rgb, srgb, drgb = ops.SGRenderFn.apply(lgt, spec, rough, albedo, t['normal'], t['view'])
+    assert rel_l2(rgb, g['sg_rgb']) < 2e-5
+    assert rel_l2(srgb, g['sg_specular_rgb']) < 2e-5
+    assert rel_l2(drgb, g['sg_diffuse_rgb']) < 2e-5
+    (rgb * t['wts']).sum().backward()
+    assert rel_l2(albedo.grad, g['g_albedo']) < 1e-4
+    assert rel_l2(rough.grad, g['g_rough']) < 1e-3
+    assert rel_l2(spec.grad, g['g_spec']) < 1e-4
+    assert rel_l2(lgt.grad, g['g_lgt']) < 1e-3
+
+
+def test_sg_render_white_specular_and_sizes():
+    from nefii_amd import ops
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=4)
+    for n in (1, 77, 4000):
+        g = torch.Generator().manual_seed(n)
+        nrm = torch.randn(n, 3, generator=g)
+        nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+        view = nrm + 0.5 * torch.randn(n, 3, generator=g)
+        view = view / view.norm(dim=-1, keepdim=True)
+        alb = torch.rand(n, 3, generator=g)
+        wts = torch.rand(n, 3, generator=g)
+        P = {}
+        for dev in ('cpu', DEV):
+            lgt = sd['envmap_material_network.lgtSGs'].clone().to(dev).requires_grad_(True)
+            s_raw = torch.tensor([[0.3]], device=dev, requires_grad=True)
+            r_raw = torch.tensor([[1.7]], device=dev, requires_grad=True)
+            spec = 0.16 * torch.sigmoid(s_raw).expand(-1, 3) ** 2
+            rough = (1 - 0.089) * torch.sigmoid(r_raw) + 0.089
+            a = alb.clone().to(dev).requires_grad_(True)
+            if dev == 'cpu':
+                out = shading.sg_closed_form(lgt, spec, rough, a, nrm, view)['sg_rgb']
+            else:
+                out = ops.SGRenderFn.apply(lgt, spec, rough, a, nrm.to(dev), view.to(dev))[0]
+            (out * wts.to(dev)).sum().backward()
+            P[dev] = (out, lgt.grad, s_raw.grad, r_raw.grad, a.grad)
+        for x, y in zip(P[DEV], P['cpu']):
+            assert rel_l2(x, y) < 1e-3, n
+        assert rel_l2(P[DEV][0], P['cpu'][0]) < 2e-5
+
+
+def test_env_radiance():
+    from nefii_amd import ops
+    mc = syn.model_conf('conf', hidden=64)
+    sd = syn.make_state_dict(mc, seed=4)
+    g = torch.Generator().manual_seed(3)
+    d = torch.randn(999, 3, generator=g)
+    d = d / d.norm(dim=-1, keepdim=True)
+    w = torch.rand(999, 3, generator=g)
+    lgt_c = sd['envmap_material_network.lgtSGs'].clone().requires_grad_(True)
+    ref = shading.env_radiance(lgt_c, d)
+    (ref * w).sum().backward()
+    lgt_g = sd['envmap_material_network.lgtSGs'].clone().to(DEV).requires_grad_(True)
+    out = ops.EnvRadianceFn.apply(lgt_g, d.to(DEV), 1e-8)
+    (out * w.to(DEV)).sum().backward()
+    assert rel_l2(out, ref) < 1e-5
+    assert rel_l2(lgt_g.grad, lgt_c.grad) < 1e-4

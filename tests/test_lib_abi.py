@@ -1,0 +1,53 @@
+"""CPU-side checks of the C-ABI boundary: the shared library builds for gfx950, loads, and exports every
+symbol include/nefii_amd.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, 'include', 'nefii_amd.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(nefii_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_builds_loads_and_exports_header_symbols():
+    from nefii_amd import _lib, build
+    build.build(verbose=False)
+    lib = _lib.lib()
+    syms = header_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), 'libnefii_hip.so does not export ' + s
+        assert s in _lib.SIGNATURES, 'no ctypes signature for ' + s
+    assert lib.nefii_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    from nefii_amd import _lib
+    # nefii_layer: 4 x int32 + 3 pointers; nefii_mlp: 8 x int32 + 12 layers
+    assert ctypes.sizeof(_lib.Layer) == 16 + 3 * 8
+    assert ctypes.sizeof(_lib.Mlp) == 32 + 12 * ctypes.sizeof(_lib.Layer)
+    assert ctypes.sizeof(_lib.TracerParams) == 32
+
+
+def test_host_side_argument_checks_need_no_gpu():
+    from nefii_amd import _lib
+    lib = _lib.lib()
+    p = _lib.TracerParams()
+    p.n_steps, p.sphere_tracing_iters, p.line_step_iters, p.n_rootfind_steps = 100, 10, 3, 32
+    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 32 + 1 + 2
+    assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) > 4096 * 100 * 4
+    assert lib.nefii_trace_rays(None, None, None, None, None, 0, None, None, None, None, None, None, 0, None, None) == -1
+    assert lib.nefii_pack_linear(None, None, 1, 1, 0, 0, 0, 0, 1.0, None, None, None, None) == -1
+
+
+def test_ops_fail_loudly_without_gpu_tensor():
+    import torch
+    from nefii_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.camera_rays(torch.zeros(1, 4, 2), torch.eye(4)[None], torch.eye(4)[None])
