@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py - training rays/s of the Step-2 material-optimisation step on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W            (N>1: launched by torch.distributed.run)
+
+Step = one full Step-2 iteration on a synthetic batch already resident in HBM: forward (camera rays, HIP
+sphere tracer, SDF value/normal, radiance + material MLPs, SG shading) + IDRLoss + backward + both Adam
+updates (idr_train.py:750-776).  N=1 workload = BASELINE.json configs[1]: "robot"-like scene, physg.conf
+model, num_pixels 4096, 128 SG lobes, indirect OFF.  N>1: every rank gets its own 4096-pixel slice of a
+4096*N-pixel global batch (the dataset's contiguous patch split) and gradients are averaged by one RCCL
+all-reduce per step: weak scaling, `value` = all ranks' primary rays / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  `roofline`: the SDF-evaluation kernel of the tracer (>90 % of the step),
+achieved = algorithmic FLOPs of all its launches (queries x 2 x MACs of the unpadded SDF MLP) / their summed
+duration, measured live with HIP events on the launch stream in an extra un-timed step; peak = dense f32
+MFMA (the kernel computes in exact fp32; see DESIGN.md for why 16-bit operands cannot be used in the tracer).
+`cpu_baseline`: the CPU oracle (kind "port": a PyTorch-CPU restatement of the reference, pinned against the
+reference's own outputs) running the same step on a bounded sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def sdf_flops_per_eval(specs):
+    return sum(2 * s.k_in * s.n_out for s in specs)
+
+
+def cpu_baseline(workload, sample_pixels, steps, warmup):
+    """Oracle training step on the host cores, bounded sample of the workload (rank 0 only)."""
+    from nefii_amd import synthetic as syn
+    from oracle import renderer as orr
+    w = dict(syn.WORKLOADS[workload])
+    mc = syn.model_conf(w['model'])
+    sd = syn.make_state_dict(mc, seed=0)
+    lc = syn.loss_conf(w['model'])
+    inp, gt = syn.make_inputs(sample_pixels, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
+    params = [v for k, v in sd.items() if not k.startswith('implicit')]
+    for v in params:
+        v.requires_grad_(True)
+    opt = torch.optim.Adam(params, lr=5e-4)
+    R = orr.Renderer(sd, mc, training=True)
+    n_rays = inp['uv'].shape[1] * (w['num_rays'] if w['num_rays'] > 0 else 1)
+    best = None
+    for i in range(warmup + steps):
+        t0 = time.perf_counter()
+        out = R.forward(inp)
+        lo = orr.idr_loss(out, gt, lc)
+        opt.zero_grad()
+        lo['loss'].backward()
+        opt.step()
+        dt = time.perf_counter() - t0
+        if i >= warmup:
+            best = dt if best is None else min(best, dt)
+    return {'value': n_rays / best, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d of the workload\'s pixels, best of %d steps after %d warm-up, torch threads = all host '
+                      'cores' % (sample_pixels, steps, warmup)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='cfg2')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-pixels', type=int, default=512)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d'
+                             % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group(backend='nccl', device_id=dev)
+
+    from nefii_amd import _lib, conf, synthetic as syn
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from nefii_amd.training.step import TrainStep
+    import ctypes
+    lib = _lib.lib()
+
+    w = dict(syn.WORKLOADS[args.workload])
+    mc = syn.model_conf(w['model'])
+    sd = syn.make_state_dict(mc, seed=0)
+    lc = syn.loss_conf(w['model'])
+    torch.manual_seed(1234 + rank)
+    model = IDRNetwork(conf.from_dict(mc))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    model.freeze_geometry()
+    model.train()
+    # weak scaling: global batch = num_pixels * world, contiguous per-rank slice of the patch list
+    inp, gt = syn.make_inputs(w['num_pixels'] * world, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'],
+                              seed=1, rank=rank, world_size=world)
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    gt = {'rgb': gt.to(dev)}
+    rays_per_rank = inp['uv'].shape[1] * (w['num_rays'] if w['num_rays'] > 0 else 1)
+    step = TrainStep(model, lc, world_size=world)
+
+    for _ in range(args.warmup):
+        step(inp, gt)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, lo = step(inp, gt)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = rays_per_rank * world / (elapsed / args.steps)
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel: one extra, un-timed step with per-launch HIP events
+        model.ray_tracer.collect_counters = True
+        lib.nefii_trace_profile_enable(1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        out, lo = step(inp, gt)
+        torch.cuda.synchronize()
+        prof_step_ms = (time.perf_counter() - t1) * 1e3
+        eval_ms, n_eval, span_ms = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+        lib.nefii_trace_profile_read(ctypes.byref(eval_ms), ctypes.byref(n_eval), ctypes.byref(span_ms))
+        lib.nefii_trace_profile_enable(0)
+        cnt = model.ray_tracer.last_counters.cpu().long()
+        n_steps = model.ray_tracer.n_steps
+        queries = int((cnt[:, 0] + cnt[:, 1] * n_steps).sum().item())
+        launches = int(((cnt[:, 0] + cnt[:, 1]) > 0).sum().item())
+        f_eval = sdf_flops_per_eval(model.implicit_network.specs)
+        achieved = queries * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
+        hit_frac = out['network_object_mask'].float().mean().item()
+        roofline = {'bound': 'mfma', 'kernel': 'eval_kernel (fused SDF MLP over the tracer work list)',
+                    'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                    'flops_per_sdf_eval': f_eval, 'sdf_evals_per_step': queries,
+                    'sdf_evals_per_primary_ray': queries / rays_per_rank,
+                    'nonempty_launches_per_step': launches, 'launches_per_step': n_eval.value,
+                    'kernel_ms_per_step': eval_ms.value, 'tracer_span_ms': span_ms.value,
+                    'profiled_step_ms': prof_step_ms, 'hit_fraction': hit_frac}
+        result = {
+            'metric': 'training rays/sec (Step-2 material opt)', 'value': value, 'unit': 'rays/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%s: robot-like synthetic scene (geometric-init SDF 8x512), physg.conf model, '
+                                   'num_pixels=%d per GPU, 128 SG lobes, indirect OFF, frozen geometry, '
+                                   'fwd+IDRLoss+bwd+2xAdam' % (args.workload, w['num_pixels']),
+                       'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
+                       'loss': float(lo['loss'].item())},
+            'roofline': roofline,
+        }
+        if not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(args.workload, args.cpu_sample_pixels, steps=3, warmup=1)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

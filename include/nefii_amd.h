@@ -126,6 +126,12 @@ int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params
                      float *out_points, uint8_t *out_hit, float *out_dists,
                      void *workspace, size_t workspace_bytes, int32_t *counters, void *stream);
 
+/* Measurement hooks (bench.py): when enabled, nefii_trace_rays brackets every SDF-evaluation launch with HIP
+ * events on the launch stream; nefii_trace_profile_read returns the summed launch durations (ms), the number
+ * of launches and the span of the last trace call, and clears the record.  Off by default. */
+int nefii_trace_profile_enable(int on);
+int nefii_trace_profile_read(double *h_eval_ms, int *h_n_eval, double *h_span_ms);
+
 /* rend_util.get_camera_params + lift (rend_util.py:90-142): uv [B,S,2], pose [B,4,4], intrinsics [B,4,4]
  * -> unit ray dirs [B,S,3] and per-ray origins [B,S,3] (camera centre broadcast). */
 int nefii_camera_rays(const float *uv, const float *pose, const float *intrinsics, int batch, int64_t samples,

@@ -59,6 +59,8 @@ SIGNATURES = {
     'nefii_trace_max_rounds': (I, [ctypes.POINTER(TracerParams)]),
     'nefii_trace_rays': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(TracerParams), P, P, P, I64, P, P, P, P, P, P,
                              ctypes.c_size_t, P, P]),
+    'nefii_trace_profile_enable': (I, [I]),
+    'nefii_trace_profile_read': (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I), ctypes.POINTER(ctypes.c_double)]),
     'nefii_camera_rays': (I, [P, P, P, I, I64, P, P, P]),
     'nefii_sg_render_forward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P]),
     'nefii_sg_render_backward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P, P, P, P, P]),

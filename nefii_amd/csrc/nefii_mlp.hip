@@ -70,12 +70,12 @@ __device__ __forceinline__ void load_tile_inputs(const nefii_mlp &m, const float
                                                  const float *in_c, const float *feat, int64_t base, int64_t n,
                                                  float *raw, Lds &lds) {
     const int tid = threadIdx.x;
-    if (tid < TILE * 9) {
-        const int p = tid / 9, c = tid - 9 * p, which = c / 3;
+    for (int i = tid; i < TILE * 9; i += WG) {     // 288 entries > 256 threads
+        const int p = i / 9, c = i - 9 * p, which = c / 3;
         const float *src = which == 0 ? in_a : (which == 1 ? in_b : in_c);
         int64_t idx = base + p;
         if (idx >= n) idx = n - 1;
-        raw[tid] = (src && m.enc_freqs[which] >= 0) ? src[idx * 3 + (c - 3 * which)] : 0.f;
+        raw[i] = (src && m.enc_freqs[which] >= 0) ? src[idx * 3 + (c - 3 * which)] : 0.f;
     }
     const int F = m.feat_width;
     const int kx0 = m.layer[0].k_x;

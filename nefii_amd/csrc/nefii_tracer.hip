@@ -11,6 +11,8 @@
 // Ray state is a few floats per ray in global memory (L2 resident); all heavy traffic is the MLP.
 // Arithmetic order follows the reference exactly (separate multiply and add for o + t*d etc.); the
 // only semantic difference is that bisection stops per ray instead of when the whole batch converged.
+#include <vector>
+
 #include "mlp_tile.h"
 
 using namespace nefii;
@@ -454,6 +456,59 @@ size_t carve(RayState &s, char *base, int64_t n, int ns) {
 
 }  // namespace
 
+// ---- optional per-launch timing (HIP events on the launch stream; off by default) ------------------
+namespace {
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> ev;      // pairs: [2i] before, [2i+1] after each eval launch
+    size_t used = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;   // whole nefii_trace_rays call
+    bool have_span = false;
+} g_prof;
+hipEvent_t prof_event() {
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        g_prof.ev.push_back(e);
+    }
+    return g_prof.ev[g_prof.used++];
+}
+}  // namespace
+
+extern "C" int nefii_trace_profile_enable(int on) {
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    g_prof.have_span = false;
+    return 0;
+}
+
+// Sum of the eval-kernel launch durations recorded since enable (ms), their count, and the span of the
+// last nefii_trace_rays call (ms).  Synchronises on the recorded events.
+extern "C" int nefii_trace_profile_read(double *eval_ms, int *n_eval, double *span_ms) {
+    double tot = 0.0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]);
+        if (e != hipSuccess) return (int)e;
+        tot += ms;
+    }
+    if (eval_ms) *eval_ms = tot;
+    if (n_eval) *n_eval = (int)(g_prof.used / 2);
+    if (span_ms) {
+        *span_ms = 0.0;
+        if (g_prof.have_span) {
+            (void)hipEventSynchronize(g_prof.t1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, g_prof.t0, g_prof.t1);
+            *span_ms = ms;
+        }
+    }
+    g_prof.used = 0;
+    return 0;
+}
+
 extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     if (!p) return 0;
     // initial eval + iters*(step + back-offs) -> sampler -> bisection steps -> min-SDF -> final bookkeeping
@@ -509,13 +564,31 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
     int64_t max_q = 2 * n_rays > n_rays * h_params->n_steps ? 2 * n_rays : n_rays * (int64_t)h_params->n_steps;
     int64_t max_tiles = (max_q + TILE - 1) / TILE;
     const int eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
+    if (g_prof.on) {
+        if (!g_prof.t0) {
+            (void)hipEventCreate(&g_prof.t0);
+            (void)hipEventCreate(&g_prof.t1);
+        }
+        (void)hipEventRecord(g_prof.t0, st);
+    }
     for (int r = 0; r < rounds; ++r) {
         hipLaunchKernelGGL(advance_kernel, dim3(adv_blocks), dim3(256), 0, st, P, r);
         HIP_CHECK_LAUNCH();
         if (r + 1 < rounds) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (g_prof.on) {
+                e0 = prof_event();
+                e1 = prof_event();
+                (void)hipEventRecord(e0, st);
+            }
             hipLaunchKernelGGL(eval_kernel, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);
             HIP_CHECK_LAUNCH();
+            if (g_prof.on) (void)hipEventRecord(e1, st);
         }
+    }
+    if (g_prof.on) {
+        (void)hipEventRecord(g_prof.t1, st);
+        g_prof.have_span = true;
     }
     if (counters) {
         e = hipMemcpyAsync(counters, P.counters, sizeof(int) * 4 * rounds, hipMemcpyDeviceToDevice, st);

@@ -1,0 +1,65 @@
+"""RayTracing with the reference's constructor and forward signature (code/model/ray_tracing.py:6-101),
+executed by the round-based HIP tracer (csrc/nefii_tracer.hip)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class RayTracing(nn.Module):
+    def __init__(self, object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=1,
+                 sphere_tracing_iters=10, n_steps=100, n_rootfind_steps=8):
+        super().__init__()
+        self.object_bounding_sphere = object_bounding_sphere
+        self.sdf_threshold = sdf_threshold
+        self.sphere_tracing_iters = sphere_tracing_iters
+        self.line_step_iters = line_step_iters
+        self.line_search_step = line_search_step
+        self.n_steps = n_steps
+        self.n_rootfind_steps = n_rootfind_steps
+        self._net = None
+        self._lin = None
+        self.last_counters = None
+        self.collect_counters = False
+        self.minsdf_steps_override = None     # parity tests replay the reference's captured uniforms
+
+    def bind(self, implicit_network):
+        """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
+        object.__setattr__(self, '_net', implicit_network)
+
+    def _cfg(self):
+        return dict(object_bounding_sphere=self.object_bounding_sphere, sdf_threshold=self.sdf_threshold,
+                    line_search_step=self.line_search_step, line_step_iters=self.line_step_iters,
+                    sphere_tracing_iters=self.sphere_tracing_iters, n_steps=self.n_steps,
+                    n_rootfind_steps=self.n_rootfind_steps)
+
+    def forward(self, sdf, cam_loc, object_mask, ray_directions):
+        """cam_loc [B,3], ray_directions [B,S,3], object_mask [B*S] -> (points [B*S,3], hit [B*S], dists [B*S]).
+
+        ``sdf``: the reference passes ``lambda x: implicit_network(x)[:, 0]``.  A Python closure cannot run
+        inside a kernel, so the tracer uses the ImplicitNetwork it was bound to (IDRNetwork binds it); passing
+        the ImplicitNetwork itself as ``sdf`` also works.  Any other callable without a bound network raises."""
+        net = sdf if hasattr(sdf, 'packed') else self._net
+        if net is None:
+            raise RuntimeError('RayTracing: no ImplicitNetwork bound; call ray_tracer.bind(implicit_network) or '
+                               'pass the network as `sdf`')
+        B, S, _ = ray_directions.shape
+        dirs = ops._f32(ray_directions).reshape(-1, 3)
+        origins = ops._f32(cam_loc).unsqueeze(1).expand(B, S, 3).reshape(-1, 3).contiguous()
+        dev = dirs.device
+        if self._lin is None or self._lin.device != dev or self._lin.numel() != self.n_steps:
+            self._lin = torch.linspace(0, 1, steps=self.n_steps).to(dev)     # ray_tracing.py:203
+        steps = None
+        if self.training:
+            if self.minsdf_steps_override is not None:
+                steps = self.minsdf_steps_override.to(dev)
+            else:
+                # drawn on the host exactly like minimal_sdf_points (:316); always drawn (the reference draws only
+                # when some ray needs the search, a data-dependent host sync this build avoids)
+                steps = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
+        params = ops.make_tracer_params(self._cfg(), self.training)
+        res = ops.trace_rays(net.packed(), params, origins, dirs, object_mask.reshape(-1), self._lin, steps,
+                             want_counters=self.collect_counters)
+        if self.collect_counters:
+            self.last_counters = res[3]
+        return res[0], res[1], res[2]
