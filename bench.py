@@ -39,6 +39,9 @@ def cpu_baseline(workload, sample_pixels, steps, warmup):
     """Oracle training step on the host cores, bounded sample of the workload (rank 0 only)."""
     from nefii_amd import synthetic as syn
     from oracle import renderer as orr
+    # these small GEMMs stop scaling early: on the 2x64-core EPYC 9575F GPU host 16 threads was the measured
+    # optimum (1 thread 253, 8: 848, 16: 1029, 32: 853, 64: 396, 128: 151 rays/s; tools/cpu_threads_probe.py)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     w = dict(syn.WORKLOADS[workload])
     mc = syn.model_conf(w['model'])
     sd = syn.make_state_dict(mc, seed=0)
@@ -62,8 +65,9 @@ def cpu_baseline(workload, sample_pixels, steps, warmup):
         if i >= warmup:
             best = dt if best is None else min(best, dt)
     return {'value': n_rays / best, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d of the workload\'s pixels, best of %d steps after %d warm-up, torch threads = all host '
-                      'cores' % (sample_pixels, steps, warmup)}
+            'sample': '%d of the workload\'s pixels, best of %d steps after %d warm-up, %d torch threads (measured '
+                      'optimum on the host; the reference itself pins 1 thread, idr_train.py:26)'
+                      % (sample_pixels, steps, warmup, torch.get_num_threads())}
 
 
 def main():

@@ -84,6 +84,9 @@ def lib():
         raise NefiiLibraryError(
             'libnefii_hip.so is not built (%s missing). Run `python -m nefii_amd.build`. '
             'There is no CPU/PyTorch fallback for the hot path.' % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; it must be the one (and only) HIP runtime in the process,
+    # so make sure torch has loaded it before our library resolves the same SONAME.
+    import torch  # noqa: F401
     try:
         handle = ctypes.CDLL(LIB_PATH)
     except OSError as e:          # e.g. libamdhip64 absent

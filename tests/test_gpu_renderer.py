@@ -48,7 +48,11 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what=''):
             # rays that miss take the argmin of 100 samples (flat minimum: the winner flips on rounding noise);
             # compare them on hit rays only, misses through sdf_output (the value reached) with a loose bound
             h = rnet[agree]
-            assert rel_l2(a[h], b[h]) < 1e-4, (what, k, rel_l2(a[h], b[h]))
+            if k == 'points':
+                assert rel_l2(a[h], b[h]) < 1e-4, (what, k, rel_l2(a[h], b[h]))
+            else:      # |sdf| <= 5e-5 on the surface: absolute comparison
+                assert (a[h] - b[h]).abs().max().item() < 2e-4, (what, k)
+                assert (a[h] - b[h]).abs().median().item() < 2e-6, (what, k)
             if k == 'sdf_output' and (~h).any():
                 assert (a[~h] - b[~h]).abs().max().item() < 5e-3, (what, k)
                 assert ((a[~h] - b[~h]).abs() < 2e-5).float().mean().item() > 0.9, (what, k)
