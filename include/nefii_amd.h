@@ -155,6 +155,29 @@ int nefii_env_radiance_forward(const float *lgtSGs, int n_lobes, const float *di
 int nefii_env_radiance_backward(const float *lgtSGs, int n_lobes, const float *dirs, int64_t n, float eps,
                                 const float *d_rgb, float *g_lgtSGs, void *stream);
 
+/* The three importance-sampled directions per surface point and their 3x3 pdf table for multiple importance
+ * sampling (cos_sampling :128, brdf_sampling :61, mix_sg_sampling :168 and the pdf_fn_* of
+ * path_tracing_render.py; table as :1312-1325).  uniforms [n,7] = (cos r1 r2 | ggx r1 r2 | mix r0 r1 r2) in the
+ * reference's draw order; roughness [n].  Outputs: wi [3,n,3], own_pdf [3,n] (clamped at 1e-6),
+ * pdf_table [3,n,3] (row = direction, column = pdf of strategy j for that direction). */
+int nefii_mis_sample(const float *lgtSGs, int n_lobes, const float *roughness, const float *normal, const float *view,
+                     const float *uniforms, int64_t n, float *wi, float *own_pdf, float *pdf_table, void *stream);
+
+/* Per-point MC shading sum of pt_render_diff_shadow_indirect_mlp (diff_geo=False), path_tracing_render.py:1406-1476:
+ * light [3,n,3] = sum of light SGs along wi (nefii_env_radiance_forward with eps 1e-6), visibility [3,n],
+ * indirect [3,n,3] radiance at secondary hits; specular [3] global, roughness [n], albedo [n,3]. */
+int nefii_mc_shade_forward(const float *specular, const float *roughness, const float *albedo, const float *normal,
+                           const float *view, const float *wi, const float *own_pdf, const float *pdf_table,
+                           const float *light, const float *visibility, const float *indirect, int64_t n,
+                           float *rgb, float *spec_rgb, float *diff_rgb, void *stream);
+/* Gradients wrt light [3,n,3], indirect [3,n,3], albedo [n,3], roughness [n] (overwritten) and, when non-NULL,
+ * the global specular [3] (accumulated atomically into a zero-initialised buffer). */
+int nefii_mc_shade_backward(const float *specular, const float *roughness, const float *albedo, const float *normal,
+                            const float *view, const float *wi, const float *own_pdf, const float *pdf_table,
+                            const float *light, const float *visibility, const float *indirect, int64_t n,
+                            const float *d_rgb, const float *d_spec, const float *d_diff, float *g_light,
+                            float *g_indirect, float *g_albedo, float *g_roughness, float *g_specular, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,9 @@ SIGNATURES = {
     'nefii_sg_render_backward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P, P, P, P, P]),
     'nefii_env_radiance_forward': (I, [P, I, P, I64, F, P, P]),
     'nefii_env_radiance_backward': (I, [P, I, P, I64, F, P, P, P]),
+    'nefii_mis_sample': (I, [P, I, P, P, P, P, I64, P, P, P, P]),
+    'nefii_mc_shade_forward': (I, [P] * 11 + [I64, P, P, P, P]),
+    'nefii_mc_shade_backward': (I, [P] * 11 + [I64] + [P] * 9),
 }
 
 _lib = None

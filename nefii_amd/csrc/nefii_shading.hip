@@ -501,3 +501,313 @@ extern "C" int nefii_env_radiance_backward(const float *lgtSGs, int n_lobes, con
     HIP_CHECK_LAUNCH();
     return 0;
 }
+
+// ================================================================================================
+// Monte-Carlo direct + near-field indirect shading (conf.conf default: pt_render_indirect_mlp)
+//   samplers + pdfs   code/model/path_tracing_render.py:12-271
+//   MIS table         code/model/path_tracing_render.py:1290-1325
+//   shading sum       code/model/path_tracing_render.py:1406-1476
+// ================================================================================================
+namespace {
+
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return {x, y, z}; }
+__device__ __forceinline__ float dot3(const F3 &a, const F3 &b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+__device__ __forceinline__ F3 cross3(const F3 &a, const F3 &b) {
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+// rotate local coordinates (z = axis n) to world space (rotate_to_normal, :12-33)
+__device__ __forceinline__ F3 to_world(const F3 &l, const F3 &n) {
+    const F3 up = n.x > 0.9f ? f3(0.f, 1.f, 0.f) : f3(1.f, 0.f, 0.f);
+    F3 t = cross3(up, n);
+    const float inv = 1.f / (sqrtf(dot3(t, t)) + TINY);
+    t = f3(t.x * inv, t.y * inv, t.z * inv);
+    const F3 s = cross3(t, n);
+    return {(l.x * t.x + l.y * s.x) + l.z * n.x, (l.x * t.y + l.y * s.y) + l.z * n.y, (l.x * t.z + l.y * s.z) + l.z * n.z};
+}
+__device__ __forceinline__ F3 polar(float theta, float phi) {
+    const float st = sinf(theta);
+    return {st * cosf(phi), st * sinf(phi), cosf(theta)};
+}
+__device__ __forceinline__ float pdf_cos_fn(const F3 &wi, const F3 &n) { return fmaxf(dot3(wi, n), TINY) / PI_F; }
+__device__ __forceinline__ float pdf_ggx_fn(const F3 &wi, const F3 &n, const F3 &v, float rough) {
+    F3 h = f3(wi.x + v.x, wi.y + v.y, wi.z + v.z);
+    const float nh = sqrtf(dot3(h, h));
+    h = f3(h.x / nh, h.y / nh, h.z / nh);
+    if (isnan(h.x)) h.x = n.x;          // wi = -v: half vector undefined -> normal (:110-111)
+    if (isnan(h.y)) h.y = n.y;
+    if (isnan(h.z)) h.z = n.z;
+    const float c = fmaxf(dot3(h, n), TINY);
+    const float r4 = (rough * rough) * (rough * rough);
+    const float root = c * c + (1.f - c * c) / r4;
+    const float pdf_h = c / (PI_F * r4 * root * root);
+    const float hv = fmaxf(dot3(h, v), TINY);
+    return pdf_h / (4.f * hv);
+}
+
+constexpr int MIS_THREADS = 128;
+constexpr int MIS_MAX_LOBES = 256;
+
+// One thread per surface point; the light lobes (axis, |lambda|, energy, c_k) are staged once per block in LDS.
+__global__ __launch_bounds__(MIS_THREADS) void mis_sample_kernel(const float *__restrict__ lgt, int M,
+                                                                 const float *__restrict__ rough,
+                                                                 const float *__restrict__ normal,
+                                                                 const float *__restrict__ view,
+                                                                 const float *__restrict__ uni, int64_t n,
+                                                                 float *__restrict__ wi_out,      // [3][n][3]
+                                                                 float *__restrict__ own_pdf,     // [3][n]
+                                                                 float *__restrict__ pdf_tab) {   // [3][n][3]
+    __shared__ float L[MIS_MAX_LOBES * 6];     // ax(3), lam, energy, c
+    for (int m = threadIdx.x; m < M; m += blockDim.x) {
+        const float *s = lgt + m * 7;
+        const float inv = 1.f / (sqrtf((s[0] * s[0] + s[1] * s[1]) + s[2] * s[2]) + TINY);
+        const float lam = fabsf(s[3]);
+        L[m * 6 + 0] = s[0] * inv;
+        L[m * 6 + 1] = s[1] * inv;
+        L[m * 6 + 2] = s[2] * inv;
+        L[m * 6 + 3] = lam;
+        L[m * 6 + 4] = (fabsf(s[4]) + fabsf(s[5])) + fabsf(s[6]);
+        L[m * 6 + 5] = lam / (2.f * PI_F * (1.f - expf(-2.f * lam)));
+    }
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const F3 nn = f3(normal[p * 3], normal[p * 3 + 1], normal[p * 3 + 2]);
+    const F3 vv = f3(view[p * 3], view[p * 3 + 1], view[p * 3 + 2]);
+    const float r = rough[p];
+    const float *u = uni + p * 7;
+    // --- cosine-weighted (:128-156)
+    const float th0 = acosf(sqrtf(1.f - u[0]));
+    const F3 w0 = to_world(polar(th0, 2.f * PI_F * u[1]), nn);
+    const float p0 = cosf(th0) / PI_F;
+    // --- GGX half-vector (:61-103)
+    const float th1 = atanf((r * r) * sqrtf(u[2] / (1.f - u[2])));
+    const F3 h1 = to_world(polar(th1, 2.f * PI_F * u[3]), nn);
+    const float vh = dot3(vv, h1);
+    const F3 w1 = f3(2.f * vh * h1.x - vv.x, 2.f * vh * h1.y - vv.y, 2.f * vh * h1.z - vv.z);
+    const float p1 = pdf_ggx_fn(w1, nn, vv, r);
+    // --- SG mixture (:168-242): lobe k ~ alpha, then a direction around its axis
+    float wsum = 0.f;
+    for (int m = 0; m < M; ++m) wsum += L[m * 6 + 4] * fmaxf(dot3(nn, f3(L[m * 6], L[m * 6 + 1], L[m * 6 + 2])), TINY);
+    int k = -1;
+    float cum = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const float a = (L[m * 6 + 4] * fmaxf(dot3(nn, f3(L[m * 6], L[m * 6 + 1], L[m * 6 + 2])), TINY)) / wsum;
+        cum += a;
+        float right = cum, left = cum - a;
+        if (m == M - 1) right = 1.f;
+        if (m == 0) left = 0.f;
+        if (k < 0 && u[4] >= left && u[4] < right) k = m;
+    }
+    if (k < 0) k = 0;
+    const F3 axk = f3(L[k * 6], L[k * 6 + 1], L[k * 6 + 2]);
+    const float lamk = L[k * 6 + 3], ck = L[k * 6 + 5];
+    const float th2 = acosf(1.f / lamk * logf(fmaxf(1.f - lamk * u[5] / (2.f * PI_F * ck), TINY)) + 1.f);
+    const F3 w2 = to_world(polar(th2, 2.f * PI_F * u[6]), axk);
+    // mixture pdf of all three directions in one sweep over the lobes (:245-271)
+    float pm0 = 0.f, pm1 = 0.f, pm2 = 0.f;
+    for (int m = 0; m < M; ++m) {
+        const F3 ax = f3(L[m * 6], L[m * 6 + 1], L[m * 6 + 2]);
+        const float a = (L[m * 6 + 4] * fmaxf(dot3(nn, ax), TINY)) / wsum;
+        const float ac = a * L[m * 6 + 5], lam = L[m * 6 + 3];
+        pm0 += ac * expf(lam * (dot3(w0, ax) - 1.f));
+        pm1 += ac * expf(lam * (dot3(w1, ax) - 1.f));
+        pm2 += ac * expf(lam * (dot3(w2, ax) - 1.f));
+    }
+    const F3 w[3] = {w0, w1, w2};
+    const float own[3] = {fmaxf(p0, TINY), fmaxf(p1, TINY), fmaxf(pm2, TINY)};
+    const float pmix[3] = {pm0, pm1, pm2};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float *wo = wi_out + ((size_t)i * n + p) * 3;
+        wo[0] = w[i].x, wo[1] = w[i].y, wo[2] = w[i].z;
+        own_pdf[(size_t)i * n + p] = own[i];
+        float *t = pdf_tab + ((size_t)i * n + p) * 3;
+        t[0] = i == 0 ? own[0] : pdf_cos_fn(w[i], nn);
+        t[1] = i == 1 ? own[1] : pdf_ggx_fn(w[i], nn, vv, r);
+        t[2] = i == 2 ? own[2] : pmix[i];
+    }
+}
+
+// GGX D * G for one sample as a function of roughness (T = float or Dual<1>)
+template <class T>
+__device__ __forceinline__ T ggx_dg(const T &rough, float nh, float d1, float d2) {
+    const T a2 = rough * rough;
+    const T a4 = a2 * a2;
+    const T root = nh * nh + (1.f - nh * nh) / a4;
+    const T D = 1.f / (PI_F * a4 * root * root);
+    const T k = (rough + 1.f) * (rough + 1.f) / 8.f;
+    const T g = (d1 / (d1 * (1.f - k) + k + TINY)) * (d2 / (d2 * (1.f - k) + k + TINY));
+    return D * g;
+}
+
+struct McGeom {      // per (point, sample) constants
+    float nh, P, d1, d2, den, K;
+};
+
+__device__ __forceinline__ McGeom mc_geom(const F3 &nn, const F3 &vv, const F3 &wi, float own, const float *tab) {
+    McGeom g;
+    F3 h = f3(wi.x + vv.x, wi.y + vv.y, wi.z + vv.z);
+    const float inv = 1.f / (sqrtf(dot3(h, h)) + TINY);
+    h = f3(h.x * inv, h.y * inv, h.z * inv);
+    g.nh = fmaxf(dot3(nn, h), 0.f);
+    const float vh = fmaxf(dot3(vv, h), 0.f);
+    g.P = exp2f(-(5.55473f * vh + 6.8316f) * vh);
+    g.d1 = fmaxf(dot3(vv, nn), 0.f);
+    g.d2 = fmaxf(dot3(wi, nn), 0.f);
+    g.den = 4.f * g.d1 * g.d2 + TINY;
+    const float den_w = fmaxf((tab[0] * tab[0] + tab[1] * tab[1]) + tab[2] * tab[2], TINY);
+    const float weight = own * own / den_w;                      // power heuristic (:390-401)
+    const float cosn = fmaxf(dot3(wi, nn), 0.f);
+    g.K = weight * cosn / own;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void mc_shade_fwd_kernel(const float *__restrict__ spec, const float *__restrict__ rough,
+                                                           const float *__restrict__ albedo,
+                                                           const float *__restrict__ normal,
+                                                           const float *__restrict__ view, const float *__restrict__ wi,
+                                                           const float *__restrict__ own_pdf,
+                                                           const float *__restrict__ pdf_tab,
+                                                           const float *__restrict__ light,      // [3][n][3]
+                                                           const float *__restrict__ vis,        // [3][n]
+                                                           const float *__restrict__ indirect,   // [3][n][3]
+                                                           int64_t n, float *__restrict__ rgb, float *__restrict__ srgb,
+                                                           float *__restrict__ drgb) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const F3 nn = f3(normal[p * 3], normal[p * 3 + 1], normal[p * 3 + 2]);
+    const F3 vv = f3(view[p * 3], view[p * 3 + 1], view[p * 3 + 2]);
+    const float r = rough[p];
+    float s_acc[3] = {0.f, 0.f, 0.f}, d_acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const size_t q = (size_t)i * n + p;
+        const F3 w = f3(wi[q * 3], wi[q * 3 + 1], wi[q * 3 + 2]);
+        const McGeom g = mc_geom(nn, vv, w, own_pdf[q], pdf_tab + q * 3);
+        const float dg = ggx_dg<float>(r, g.nh, g.d1, g.d2);
+        const float v = vis[q];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float F = spec[c] + (1.f - spec[c]) * g.P;
+            const float fs = F * dg / g.den;
+            const float Lc = light[q * 3 + c] * v + (1.f - v) * indirect[q * 3 + c];
+            s_acc[c] += fmaxf(g.K * Lc * fs, 0.f);
+            d_acc[c] += fmaxf(g.K * Lc * (albedo[p * 3 + c] / PI_F), 0.f);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        srgb[p * 3 + c] = s_acc[c];
+        drgb[p * 3 + c] = d_acc[c];
+        rgb[p * 3 + c] = s_acc[c] + d_acc[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void mc_shade_bwd_kernel(
+    const float *__restrict__ spec, const float *__restrict__ rough, const float *__restrict__ albedo,
+    const float *__restrict__ normal, const float *__restrict__ view, const float *__restrict__ wi,
+    const float *__restrict__ own_pdf, const float *__restrict__ pdf_tab, const float *__restrict__ light,
+    const float *__restrict__ vis, const float *__restrict__ indirect, int64_t n, const float *__restrict__ d_rgb,
+    const float *__restrict__ d_s, const float *__restrict__ d_d, float *__restrict__ g_light,
+    float *__restrict__ g_ind, float *__restrict__ g_alb, float *__restrict__ g_rough, float *__restrict__ g_spec) {
+    __shared__ float scratch[4 * 3];
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float gsp[3] = {0.f, 0.f, 0.f};
+    if (p < n) {
+        const F3 nn = f3(normal[p * 3], normal[p * 3 + 1], normal[p * 3 + 2]);
+        const F3 vv = f3(view[p * 3], view[p * 3 + 1], view[p * 3 + 2]);
+        const Dual<1> r = seed<1>(rough[p], 0);
+        float ga[3] = {0.f, 0.f, 0.f};
+        float gr = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const size_t q = (size_t)i * n + p;
+            const F3 w = f3(wi[q * 3], wi[q * 3 + 1], wi[q * 3 + 2]);
+            const McGeom g = mc_geom(nn, vv, w, own_pdf[q], pdf_tab + q * 3);
+            const Dual<1> dg = ggx_dg<Dual<1>>(r, g.nh, g.d1, g.d2);
+            const float v = vis[q];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float go = d_rgb ? d_rgb[p * 3 + c] : 0.f;
+                const float gs_up = go + (d_s ? d_s[p * 3 + c] : 0.f);
+                const float gd_up = go + (d_d ? d_d[p * 3 + c] : 0.f);
+                const float F = spec[c] + (1.f - spec[c]) * g.P;
+                const float fs = F * dg.v / g.den;
+                const float Lc = light[q * 3 + c] * v + (1.f - v) * indirect[q * 3 + c];
+                const float a_pi = albedo[p * 3 + c] / PI_F;
+                const float gs = (g.K * Lc * fs > 0.f) ? gs_up : 0.f;
+                const float gd = (g.K * Lc * a_pi > 0.f) ? gd_up : 0.f;
+                const float dL = gs * g.K * fs + gd * g.K * a_pi;
+                g_light[q * 3 + c] = dL * v;
+                g_ind[q * 3 + c] = dL * (1.f - v);
+                ga[c] += gd * g.K * Lc / PI_F;
+                const float dfs = gs * g.K * Lc;
+                gr += dfs * F * dg.d[0] / g.den;
+                gsp[c] += dfs * (1.f - g.P) * dg.v / g.den;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g_alb[p * 3 + c] = ga[c];
+        g_rough[p] = gr;
+    }
+    if (g_spec) {
+        block_sum<3>(gsp, scratch);
+        if (threadIdx.x == 0) {
+            atomicAdd(&g_spec[0], gsp[0]);
+            atomicAdd(&g_spec[1], gsp[1]);
+            atomicAdd(&g_spec[2], gsp[2]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int nefii_mis_sample(const float *lgtSGs, int n_lobes, const float *roughness, const float *normal,
+                                const float *view, const float *uniforms, int64_t n, float *wi, float *own_pdf,
+                                float *pdf_table, void *stream) {
+    if (!lgtSGs || !roughness || !normal || !view || !uniforms || !wi || !own_pdf || !pdf_table) return NEFII_E_ARG;
+    if (n <= 0) return 0;
+    if (n_lobes <= 0 || n_lobes > MIS_MAX_LOBES) return NEFII_E_SHAPE;
+    hipLaunchKernelGGL(mis_sample_kernel, dim3((unsigned)((n + MIS_THREADS - 1) / MIS_THREADS)), dim3(MIS_THREADS), 0,
+                       (hipStream_t)stream, lgtSGs, n_lobes, roughness, normal, view, uniforms, n, wi, own_pdf,
+                       pdf_table);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nefii_mc_shade_forward(const float *specular, const float *roughness, const float *albedo,
+                                      const float *normal, const float *view, const float *wi, const float *own_pdf,
+                                      const float *pdf_table, const float *light, const float *visibility,
+                                      const float *indirect, int64_t n, float *rgb, float *spec_rgb, float *diff_rgb,
+                                      void *stream) {
+    if (!specular || !roughness || !albedo || !normal || !view || !wi || !own_pdf || !pdf_table || !light ||
+        !visibility || !indirect || !rgb || !spec_rgb || !diff_rgb)
+        return NEFII_E_ARG;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mc_shade_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       specular, roughness, albedo, normal, view, wi, own_pdf, pdf_table, light, visibility, indirect, n,
+                       rgb, spec_rgb, diff_rgb);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nefii_mc_shade_backward(const float *specular, const float *roughness, const float *albedo,
+                                       const float *normal, const float *view, const float *wi, const float *own_pdf,
+                                       const float *pdf_table, const float *light, const float *visibility,
+                                       const float *indirect, int64_t n, const float *d_rgb, const float *d_spec,
+                                       const float *d_diff, float *g_light, float *g_indirect, float *g_albedo,
+                                       float *g_roughness, float *g_specular, void *stream) {
+    if (!specular || !roughness || !albedo || !normal || !view || !wi || !own_pdf || !pdf_table || !light ||
+        !visibility || !indirect || !g_light || !g_indirect || !g_albedo || !g_roughness)
+        return NEFII_E_ARG;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mc_shade_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       specular, roughness, albedo, normal, view, wi, own_pdf, pdf_table, light, visibility, indirect, n,
+                       d_rgb, d_spec, d_diff, g_light, g_indirect, g_albedo, g_roughness, g_specular);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,81 @@
+"""pt_render_indirect_mlp with the reference's signature (code/model/path_tracing_render.py:1255-1487,
+diff_geo=False): 3-sample MIS direct lighting + near-field indirect light from the radiance network at
+secondary hits, on HIP kernels.
+
+Per call: nefii_mis_sample (3 directions + 3x3 pdf table per point) -> nefii_trace_rays on the 3N secondary
+rays (one batched trace, the reference's speed_first path :1332-1354) -> SDF value/normal + radiance MLP at the
+secondary hits (get_visibility_and_indirect_light :2109-2166; visibility = 1 - hit) -> light-SG sum along the
+sampled directions -> nefii_mc_shade (GGX + Lambert, power-heuristic weights).  The reference's extra SDF
+evaluation of all 3N light points (:2112) has no consumer when diff_geo=False and is not executed.
+
+Of the reference's 12 renderer variants only this one (and its _memsave alias) is selected by a shipped conf."""
+import torch
+
+from .. import ops
+
+TINY_NUMBER = 1e-6
+
+
+def draw_uniforms(n, device):
+    """The 7 uniforms per point in the reference's call order (cos r1 r2 | ggx r1 r2 | mix r0 r1 r2),
+    each a separate torch.rand like the reference (:138-139, :73-74, :201, :219-220)."""
+    u = [torch.rand(n, 1, device=device) for _ in range(4)]
+    u.append(torch.rand(n, 1, 1, device=device).reshape(n, 1))
+    u += [torch.rand(n, 1, device=device) for _ in range(2)]
+    return torch.cat(u, dim=1)
+
+
+def pt_render_indirect_mlp(lgtSGs, specular_reflectance, roughness, diffuse_albedo, normal, viewdirs, points, model,
+                           blending_weights=None, diffuse_rgb=None):
+    """lgtSGs [M,7]; specular_reflectance [1,3]; roughness [...,1]; diffuse_albedo/normal/viewdirs/points [...,3];
+    model: the IDRNetwork.  Returns the reference's dict: sg_rgb, sg_specular_rgb, sg_diffuse_rgb,
+    sg_diffuse_albedo, secondary_points [3,...,3], secondary_mask [3,...,1], secondary_dir [3,...,3]."""
+    if blending_weights is not None or diffuse_rgb is not None:
+        raise NotImplementedError('blending weights / precomputed diffuse (no shipped conf)')
+    shape = list(normal.shape[:-1])
+    n3 = normal.reshape(-1, 3)
+    v3 = viewdirs.reshape(-1, 3)
+    p3 = points.reshape(-1, 3)
+    a3 = diffuse_albedo.reshape(-1, 3)
+    r1 = roughness.reshape(-1, 1)
+    n = n3.shape[0]
+    dev = n3.device
+    with torch.no_grad():
+        uniforms = getattr(model, 'uniforms_override', None)
+        if uniforms is None:
+            uniforms = draw_uniforms(n, dev)
+        else:
+            uniforms = uniforms.to(dev)
+        wi, own, tab = ops.mis_sample(lgtSGs, r1, n3, v3, uniforms)
+        # secondary rays: origin = surface point, one batched trace of the 3N rays
+        origins = p3.detach().unsqueeze(0).expand(3, n, 3).reshape(-1, 1, 3)
+        sec_pts, sec_hit, sec_dist = model.ray_tracer(sdf=model.implicit_network,
+                                                      cam_loc=origins.reshape(-1, 3),
+                                                      object_mask=torch.ones(3 * n, dtype=torch.bool, device=dev),
+                                                      ray_directions=wi.reshape(-1, 1, 3))
+        vis = 1.0 - sec_hit.to(torch.float32)                                    # [3n]
+        hidx = torch.nonzero(sec_hit).flatten()
+    # indirect radiance at secondary hits (gradient reaches the radiance network: not detached in the reference)
+    indirect = torch.zeros(3 * n, 3, device=dev)
+    if hidx.numel() > 0:
+        with torch.no_grad():
+            hp = sec_pts.index_select(0, hidx)
+            _, feats, g = model.implicit_network.value_feature_gradient(hp)
+            hn = g / (torch.norm(g, dim=-1, keepdim=True) + 1e-6)
+            hv = -wi.reshape(-1, 3).index_select(0, hidx)
+            hv = hv / (torch.norm(hv, dim=-1, keepdim=True) + 1e-6)
+        idr = model.rendering_network(hp, hn, hv, feats)
+        indirect = indirect.index_put((hidx,), idr)
+    light = ops.EnvRadianceFn.apply(lgtSGs, wi.reshape(-1, 3), TINY_NUMBER)      # [3n,3]
+    rgb, srgb, drgb = ops.McShadeFn.apply(specular_reflectance, r1, a3, n3, v3, wi, own, tab,
+                                          light.reshape(3, n, 3), vis.reshape(3, n), indirect.reshape(3, n, 3))
+    return {'sg_rgb': rgb.reshape(shape + [3]), 'sg_specular_rgb': srgb.reshape(shape + [3]),
+            'sg_diffuse_rgb': drgb.reshape(shape + [3]), 'sg_diffuse_albedo': diffuse_albedo,
+            'secondary_points': sec_pts.reshape([3] + shape + [3]),
+            'secondary_mask': sec_hit.reshape([3] + shape + [1]),
+            'secondary_dir': wi.reshape([3] + shape + [3])}
+
+
+def pt_render_indirect_mlp_memsave(*args, **kwargs):
+    """Same result; the reference's memsave variant only traces the three sample sets one at a time."""
+    return pt_render_indirect_mlp(*args, **kwargs)

@@ -22,6 +22,7 @@ class RayTracing(nn.Module):
         self.last_counters = None
         self.collect_counters = False
         self.minsdf_steps_override = None     # parity tests replay the reference's captured uniforms
+        self._calls = 0
 
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
@@ -52,7 +53,11 @@ class RayTracing(nn.Module):
         steps = None
         if self.training:
             if self.minsdf_steps_override is not None:
-                steps = self.minsdf_steps_override.to(dev)
+                ov = self.minsdf_steps_override
+                if isinstance(ov, (list, tuple)):      # one entry per trace call (primary, secondary, ...)
+                    ov = ov[self._calls % len(ov)]
+                    self._calls += 1
+                steps = ov.to(dev)
             else:
                 # drawn on the host exactly like minimal_sdf_points (:316); always drawn (the reference draws only
                 # when some ray needs the search, a data-dependent host sync this build avoids)

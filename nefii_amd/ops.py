@@ -372,3 +372,58 @@ def material_specs(cfg, feature_vector_size, dim_out):
     for l in range(1, len(dims) - 1):
         specs.append(LayerSpec(dims[l + 1], dims[l], x_src0=0, x_len=dims[l]))
     return specs, [Lx, -1, -1]
+
+
+# ---- Monte-Carlo direct + indirect shading ----------------------------------------------------------
+def mis_sample(lgt, rough, normal, view, uniforms):
+    """-> wi [3,n,3], own_pdf [3,n], pdf_table [3,n,3]   (no gradient: the reference samples under no_grad)."""
+    lib = _lib.lib()
+    n = normal.shape[0]
+    dev = normal.device
+    wi = torch.empty(3, n, 3, device=dev, dtype=torch.float32)
+    own = torch.empty(3, n, device=dev, dtype=torch.float32)
+    tab = torch.empty(3, n, 3, device=dev, dtype=torch.float32)
+    lgt_c = _f32(lgt)
+    _lib.check(lib.nefii_mis_sample(_ptr(lgt_c), lgt_c.shape[0], _ptr(_f32(rough).reshape(-1)), _ptr(_f32(normal)),
+                                    _ptr(_f32(view)), _ptr(_f32(uniforms)), n, _ptr(wi), _ptr(own), _ptr(tab),
+                                    _stream()), 'nefii_mis_sample')
+    return wi, own, tab
+
+
+class McShadeFn(torch.autograd.Function):
+    """Sum over the 3 MIS samples of (direct*vis + (1-vis)*indirect) x (GGX specular + Lambert);
+    differentiable wrt light, indirect, albedo, roughness and (if it requires grad) the global specular."""
+
+    @staticmethod
+    def forward(ctx, spec, rough, albedo, normal, view, wi, own, tab, light, vis, indirect):
+        lib = _lib.lib()
+        n = normal.shape[0]
+        t = [_f32(spec.expand(1, 3)), _f32(rough).reshape(-1), _f32(albedo), _f32(normal), _f32(view), _f32(wi),
+             _f32(own), _f32(tab), _f32(light), _f32(vis), _f32(indirect)]
+        rgb = torch.empty(n, 3, device=normal.device, dtype=torch.float32)
+        srgb, drgb = torch.empty_like(rgb), torch.empty_like(rgb)
+        _lib.check(lib.nefii_mc_shade_forward(*[_ptr(x) for x in t], n, _ptr(rgb), _ptr(srgb), _ptr(drgb), _stream()),
+                   'nefii_mc_shade_forward')
+        ctx.save_for_backward(*t)
+        ctx.spec_grad = spec.requires_grad
+        ctx.spec_shape = tuple(spec.shape)
+        ctx.rough_shape = tuple(rough.shape)
+        return rgb, srgb, drgb
+
+    @staticmethod
+    def backward(ctx, d_rgb, d_s, d_d):
+        lib = _lib.lib()
+        t = ctx.saved_tensors
+        n = t[3].shape[0]
+        dev = t[3].device
+        g_light = torch.empty(3, n, 3, device=dev, dtype=torch.float32)
+        g_ind = torch.empty_like(g_light)
+        g_alb = torch.empty(n, 3, device=dev, dtype=torch.float32)
+        g_rough = torch.empty(n, device=dev, dtype=torch.float32)
+        g_spec = torch.zeros(1, 3, device=dev, dtype=torch.float32) if ctx.spec_grad else None
+        _lib.check(lib.nefii_mc_shade_backward(*[_ptr(x) for x in t], n, _ptr(_f32(d_rgb)), _ptr(_f32(d_s)),
+                                               _ptr(_f32(d_d)), _ptr(g_light), _ptr(g_ind), _ptr(g_alb), _ptr(g_rough),
+                                               _ptr(g_spec), _stream()), 'nefii_mc_shade_backward')
+        if g_spec is not None and ctx.spec_shape[-1] == 1:
+            g_spec = g_spec.sum(-1, keepdim=True)
+        return (g_spec, g_rough.reshape(ctx.rough_shape), g_alb, None, None, None, None, None, g_light, None, g_ind)

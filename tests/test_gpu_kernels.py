@@ -316,3 +316,65 @@ def test_env_radiance():
     (out * w.to(DEV)).sum().backward()
     assert rel_l2(out, ref) < 1e-5
     assert rel_l2(lgt_g.grad, lgt_c.grad) < 1e-4
+
+
+def _mc_inputs(n, seed, hidden=64):
+    mc = syn.model_conf('conf', hidden=hidden)
+    sd = syn.make_state_dict(mc, seed=4)
+    g = torch.Generator().manual_seed(seed)
+    nrm = torch.randn(n, 3, generator=g)
+    nrm = nrm / nrm.norm(dim=-1, keepdim=True)
+    view = nrm + 0.7 * torch.randn(n, 3, generator=g)
+    view = view / view.norm(dim=-1, keepdim=True)
+    rough = 0.089 + 0.9 * torch.rand(n, 1, generator=g)
+    alb = torch.rand(n, 3, generator=g)
+    uni = torch.rand(n, 7, generator=g)
+    return sd['envmap_material_network.lgtSGs'].clone(), nrm, view, rough, alb, uni, g
+
+
+def test_mis_sampler_matches_oracle():
+    from nefii_amd import ops
+    lgt, nrm, view, rough, alb, uni, g = _mc_inputs(3000, 21)
+    ws, own, table, _ = shading.draw_mis_directions(lgt, rough, nrm, view, uni)
+    wi, o, tab = ops.mis_sample(lgt.to(DEV), rough.to(DEV), nrm.to(DEV), view.to(DEV), uni.to(DEV))
+    wi, o, tab = wi.cpu(), o.cpu(), tab.cpu()
+    for i in range(3):
+        # a handful of points may pick a neighbouring lobe when r0 sits on a CDF boundary
+        err = (wi[i] - ws[i]).abs().max(dim=-1)[0]
+        assert (err < 1e-4).float().mean().item() > 0.998, (i, (err < 1e-4).float().mean().item())
+        ok = err < 1e-4
+        assert rel_l2(o[i][ok], own[i].reshape(-1)[ok]) < 1e-4, i
+        for j in range(3):
+            assert rel_l2(tab[i, :, j][ok], table[i][j].reshape(-1)[ok]) < 2e-4, (i, j)
+    assert torch.isfinite(wi).all() and torch.isfinite(tab).all()
+
+
+def test_mc_shade_forward_backward_matches_oracle():
+    from nefii_amd import ops
+    n = 2000
+    lgt0, nrm, view, rough0, alb0, uni, g = _mc_inputs(n, 33)
+    ws, own, table, _ = shading.draw_mis_directions(lgt0, rough0, nrm, view, uni)
+    vis = [(torch.rand(n, 1, generator=g) < 0.6).float() for _ in range(3)]
+    ind0 = [torch.rand(n, 3, generator=g) for _ in range(3)]
+    wts = torch.rand(n, 3, generator=g)
+    res = {}
+    for dev in ('cpu', DEV):
+        lgt = lgt0.clone().to(dev).requires_grad_(True)
+        rough = rough0.clone().to(dev).requires_grad_(True)
+        alb = alb0.clone().to(dev).requires_grad_(True)
+        ind = [x.clone().to(dev).requires_grad_(True) for x in ind0]
+        spec = torch.tensor([[0.04, 0.05, 0.06]], device=dev, requires_grad=True)
+        if dev == 'cpu':
+            out = shading.mc_shade(lgt, spec, rough, alb, nrm, view, ws, own, table, vis, ind)['sg_rgb']
+        else:
+            wi = torch.stack(ws).to(dev)
+            o = torch.stack([x.reshape(-1) for x in own]).to(dev)
+            tab = torch.stack([torch.cat(table[i], dim=1) for i in range(3)]).to(dev)
+            light = ops.EnvRadianceFn.apply(lgt, wi.reshape(-1, 3), 1e-6).reshape(3, n, 3)
+            out = ops.McShadeFn.apply(spec, rough, alb, nrm.to(dev), view.to(dev), wi, o, tab, light,
+                                      torch.stack([v.reshape(-1) for v in vis]).to(dev), torch.stack(ind))[0]
+        (out * wts.to(dev)).sum().backward()
+        res[dev] = [out, lgt.grad, rough.grad, alb.grad, spec.grad] + [x.grad for x in ind]
+    names = ['rgb', 'g_lgt', 'g_rough', 'g_albedo', 'g_spec', 'g_ind0', 'g_ind1', 'g_ind2']
+    for name, a, b in zip(names, res[DEV], res['cpu']):
+        assert rel_l2(a, b) < 2e-4, (name, rel_l2(a, b))

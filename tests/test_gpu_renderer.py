@@ -155,3 +155,49 @@ def test_trainable_geometry_is_refused():
     inp, _ = syn.make_inputs(16, (64, 64), 100.0, (0.2, 0.1, 2.0), -1, seed=2)
     with pytest.raises(NotImplementedError):
         m(to_dev(inp))
+
+
+@pytest.mark.parametrize('name', ['conf', 'neus'])
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_forward_indirect_golden(golden, name, mode):
+    """conf.conf / conf_neus.conf models: MIS sampling + secondary trace + indirect radiance + MC shading,
+    replaying the reference's captured random draws."""
+    g = golden('forward_%s_%s' % (name, mode))
+    mc = syn.model_conf(name, hidden=64)
+    sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+    m = build_model(mc, sd, mode == 'train')
+    d = torch.rand(100)
+    m.ray_tracer.minsdf_steps_override = [g.get('minsdf_steps', d), g.get('minsdf_steps2', d)]
+    m.uniforms_override = g['uniforms']
+    inp = to_dev({'uv': g['uv'], 'pose': g['pose'], 'intrinsics': g['intrinsics'], 'object_mask': g['in_object_mask']})
+    ctx = torch.enable_grad() if mode == 'train' else torch.no_grad()
+    with ctx:
+        out = m(inp)
+    compare_outputs(out, g, what=(name, mode))
+    sm, rsm = out['secondary_mask'].cpu(), g['secondary_mask']
+    assert (sm != rsm).float().mean().item() < 0.01
+    if mode == 'train':
+        from nefii_amd.model.loss import IDRLoss
+        lo = IDRLoss(**syn.loss_conf(name))(out, {'rgb': g['rgb_gt'].to(DEV)})
+        for k in ('loss', 'idr_rgb_loss', 'sg_rgb_loss', 'mask_loss', 'normalsmooth_loss', 'background_rgb_loss'):
+            assert abs(lo[k].item() - g['loss.' + k].item()) <= 3e-3 * abs(g['loss.' + k].item()) + 1e-6, k
+        lo['loss'].backward()
+        for pname, p in m.named_parameters():
+            key = 'gnorm.' + pname
+            if key in g and g[key].item() > 0:
+                assert p.grad is not None, pname
+                assert abs(p.grad.norm().item() - g[key].item()) <= 2e-2 * g[key].item() + 1e-7, pname
+            if 'grad.' + pname in g and g[key].item() > 0:
+                assert rel_l2(p.grad, g['grad.' + pname]) < 2e-2, pname
+
+
+def test_forward_with_point_golden(golden):
+    g = golden('forward_point_conf')
+    mc = syn.model_conf('conf', hidden=64)
+    sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+    m = build_model(mc, sd, True)
+    m.uniforms_override = g['uniforms']
+    m.ray_tracer.minsdf_steps_override = g['minsdf_steps2'] if g['minsdf_steps2'].numel() else torch.rand(100)
+    out = m({'points': g['points'].to(DEV), 'ray_dirs': g['ray_dirs'].to(DEV)}, with_point=True)
+    assert rel_l2(out['idr_rgb_values'], g['idr_rgb_values']) < 1e-4
+    assert rel_l2(out['sg_rgb_values'], g['sg_rgb_values']) < 1e-3
