@@ -118,8 +118,11 @@ typedef struct nefii_tracer_params {
 size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *h_params);
 int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
 /* lin_steps: the n_steps values of torch.linspace(0,1,n_steps); minsdf_steps: the n_steps uniforms of
- * minimal_sdf_points (only read when training).  counters (optional, int32 [max_rounds][4]) receives the
- * number of single / dense queries per round: counters[r][0] singles, [r][1] dense rays. */
+ * minimal_sdf_points (only read when training).  counters (optional, int32 [max_rounds][4]) receives per round:
+ * [r][0] single queries, [r][1] rays with n_steps dense queries, [r][2] rays in bisection (7 speculative queries each:
+ * three levels of the bisection tree per round), [r][3] bisection evaluations actually consumed.
+ * Executed SDF evaluations = [0] + n_steps*[1] + 7*[2]; algorithmic (what the reference's recurrence needs)
+ * = [0] + n_steps*[1] + [3]. */
 int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
                      const float *origins, const float *dirs, const uint8_t *object_mask, int64_t n_rays,
                      const float *lin_steps, const float *minsdf_steps,

@@ -31,12 +31,32 @@ struct Lds {
     float E[TILE * ES];
 };
 
+// Softplus(beta=100, threshold=20) = log1p(exp(100 v))/100 (torch.nn.Softplus, implicit_differentiable_renderer.py:83)
+// on the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, 1 ulp each) with the two places
+// where a plain exp2/log2 formulation loses bits compensated:
+//   * exp(z) = 2^(z*log2e): the rounding error of the product z*log2e (up to |z| * 2^-24) is carried as t_lo
+//     and folded back in first order, so exp keeps ~1 ulp for the whole range of z;
+//   * log1p(e) = log(u) + (e - (u-1))/u with u = fl(1+e): exact to first order in the rounding of 1+e, and
+//     reduces to e for e < 2^-24.
+// ~16 VALU instructions instead of ~150 for the libm expf/log1pf + IEEE division pair (the epilogue of a
+// 512-wide layer evaluates 64 of these per lane).
+__device__ __forceinline__ float softplus100(float v) {
+    const float z = v * 100.f;
+    const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f, LN2 = 0.693147182464599609375f;
+    const float t_hi = z * L2E_HI;
+    const float t_lo = __builtin_fmaf(z, L2E_HI, -t_hi) + z * L2E_LO;
+    const float e_hw = __builtin_amdgcn_exp2f(t_hi);
+    const float e = __builtin_fmaf(e_hw, t_lo * LN2, e_hw);
+    const float u = 1.f + e;
+    const float c = (e - (u - 1.f)) * __builtin_amdgcn_rcpf(u);
+    const float r = __builtin_fmaf(__builtin_amdgcn_logf(u), LN2, c);     // v_log_f32 is log2
+    return z > 20.f ? v : r * 0.01f;
+}
+
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == NEFII_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == NEFII_ACT_ELU) return v > 0.f ? v : expm1f(v);
-    // Softplus(beta=100, threshold=20): torch.nn.Softplus as used at implicit_differentiable_renderer.py:83
-    float z = v * 100.f;
-    return z > 20.f ? v : log1pf(expf(z)) / 100.f;
+    return softplus100(v);
 }
 
 // derivative of the activation expressed through its OUTPUT h (what the stash keeps)
@@ -124,29 +144,40 @@ __device__ __forceinline__ void gemm_block(const float *A, int a_stride, int kgr
     if (kgroups <= 0 || ntw <= 0) return;
     const int r = lane & 31, h = lane >> 5;
     const float *arow = A + r * a_stride + 4 * h;
-    float4 bc[4], bn[4];
+    // weight fragments run TWO k-groups ahead of the MFMAs (an L2 miss served by the Infinity Cache costs
+    // ~550+ cycles; one group of 16 MFMAs covers 1024), the LDS A fragment one group ahead
+    float4 b0[4], b1[4], b2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        bc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < ntw) bc[j] = wp[(size_t)(wave + 4 * j) * 64 + lane];
+        b0[j] = b1[j] = b2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < ntw) {
+            b0[j] = wp[(size_t)(wave + 4 * j) * 64 + lane];
+            if (kgroups > 1) b1[j] = wp[((size_t)NT + wave + 4 * j) * 64 + lane];
+        }
     }
+    float4 a = *reinterpret_cast<const float4 *>(arow);
     for (int g = 0; g < kgroups; ++g) {
-        if (g + 1 < kgroups) {
+        if (g + 2 < kgroups) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < ntw) bn[j] = wp[((size_t)(g + 1) * NT + wave + 4 * j) * 64 + lane];
+                if (j < ntw) b2[j] = wp[((size_t)(g + 2) * NT + wave + 4 * j) * 64 + lane];
         }
-        const float4 a = *reinterpret_cast<const float4 *>(arow + 8 * g);
+        float4 an = a;
+        if (g + 1 < kgroups) an = *reinterpret_cast<const float4 *>(arow + 8 * (g + 1));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (j < ntw) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bc[j].x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bc[j].y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bc[j].z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bc[j].w, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[j].x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0[j].y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0[j].z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0[j].w, acc[j], 0, 0, 0);
             }
+        a = an;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bc[j] = bn[j];
+        for (int j = 0; j < 4; ++j) {
+            b0[j] = b1[j];
+            b1[j] = b2[j];
+        }
     }
 }
 

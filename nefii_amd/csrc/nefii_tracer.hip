@@ -34,6 +34,7 @@ struct RayState {            // SoA views into the workspace
     float *big;              // [n][n_steps] dense query results
     unsigned *singles;       // [2n]  (ray << 2 | kind)
     unsigned *dense;         // [n]   (ray << 1 | which)  which: 0 sampler, 1 min-sdf
+    unsigned *tri;           // [n]   rays in bisection: 7 speculative queries each (3 levels of the bisection tree)
 };
 
 // flags layout
@@ -62,37 +63,57 @@ struct Params {
 
 // ---- work-list append: block-aggregated ------------------------------------------------------
 // each thread contributes n_single (0..2) single queries and n_dense (0..1) dense rays.
-__device__ __forceinline__ void append_queries(const Params &P, int round, bool qs, bool qe, bool qm, bool qd,
-                                               unsigned ray, unsigned dense_which) {
-    __shared__ int wtot[2][4];
-    __shared__ int base[2];
+__device__ __forceinline__ void append_queries(const Params &P, int round, bool qs, bool qe, bool qt, bool qd,
+                                               unsigned ray, unsigned dense_which, int consumed) {
+    __shared__ int wtot[4][4];
+    __shared__ int base[3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long bs = __ballot(qs), be = __ballot(qe), bm = __ballot(qm), bd = __ballot(qd);
+    const unsigned long long bs = __ballot(qs), be = __ballot(qe), bt = __ballot(qt), bd = __ballot(qd);
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int tot_single = __popcll(bs) + __popcll(be) + __popcll(bm);
-    const int tot_dense = __popcll(bd);
+    int cons = consumed;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cons += __shfl_xor(cons, o);
     if (lane == 0) {
-        wtot[0][wave] = tot_single;
-        wtot[1][wave] = tot_dense;
+        wtot[0][wave] = __popcll(bs) + __popcll(be);
+        wtot[1][wave] = __popcll(bd);
+        wtot[2][wave] = __popcll(bt);
+        wtot[3][wave] = cons;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int a = wtot[0][0] + wtot[0][1] + wtot[0][2] + wtot[0][3];
-        int b = wtot[1][0] + wtot[1][1] + wtot[1][2] + wtot[1][3];
-        base[0] = a ? atomicAdd(&P.counters[round * 4 + 0], a) : 0;
-        base[1] = b ? atomicAdd(&P.counters[round * 4 + 1], b) : 0;
+        int t[4];
+        for (int i = 0; i < 4; ++i) t[i] = wtot[i][0] + wtot[i][1] + wtot[i][2] + wtot[i][3];
+        for (int i = 0; i < 3; ++i) base[i] = t[i] ? atomicAdd(&P.counters[round * 4 + i], t[i]) : 0;
+        if (t[3]) atomicAdd(&P.counters[round * 4 + 3], t[3]);
     }
     __syncthreads();
-    int off_s = base[0], off_d = base[1];
+    int off_s = base[0], off_d = base[1], off_t = base[2];
     for (int w = 0; w < wave; ++w) {
         off_s += wtot[0][w];
         off_d += wtot[1][w];
+        off_t += wtot[2][w];
     }
     if (qs) P.s.singles[off_s + __popcll(bs & lt)] = (ray << 2) | Q_START;
     if (qe) P.s.singles[off_s + __popcll(bs) + __popcll(be & lt)] = (ray << 2) | Q_END;
-    if (qm) P.s.singles[off_s + __popcll(bs) + __popcll(be) + __popcll(bm & lt)] = (ray << 2) | Q_MID;
     if (qd) P.s.dense[off_d + __popcll(bd & lt)] = (ray << 1) | dense_which;
+    if (qt) P.s.tri[off_t + __popcll(bt & lt)] = ray;
     __syncthreads();
+}
+
+// depth of node j (0..6) of the 3-level bisection tree over [lo, hi]; identical arithmetic to the sequential
+// recurrence mid = (lo + hi) / 2 (ray_tracing.py:262,275), so speculated points ARE the points bisection would visit
+__device__ __forceinline__ float tri_depth(float lo, float hi, int j) {
+    const float m1 = fmul(fadd(lo, hi), 0.5f);
+    if (j == 0) return m1;
+    const float m2a = fmul(fadd(lo, m1), 0.5f), m2b = fmul(fadd(m1, hi), 0.5f);
+    switch (j) {
+        case 1: return m2a;
+        case 2: return m2b;
+        case 3: return fmul(fadd(lo, m2a), 0.5f);
+        case 4: return fmul(fadd(m2a, m1), 0.5f);
+        case 5: return fmul(fadd(m1, m2b), 0.5f);
+        default: return fmul(fadd(m2b, hi), 0.5f);
+    }
 }
 
 __device__ __forceinline__ void finish(const Params &P, int64_t r, float dist, bool hit) {
@@ -109,8 +130,9 @@ __device__ __forceinline__ void finish(const Params &P, int64_t r, float dist, b
 __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < P.n;
-    bool qs = false, qe = false, qm = false, qd = false;
+    bool qs = false, qe = false, qt = false, qd = false;
     unsigned dense_which = 0;
+    int consumed = 0;          // bisection evaluations actually used this round (of the 7 speculated per ray)
     const nefii_tracer_params &tp = P.p;
     const float thr = tp.sdf_threshold;
     int fl = 0;
@@ -278,7 +300,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                 P.s.hi[r] = hi;
                 P.s.mid[r] = mid;
                 fl = (fl & ~(F_PHASE | (F_IT_MASK << F_IT_SHIFT))) | PH_BISECT;
-                qm = true;
+                qt = true;
                 go = true;
             }
         }
@@ -292,21 +314,31 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
     }
 
     if (valid && ph == PH_BISECT) {
-        // one bisection step (ray_tracing.py:264-277), per ray
+        // up to three bisection steps per round (ray_tracing.py:264-277, per ray): the 7 nodes of the next three
+        // levels were evaluated speculatively last round; walk them with the sequential rule
         float lo = P.s.lo[r], hi = P.s.hi[r], mid = P.s.mid[r];
-        const float f_mid = P.s.res_s[r];
+        const float *f = P.s.big + (size_t)r * tp.n_steps;
         int it = (fl >> F_IT_SHIFT) & F_IT_MASK;
-        if (f_mid > 0.f) lo = mid; else hi = mid;
-        mid = fmul(fadd(lo, hi), 0.5f);
-        ++it;
-        const bool work = fsub(hi, lo) > 1e-6f;
+        int node = 0;
+        bool more = true;
+#pragma unroll
+        for (int level = 0; level < 3 && more; ++level) {
+            const float f_mid = f[node];
+            ++consumed;
+            const int bit = f_mid > 0.f ? 1 : 0;
+            if (bit) lo = mid; else hi = mid;
+            mid = fmul(fadd(lo, hi), 0.5f);
+            ++it;
+            more = (fsub(hi, lo) > 1e-6f) && (it < tp.n_rootfind_steps);
+            node = level == 0 ? 1 + bit : 3 + 2 * (node - 1) + bit;
+        }
         P.s.mid[r] = mid;
-        if (work && it < tp.n_rootfind_steps) {
+        if (more) {
             P.s.lo[r] = lo;
             P.s.hi[r] = hi;
             fl = (fl & ~(F_IT_MASK << F_IT_SHIFT)) | (it << F_IT_SHIFT);
             P.s.flags[r] = fl;
-            qm = true;
+            qt = true;
             ph = -1;
         } else {
             ph = PH_MINSDF + 1;
@@ -359,7 +391,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         P.s.flags[r] = (fl & ~F_PHASE) | PH_DONE;
     }
 
-    append_queries(P, round, qs, qe, qm, qd, (unsigned)r, dense_which);
+    append_queries(P, round, qs, qe, qt, qd, (unsigned)r, dense_which, consumed);
 }
 
 // ---- SDF evaluation of one round's work list -------------------------------------------------
@@ -370,8 +402,10 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int
     const int tid = threadIdx.x;
     const int n_single = P.counters[round * 4 + 0];
     const int n_dense = P.counters[round * 4 + 1];
+    const int n_tri = P.counters[round * 4 + 2];
     const int ns = P.p.n_steps;
-    const int64_t total = (int64_t)n_single + (int64_t)n_dense * ns;
+    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * ns;
+    const int64_t total = n_sd + (int64_t)n_tri * 7;
     const int64_t n_tiles = (total + TILE - 1) / TILE;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
@@ -390,6 +424,13 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int
                     const int kind = e & 3;
                     t = kind == Q_START ? P.s.t_s[r] : (kind == Q_END ? P.s.t_e[r] : P.s.mid[r]);
                     dst = kind == Q_END ? &P.s.res_e[r] : &P.s.res_s[r];
+                } else if (q >= n_sd) {
+                    const int64_t qq = q - n_sd;
+                    const int64_t ti = qq / 7;
+                    const int j = (int)(qq - ti * 7);
+                    r = P.s.tri[ti];
+                    t = tri_depth(P.s.lo[r], P.s.hi[r], j);
+                    dst = &P.s.big[(size_t)r * ns + j];
                 } else {
                     const int64_t qq = q - n_single;
                     const int64_t di = qq / ns;
@@ -451,6 +492,7 @@ size_t carve(RayState &s, char *base, int64_t n, int ns) {
     s.big = (float *)take(sizeof(float) * (size_t)n * ns);
     s.singles = (unsigned *)take(sizeof(unsigned) * 2 * n);
     s.dense = (unsigned *)take(sizeof(unsigned) * n);
+    s.tri = (unsigned *)take(sizeof(unsigned) * n);
     return off;
 }
 
@@ -511,8 +553,8 @@ extern "C" int nefii_trace_profile_read(double *eval_ms, int *n_eval, double *sp
 
 extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     if (!p) return 0;
-    // initial eval + iters*(step + back-offs) -> sampler -> bisection steps -> min-SDF -> final bookkeeping
-    return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + p->n_rootfind_steps + 1 + 2;
+    // initial eval + iters*(step + back-offs) -> sampler -> bisection (3 levels per round) -> min-SDF -> bookkeeping
+    return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + (p->n_rootfind_steps + 2) / 3 + 1 + 2;
 }
 
 extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *p) {
@@ -533,7 +575,7 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
     if (n_rays <= 0) return 0;
     if (n_rays >= (1ll << 29)) return NEFII_E_SHAPE;
     if (h_params->training && !minsdf_steps) return NEFII_E_ARG;
-    if (h_params->n_steps < 2 || h_params->sphere_tracing_iters > 250 || h_params->line_step_iters > 15 ||
+    if (h_params->n_steps < 8 || h_params->sphere_tracing_iters > 250 || h_params->line_step_iters > 15 ||
         h_params->n_rootfind_steps > 250)
         return NEFII_E_SHAPE;
     if (h_sdf->enc_freqs[0] < 0 || h_sdf->enc_freqs[1] >= 0 || h_sdf->enc_freqs[2] >= 0 || h_sdf->feat_width != 0 ||
@@ -561,7 +603,7 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
     if (e != hipSuccess) return (int)e;
     const int adv_blocks = (int)((n_rays + 255) / 256);
     // eval grid: enough workgroups for the largest possible round, capped at 2 per CU (grid-stride beyond)
-    int64_t max_q = 2 * n_rays > n_rays * h_params->n_steps ? 2 * n_rays : n_rays * (int64_t)h_params->n_steps;
+    int64_t max_q = n_rays * (int64_t)h_params->n_steps;      // n_steps >= 8 > 7 (bisection tree) > 2 (both ends)
     int64_t max_tiles = (max_q + TILE - 1) / TILE;
     const int eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
     if (g_prof.on) {

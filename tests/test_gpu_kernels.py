@@ -230,7 +230,7 @@ def test_tracer_vs_oracle_and_counts(hidden, bumpy, n):
         compare_trace(sdf, o, d, got, ref['hit'], ref['dists'], (hidden, bumpy, training),
                       argmin_set(ref['hit'], om, training))
         cnt = got[3].cpu().long()
-        gpu_evals = (cnt[:, 0] + cnt[:, 1] * 100).sum().item()
+        gpu_evals = (cnt[:, 0] + cnt[:, 1] * 100 + cnt[:, 3]).sum().item()     # algorithmic (header: counters)
         c = ref['counters']
         cpu_evals = sum(c.get(k, 0) for k in ('sphere_trace', 'sampler', 'bisect', 'min_sdf'))
         assert abs(gpu_evals - cpu_evals) <= 0.01 * cpu_evals, (gpu_evals, cpu_evals)

@@ -124,7 +124,7 @@ def test_train_step_full_size_vs_oracle(wl):
             assert rel_l2(p.grad, sdo[name].grad) < 2e-2, (name, rel_l2(p.grad, sdo[name].grad))
     # the tracer's query counters equal the oracle's SDF evaluation counts (exact algorithmic work, no padding)
     cnt = m.ray_tracer.last_counters.cpu().long()
-    gpu_evals = (cnt[:, 0] + cnt[:, 1] * 100).sum().item()
+    gpu_evals = (cnt[:, 0] + cnt[:, 1] * 100 + cnt[:, 3]).sum().item()     # algorithmic (header: counters)
     c = R.counters
     cpu_evals = sum(c.get(k, 0) for k in ('sphere_trace', 'sampler', 'bisect', 'min_sdf'))
     assert abs(gpu_evals - cpu_evals) <= 0.01 * cpu_evals, (gpu_evals, cpu_evals)

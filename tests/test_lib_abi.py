@@ -40,7 +40,7 @@ def test_host_side_argument_checks_need_no_gpu():
     lib = _lib.lib()
     p = _lib.TracerParams()
     p.n_steps, p.sphere_tracing_iters, p.line_step_iters, p.n_rootfind_steps = 100, 10, 3, 32
-    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 32 + 1 + 2
+    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 11 + 1 + 2    # bisection: 3 levels per round
     assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) > 4096 * 100 * 4
     assert lib.nefii_trace_rays(None, None, None, None, None, 0, None, None, None, None, None, None, 0, None, None) == -1
     assert lib.nefii_pack_linear(None, None, 1, 1, 0, 0, 0, 0, 1.0, None, None, None, None) == -1
