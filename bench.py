@@ -88,10 +88,16 @@ def main():
             raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d'
                              % (args.gpus, args.gpus))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # one process per GPU; NEFII_BENCH_BACKEND=gloo lets the multi-process path be smoke-tested on a 1-GPU box
+    backend = os.environ.get('NEFII_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
-        dist.init_process_group(backend='nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from nefii_amd import _lib, conf, synthetic as syn
     from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
@@ -115,7 +121,10 @@ def main():
     inp = {k: v.to(dev) for k, v in inp.items()}
     gt = {'rgb': gt.to(dev)}
     rays_per_rank = inp['uv'].shape[1] * (w['num_rays'] if w['num_rays'] > 0 else 1)
-    step = TrainStep(model, lc, world_size=world)
+    indirect = mc.get('render_type', 'sg') != 'sg'
+    # conf.conf runs: secondary-consistency step every 10 iterations on 1024/world points (robot/run_s2.sh:25-26)
+    step = TrainStep(model, lc, world_size=world, secondary_train_interval=10 if indirect else 0,
+                     secondary_batch_size=1024, num_rays=w['num_rays'])
 
     for _ in range(args.warmup):
         step(inp, gt)
@@ -130,7 +139,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
@@ -140,6 +149,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: one extra, un-timed step with per-launch HIP events
         model.ray_tracer.collect_counters = True
+        model.ray_tracer.counter_sum = None
         lib.nefii_trace_profile_enable(1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
@@ -149,7 +159,7 @@ def main():
         eval_ms, n_eval, span_ms = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
         lib.nefii_trace_profile_read(ctypes.byref(eval_ms), ctypes.byref(n_eval), ctypes.byref(span_ms))
         lib.nefii_trace_profile_enable(0)
-        cnt = model.ray_tracer.last_counters.cpu().long()
+        cnt = model.ray_tracer.counter_sum.cpu().long()       # primary + secondary traces of the step
         n_steps = model.ray_tracer.n_steps
         # algorithmic evaluations (what the reference's recurrences need) vs executed (incl. the unused nodes of
         # the speculative 3-level bisection tree); the roofline credits only the algorithmic ones
@@ -171,9 +181,12 @@ def main():
             'metric': 'training rays/sec (Step-2 material opt)', 'value': value, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s: robot-like synthetic scene (geometric-init SDF 8x512), physg.conf model, '
-                                   'num_pixels=%d per GPU, 128 SG lobes, indirect OFF, frozen geometry, '
-                                   'fwd+IDRLoss+bwd+2xAdam' % (args.workload, w['num_pixels']),
+            'config': {'workload': '%s: robot-like synthetic scene (geometric-init SDF), %s model, num_pixels=%d per GPU'
+                                   '%s, 128 SG lobes, %s, frozen geometry, fwd+IDRLoss+bwd+2xAdam'
+                                   % (args.workload, {'physg': 'physg.conf', 'conf': 'conf.conf', 'neus': 'conf_neus.conf'}[w['model']],
+                                      w['num_pixels'], (' x %d rays/pixel' % w['num_rays']) if w['num_rays'] > 0 else '',
+                                      'indirect OFF (closed-form SG)' if mc.get('render_type', 'sg') == 'sg'
+                                      else 'MC direct + near-field indirect ON'),
                        'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
                        'loss': float(lo['loss'].item())},
             'roofline': roofline,

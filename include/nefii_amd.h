@@ -134,6 +134,8 @@ int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params
  * of launches and the span of the last trace call, and clears the record.  Off by default. */
 int nefii_trace_profile_enable(int on);
 int nefii_trace_profile_read(double *h_eval_ms, int *h_n_eval, double *h_span_ms);
+/* per-launch durations (ms) in launch order into h_ms[cap]; returns the count (does not clear the record) */
+int nefii_trace_profile_launches(float *h_ms, int cap);
 
 /* rend_util.get_camera_params + lift (rend_util.py:90-142): uv [B,S,2], pose [B,4,4], intrinsics [B,4,4]
  * -> unit ray dirs [B,S,3] and per-ray origins [B,S,3] (camera centre broadcast). */

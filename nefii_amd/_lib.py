@@ -61,6 +61,7 @@ SIGNATURES = {
                              ctypes.c_size_t, P, P]),
     'nefii_trace_profile_enable': (I, [I]),
     'nefii_trace_profile_read': (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I), ctypes.POINTER(ctypes.c_double)]),
+    'nefii_trace_profile_launches': (I, [ctypes.POINTER(ctypes.c_float), I]),
     'nefii_camera_rays': (I, [P, P, P, I, I64, P, P, P]),
     'nefii_sg_render_forward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P]),
     'nefii_sg_render_backward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P, P, P, P, P]),

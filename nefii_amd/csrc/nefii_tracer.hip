@@ -551,6 +551,19 @@ extern "C" int nefii_trace_profile_read(double *eval_ms, int *n_eval, double *sp
     return 0;
 }
 
+// Per-launch durations (ms) of the recorded eval launches, in launch order; does not clear the record.
+extern "C" int nefii_trace_profile_launches(float *h_ms, int cap) {
+    int n = 0;
+    for (size_t i = 0; i + 1 < g_prof.used && n < cap; i += 2, ++n) {
+        hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
+        if (e != hipSuccess) return -(int)e;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]);
+        h_ms[n] = ms;
+    }
+    return n;
+}
+
 extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     if (!p) return 0;
     // initial eval + iters*(step + back-offs) -> sampler -> bisection (3 levels per round) -> min-SDF -> bookkeeping

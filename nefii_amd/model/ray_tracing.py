@@ -20,6 +20,7 @@ class RayTracing(nn.Module):
         self._net = None
         self._lin = None
         self.last_counters = None
+        self.counter_sum = None       # summed over calls while collect_counters (primary + secondary traces)
         self.collect_counters = False
         self.minsdf_steps_override = None     # parity tests replay the reference's captured uniforms
         self._calls = 0
@@ -67,4 +68,5 @@ class RayTracing(nn.Module):
                              want_counters=self.collect_counters)
         if self.collect_counters:
             self.last_counters = res[3]
+            self.counter_sum = res[3].clone() if self.counter_sum is None else self.counter_sum + res[3]
         return res[0], res[1], res[2]

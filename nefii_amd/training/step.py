@@ -19,7 +19,13 @@ def allreduce_mean_gradients(params, world_size, group=None):
     if not grads:
         return 0
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if flat.is_cuda and dist.get_backend(group) == 'gloo':
+        # CPU-staged path for smoke-testing the multi-process logic on a box without RCCL peers
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(world_size)
     off = 0
     for g in grads:
@@ -30,10 +36,17 @@ def allreduce_mean_gradients(params, world_size, group=None):
 
 
 class TrainStep:
-    def __init__(self, model, loss_conf, idr_lr=5e-4, sg_lr=5e-4, world_size=1):
+    def __init__(self, model, loss_conf, idr_lr=5e-4, sg_lr=5e-4, world_size=1, secondary_train_interval=0,
+                 secondary_batch_size=1024, num_rays=1):
         self.model = model
         self.loss = IDRLoss(**loss_conf)
         self.world_size = world_size
+        # secondary-point consistency step (idr_train.py:44,788,804-852): every `interval` iterations, on the first
+        # secondary_batch_size // world masked secondary hits, each replicated num_rays times
+        self.secondary_train_interval = secondary_train_interval
+        self.secondary_batch_size = secondary_batch_size // max(world_size, 1)
+        self.num_rays = max(num_rays, 1)
+        self.cur_iter = 0
         self.idr_optimizer = torch.optim.Adam(list(model.implicit_network.parameters()) +
                                               list(model.rendering_network.parameters()), lr=idr_lr)
         self.sg_optimizer = torch.optim.Adam(model.envmap_material_network.parameters(), lr=sg_lr)
@@ -48,4 +61,32 @@ class TrainStep:
         allreduce_mean_gradients(self.trainable, self.world_size)
         self.idr_optimizer.step()
         self.sg_optimizer.step()
+        if self.secondary_train_interval > 0 and self.cur_iter % self.secondary_train_interval == 0:
+            self.train_with_secondary(out)
+        self.cur_iter += 1
         return out, lo
+
+    def train_with_secondary(self, model_outputs):
+        """L1(sg_rgb, idr_rgb) at secondary hit points, seen from the direction they were hit from
+        (idr_train.py:804-852): ties the material/light decomposition to the radiance field where the camera
+        never looks."""
+        pts, mask, dirs = (model_outputs.get(k) for k in ('secondary_points', 'secondary_mask', 'secondary_dir'))
+        if pts is None or mask is None or dirs is None:
+            return None
+        m = mask.reshape(-1)
+        idx = torch.nonzero(m).flatten()[:self.secondary_batch_size]
+        if idx.numel() == 0:
+            return None
+        p = pts.detach().reshape(-1, 3).index_select(0, idx)
+        d = dirs.detach().reshape(-1, 3).index_select(0, idx)
+        n = p.shape[0]
+        ret = self.model({'points': p.unsqueeze(1).expand(n, self.num_rays, 3),
+                          'ray_dirs': d.unsqueeze(1).expand(n, self.num_rays, 3)}, with_point=True)
+        loss = torch.nn.functional.l1_loss(ret['sg_rgb_values'], ret['idr_rgb_values'])
+        self.idr_optimizer.zero_grad()
+        self.sg_optimizer.zero_grad()
+        loss.backward()
+        allreduce_mean_gradients(self.trainable, self.world_size)
+        self.idr_optimizer.step()
+        self.sg_optimizer.step()
+        return loss

@@ -201,3 +201,30 @@ def test_forward_with_point_golden(golden):
     out = m({'points': g['points'].to(DEV), 'ray_dirs': g['ray_dirs'].to(DEV)}, with_point=True)
     assert rel_l2(out['idr_rgb_values'], g['idr_rgb_values']) < 1e-4
     assert rel_l2(out['sg_rgb_values'], g['sg_rgb_values']) < 1e-3
+
+
+def test_forward_full_size_conf_vs_oracle():
+    """conf.conf at full network size (8x512 SDF with feature vector, 8x512 material, 4x512 radiance), multi-ray
+    pixels, MC direct + indirect with injected draws, bumpy geometry so that secondary rays do hit."""
+    mc = syn.model_conf('conf')
+    sd = syn.make_state_dict(mc, seed=0, bumpy=0.004)
+    inp, gt = syn.make_inputs(64, (64, 64), 100.0, (0.2, 0.1, 2.0), 4, seed=8)
+    g = torch.Generator().manual_seed(5)
+    steps1, steps2 = torch.rand(100, generator=g), torch.rand(100, generator=g)
+    sdo = {k: v.clone() for k, v in sd.items()}
+    R = orr.Renderer(sdo, mc, training=True)
+    R.dead_work = False
+    with torch.no_grad():
+        # first pass only to learn how many hit points there are (uniforms are per hit point)
+        probe = R.forward(inp, steps1, None, steps2)
+    uniforms = probe['_uniforms']
+    with torch.no_grad():
+        ref = R.forward(inp, steps1, uniforms, steps2)
+    m = build_model(mc, sd, True)
+    m.ray_tracer.minsdf_steps_override = [steps1, steps2]
+    m.uniforms_override = uniforms
+    with torch.no_grad():
+        out = m(to_dev(inp))
+    compare_outputs(out, ref, max_flips=2, what='conf512')
+    assert (out['secondary_mask'].cpu() != ref['secondary_mask']).float().mean().item() < 0.01
+    assert ref['secondary_mask'].float().mean().item() > 0.01      # the indirect branch is exercised

@@ -1,0 +1,49 @@
+"""Per-round anatomy of the tracer on a workload: queries per round and the eval launch durations
+(HIP events on the launch stream).  Usage: python tools/trace_rounds.py [cfg2] [train|eval]"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nefii_amd import _lib, conf, synthetic as syn
+from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+
+wl = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
+mode = sys.argv[2] if len(sys.argv) > 2 else 'train'
+w = dict(syn.WORKLOADS[wl])
+mc = syn.model_conf(w['model'])
+sd = syn.make_state_dict(mc, seed=0)
+dev = torch.device('cuda:0')
+m = IDRNetwork(conf.from_dict(mc))
+m.load_state_dict(sd)
+m = m.to(dev)
+m.freeze_geometry()
+m.train(mode == 'train')
+inp, gt = syn.make_inputs(w['num_pixels'], w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
+inp = {k: v.to(dev) for k, v in inp.items()}
+lib = _lib.lib()
+m.ray_tracer.collect_counters = True
+from nefii_amd.utils import rend_util
+uv = inp['uv'] if inp['uv'].dim() == 3 else inp['uv'].reshape(1, -1, 2)
+dirs, cam = rend_util.get_camera_params(uv, inp['pose'], inp['intrinsics'])
+om = torch.ones(dirs.shape[1], dtype=torch.bool, device=dev)
+for it in range(3):
+    lib.nefii_trace_profile_enable(1)
+    with torch.no_grad():
+        m.ray_tracer(m.implicit_network, cam, om, dirs)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_float * 256)()
+    n = lib.nefii_trace_profile_launches(buf, 256)
+    lib.nefii_trace_profile_enable(0)
+cnt = m.ray_tracer.last_counters.cpu().tolist()
+tot = 0.0
+print('round  singles  dense  tri  consumed  queries   tiles   ms    us/tile')
+for r in range(n):
+    q = cnt[r][0] + cnt[r][1] * 100 + cnt[r][2] * 7
+    tiles = (q + 31) // 32
+    tot += buf[r]
+    if q:
+        print('%4d %8d %6d %5d %8d %9d %7d %7.3f %8.2f' % (r, cnt[r][0], cnt[r][1], cnt[r][2], cnt[r][3], q, tiles,
+                                                          buf[r], buf[r] * 1e3 / max(tiles, 1)))
+print('total eval ms %.3f over %d launches' % (tot, n))
