@@ -49,6 +49,8 @@ typedef struct nefii_layer {
     const float *w_fwd;      /* packed [ (k_x+k_e)/8 ][ n_pad/32 ][64][4] */
     const float *w_bwd;      /* packed transpose for input gradients, or NULL */
     const float *bias;       /* [n_pad] */
+    const void *w_f16x3;     /* optional: fp16 hi/lo split of w_fwd * 64 in 32x32x16 fragment order
+                                [ (k_x+k_e)/16 ][ n_pad/32 ][ hi | lo ][64 lanes][8 halves]  (nefii_pack_linear_f16x3) */
 } nefii_layer;
 
 typedef struct nefii_mlp {
@@ -72,6 +74,12 @@ int nefii_abi_version(void);
 int nefii_pack_linear(const float *W, const float *bias, int n_out, int k_in,
                       int x_src0, int x_len, int e_src0, int e_len, float scale,
                       float *w_fwd, float *w_bwd, float *bias_pad, void *stream);
+
+/* fp16 hi/lo split of the same weights for the 3-MFMA split-precision path (x*w ~ xh*wh + xh*wl + xl*wh, fp32
+ * accumulate; the dropped xl*wl term is ~2^-22 relative).  Weights are pre-multiplied by 64 (exact) so that
+ * the lo halves of typical |w| ~ 0.05 stay normal fp16 numbers; the kernel scales accumulators by 1/64. */
+int nefii_pack_linear_f16x3(const float *W, int n_out, int k_in, int x_src0, int x_len, int e_src0, int e_len,
+                            float scale, void *w_f16x3, void *stream);
 
 /* Fused MLP forward over n points (replaces ImplicitNetwork.forward :85-108, RenderingNetwork.forward
  * :196-241 and EnvmapMaterialNetwork's diffuse_albedo_layers sg_envmap_material.py:369).
@@ -113,6 +121,8 @@ typedef struct nefii_tracer_params {
     float object_bounding_sphere, sdf_threshold, line_search_step;
     int32_t line_step_iters, sphere_tracing_iters, n_steps, n_rootfind_steps;
     int32_t training;
+    int32_t precision;       /* SDF evaluation inside the tracer: 0 = f32-input MFMA (exact fp32),
+                                1 = 3x fp16 split MFMA (needs w_f16x3 in every layer) */
 } nefii_tracer_params;
 
 size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *h_params);

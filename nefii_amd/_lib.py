@@ -25,7 +25,7 @@ c_float_p = ctypes.c_void_p     # device pointers travel as integers
 class Layer(ctypes.Structure):
     _fields_ = [('k_x', ctypes.c_int32), ('k_e', ctypes.c_int32), ('n_out', ctypes.c_int32),
                 ('n_pad', ctypes.c_int32), ('w_fwd', ctypes.c_void_p), ('w_bwd', ctypes.c_void_p),
-                ('bias', ctypes.c_void_p)]
+                ('bias', ctypes.c_void_p), ('w_f16x3', ctypes.c_void_p)]
 
 
 class Mlp(ctypes.Structure):
@@ -38,7 +38,7 @@ class TracerParams(ctypes.Structure):
     _fields_ = [('object_bounding_sphere', ctypes.c_float), ('sdf_threshold', ctypes.c_float),
                 ('line_search_step', ctypes.c_float), ('line_step_iters', ctypes.c_int32),
                 ('sphere_tracing_iters', ctypes.c_int32), ('n_steps', ctypes.c_int32),
-                ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32)]
+                ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32), ('precision', ctypes.c_int32)]
 
 
 P = ctypes.c_void_p
@@ -50,6 +50,7 @@ F = ctypes.c_float
 SIGNATURES = {
     'nefii_abi_version': (I, []),
     'nefii_pack_linear': (I, [P, P, I, I, I, I, I, I, F, P, P, P, P]),
+    'nefii_pack_linear_f16x3': (I, [P, I, I, I, I, I, I, F, P, P]),
     'nefii_mlp_forward': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P]),
     'nefii_mlp_backward': (I, [ctypes.POINTER(Mlp), P, I, P, I, I64, P, I, P]),
     'nefii_encode_inputs': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P]),

@@ -200,6 +200,115 @@ __device__ __forceinline__ void layer_gemm(const nefii_layer &L, const float *X,
     gemm_block(E, ES, L.k_e >> 3, wp + (size_t)(L.k_x >> 3) * n_tiles * 64, n_tiles, wave, lane, ntw, acc);
 }
 
+// ================================================================================================
+// Split-precision variant: operands as fp16 (hi, lo) pairs, three v_mfma_f32_32x32x16_f16 per 16-deep k-step
+//     x*w ~= xh*wh + xh*wl + xl*wh      (fp32 accumulate; every partial product is exact in fp32)
+// ~5.3x the f32-input MFMA rate with ~2^-22 relative operand error, i.e. fp32-class accuracy (a single fp16 or
+// bf16 pass fails the 1e-3 parity bar: BASELINE.md).  Activations live in LDS as two half arrays (row stride
+// 520 halves = 16 B * 65: ds_read_b128 of the A fragment stays conflict-free), weights stream from L2 in
+// 32x32x16 fragment order, hi block then lo block, pre-scaled by 64 (exact) so that lo halves stay normal.
+// ================================================================================================
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr int XS16 = 520;               // halves per X row
+constexpr int ES16 = 104;               // halves per E row (16 B * 13)
+constexpr float W16_SCALE = 64.f;
+
+struct Lds16 {
+    _Float16 Xh[TILE * XS16], Xl[TILE * XS16];
+    _Float16 Eh[TILE * ES16], El[TILE * ES16];
+};
+
+__device__ __forceinline__ void split16(float v, _Float16 &hi, _Float16 &lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+__device__ __forceinline__ void encode_tile16(const nefii_mlp &m, const float *raw, Lds16 &lds, int k_e) {
+    const int tid = threadIdx.x;
+    const int p = tid & 31, part = tid >> 5;
+    const int w0 = enc_width(m.enc_freqs[0]), w1 = enc_width(m.enc_freqs[1]), w2 = enc_width(m.enc_freqs[2]);
+    for (int c = part; c < k_e; c += 8) {
+        float val = 0.f;
+        if (c < w0) {
+            val = enc_value(raw + p * 9, c);
+        } else if (c < w0 + w1) {
+            val = enc_value(raw + p * 9 + 3, c - w0);
+        } else if (c < w0 + w1 + w2) {
+            val = enc_value(raw + p * 9 + 6, c - w0 - w1);
+        }
+        split16(val, lds.Eh[p * ES16 + c], lds.El[p * ES16 + c]);
+    }
+}
+
+// acc[j] += A[32 x 16*ksteps] * W for this wave's tiles.  wp: half8 index ((s*NT + t)*2 + part)*64 + lane
+__device__ __forceinline__ void gemm_block16(const _Float16 *Ah, const _Float16 *Al, int a_stride, int ksteps,
+                                             const half8 *__restrict__ wp, int NT, int wave, int lane, int ntw,
+                                             f32x16 (&acc)[4]) {
+    if (ksteps <= 0 || ntw <= 0) return;
+    const int r = lane & 31, h = lane >> 5;
+    const _Float16 *ah = Ah + r * a_stride + 8 * h;
+    const _Float16 *al = Al + r * a_stride + 8 * h;
+    half8 bh0[4], bl0[4], bh1[4], bl1[4], bh2[4], bl2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        bh0[j] = bl0[j] = bh1[j] = bl1[j] = bh2[j] = bl2[j] = (half8)(_Float16)0;
+        if (j < ntw) {
+            const size_t t = wave + 4 * j;
+            bh0[j] = wp[(t * 2) * 64 + lane];
+            bl0[j] = wp[(t * 2 + 1) * 64 + lane];
+            if (ksteps > 1) {
+                bh1[j] = wp[(((size_t)NT + t) * 2) * 64 + lane];
+                bl1[j] = wp[(((size_t)NT + t) * 2 + 1) * 64 + lane];
+            }
+        }
+    }
+    half8 a_hi = *reinterpret_cast<const half8 *>(ah), a_lo = *reinterpret_cast<const half8 *>(al);
+    for (int s = 0; s < ksteps; ++s) {
+        if (s + 2 < ksteps) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < ntw) {
+                    const size_t t = (size_t)(s + 2) * NT + wave + 4 * j;
+                    bh2[j] = wp[(t * 2) * 64 + lane];
+                    bl2[j] = wp[(t * 2 + 1) * 64 + lane];
+                }
+        }
+        half8 n_hi = a_hi, n_lo = a_lo;
+        if (s + 1 < ksteps) {
+            n_hi = *reinterpret_cast<const half8 *>(ah + 16 * (s + 1));
+            n_lo = *reinterpret_cast<const half8 *>(al + 16 * (s + 1));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < ntw) {
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh0[j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl0[j], acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh0[j], acc[j], 0, 0, 0);
+            }
+        a_hi = n_hi;
+        a_lo = n_lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bh0[j] = bh1[j];
+            bl0[j] = bl1[j];
+            bh1[j] = bh2[j];
+            bl1[j] = bl2[j];
+        }
+    }
+}
+
+__device__ __forceinline__ void layer_gemm16(const nefii_layer &L, const Lds16 &lds, int n_tiles, f32x16 (&acc)[4],
+                                             int &ntw) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    ntw = (n_tiles - wave + 3) >> 2;
+    if (ntw < 0) ntw = 0;
+    zero_acc(acc);
+    const half8 *wp = reinterpret_cast<const half8 *>(L.w_f16x3);
+    gemm_block16(lds.Xh, lds.Xl, XS16, L.k_x >> 4, wp, n_tiles, wave, lane, ntw, acc);
+    gemm_block16(lds.Eh, lds.El, ES16, L.k_e >> 4, wp + (size_t)(L.k_x >> 4) * n_tiles * 2 * 64, n_tiles, wave, lane,
+                 ntw, acc);
+}
+
 // accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
 #define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \

@@ -63,6 +63,44 @@ extern "C" int nefii_pack_linear(const float *W, const float *bias, int n_out, i
     return 0;
 }
 
+// fp16 hi/lo split in 32x32x16 fragment order: half8 index ((s*NT + t)*2 + part)*64 + lane, element j:
+// W[n = 32t + (lane&31)][k = 16s + 8(lane>>5) + j] * scale * 64
+__global__ void pack_linear_f16x3_kernel(const float *__restrict__ W, int n_out, int k_in, int kx, int ke, int n_pad,
+                                         int x_src0, int x_len, int e_src0, int e_len, float scale,
+                                         _Float16 *__restrict__ out) {
+    const int K = kx + ke, NT = n_pad >> 5;
+    const int total = (K >> 4) * NT * 64;          // (s, t, lane) triples
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, blk = idx >> 6;
+        const int t = blk % NT, st = blk / NT;
+        const int n = 32 * t + (lane & 31);
+        _Float16 *hi = out + (((size_t)blk * 2) * 64 + lane) * 8;
+        _Float16 *lo = out + (((size_t)blk * 2 + 1) * 64 + lane) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = 16 * st + 8 * (lane >> 5) + j;
+            const int c = src_col(kk, kx, x_src0, x_len, e_src0, e_len);
+            const float w = (n < n_out && c >= 0) ? W[(size_t)n * k_in + c] * scale * W16_SCALE : 0.f;
+            split16(w, hi[j], lo[j]);
+        }
+    }
+}
+
+extern "C" int nefii_pack_linear_f16x3(const float *W, int n_out, int k_in, int x_src0, int x_len, int e_src0, int e_len,
+                                       float scale, void *w_f16x3, void *stream) {
+    if (!W || !w_f16x3 || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
+    const int kx = round32(x_len), ke = round32(e_len), n_pad = round32(n_out);
+    if (n_pad > NEFII_MAX_WIDTH || kx > NEFII_MAX_WIDTH || ke > NEFII_MAX_ENC || kx + ke == 0) return NEFII_E_SHAPE;
+    if (x_src0 + x_len > k_in || e_src0 + e_len > k_in) return NEFII_E_SHAPE;
+    const int total = ((kx + ke) >> 4) * (n_pad >> 5) * 64;
+    int blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pack_linear_f16x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, n_out, k_in, kx, ke,
+                       n_pad, x_src0, x_len, e_src0, e_len, scale, (_Float16 *)w_f16x3);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // shared prologue: stage raw inputs + features of one 32-point tile, encode into E
 // ------------------------------------------------------------------------------------------------

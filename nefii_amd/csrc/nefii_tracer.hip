@@ -395,66 +395,71 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
 }
 
 // ---- SDF evaluation of one round's work list -------------------------------------------------
+// decode the 32 queries of a tile into points (raw[32][9]) and result addresses (dest[32])
+__device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, int64_t total, int n_single, int64_t n_sd,
+                                            float *raw, float **dest) {
+    const int tid = threadIdx.x;
+    if (tid >= TILE) return;
+    const int ns = P.p.n_steps;
+    int64_t q = tile * TILE + tid;
+    float *dst = nullptr;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (q < total) {
+        int64_t r;
+        float t;
+        if (q < n_single) {
+            const unsigned e = P.s.singles[q];
+            r = e >> 2;
+            const int kind = e & 3;
+            t = kind == Q_START ? P.s.t_s[r] : (kind == Q_END ? P.s.t_e[r] : P.s.mid[r]);
+            dst = kind == Q_END ? &P.s.res_e[r] : &P.s.res_s[r];
+        } else if (q >= n_sd) {
+            const int64_t qq = q - n_sd;
+            const int64_t ti = qq / 7;
+            const int j = (int)(qq - ti * 7);
+            r = P.s.tri[ti];
+            t = tri_depth(P.s.lo[r], P.s.hi[r], j);
+            dst = &P.s.big[(size_t)r * ns + j];
+        } else {
+            const int64_t qq = q - n_single;
+            const int64_t di = qq / ns;
+            const int i = (int)(qq - di * ns);
+            const unsigned e = P.s.dense[di];
+            r = e >> 1;
+            if (e & 1) {   // min-SDF search depths: steps * (max - min) + min   (ray_tracing.py:319)
+                const float tmin = P.s.t_min[r], tmax = P.s.t_max[r];
+                t = fadd(fmul(P.steps[i], fsub(tmax, tmin)), tmin);
+            } else {       // sampler depths: min + lin * (max - min)            (ray_tracing.py:205)
+                const float a = P.s.t_s[r];
+                t = fadd(a, fmul(P.lin[i], fsub(P.s.t_e[r], a)));
+            }
+            dst = &P.s.big[(size_t)r * ns + i];
+        }
+        px = fadd(P.o[r * 3], fmul(t, P.d[r * 3]));
+        py = fadd(P.o[r * 3 + 1], fmul(t, P.d[r * 3 + 1]));
+        pz = fadd(P.o[r * 3 + 2], fmul(t, P.d[r * 3 + 2]));
+    }
+    dest[tid] = dst;
+    float *rw = raw + tid * 9;
+    rw[0] = px, rw[1] = py, rw[2] = pz;
+    rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
+}
+
 __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int round) {
     __shared__ Lds lds;
     __shared__ float raw[TILE * 9];
     __shared__ float *dest[TILE];
-    const int tid = threadIdx.x;
     const int n_single = P.counters[round * 4 + 0];
     const int n_dense = P.counters[round * 4 + 1];
     const int n_tri = P.counters[round * 4 + 2];
-    const int ns = P.p.n_steps;
-    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * ns;
+    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
     const int64_t total = n_sd + (int64_t)n_tri * 7;
     const int64_t n_tiles = (total + TILE - 1) / TILE;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
     const int Lm1 = m.n_layers - 1;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (tid < TILE) {
-            int64_t q = tile * TILE + tid;
-            float *dst = nullptr;
-            float px = 0.f, py = 0.f, pz = 0.f;
-            if (q < total) {
-                int64_t r;
-                float t;
-                if (q < n_single) {
-                    const unsigned e = P.s.singles[q];
-                    r = e >> 2;
-                    const int kind = e & 3;
-                    t = kind == Q_START ? P.s.t_s[r] : (kind == Q_END ? P.s.t_e[r] : P.s.mid[r]);
-                    dst = kind == Q_END ? &P.s.res_e[r] : &P.s.res_s[r];
-                } else if (q >= n_sd) {
-                    const int64_t qq = q - n_sd;
-                    const int64_t ti = qq / 7;
-                    const int j = (int)(qq - ti * 7);
-                    r = P.s.tri[ti];
-                    t = tri_depth(P.s.lo[r], P.s.hi[r], j);
-                    dst = &P.s.big[(size_t)r * ns + j];
-                } else {
-                    const int64_t qq = q - n_single;
-                    const int64_t di = qq / ns;
-                    const int i = (int)(qq - di * ns);
-                    const unsigned e = P.s.dense[di];
-                    r = e >> 1;
-                    if (e & 1) {   // min-SDF search depths: steps * (max - min) + min   (ray_tracing.py:319)
-                        const float tmin = P.s.t_min[r], tmax = P.s.t_max[r];
-                        t = fadd(fmul(P.steps[i], fsub(tmax, tmin)), tmin);
-                    } else {       // sampler depths: min + lin * (max - min)            (ray_tracing.py:205)
-                        const float a = P.s.t_s[r];
-                        t = fadd(a, fmul(P.lin[i], fsub(P.s.t_e[r], a)));
-                    }
-                    dst = &P.s.big[(size_t)r * ns + i];
-                }
-                px = fadd(P.o[r * 3], fmul(t, P.d[r * 3]));
-                py = fadd(P.o[r * 3 + 1], fmul(t, P.d[r * 3 + 1]));
-                pz = fadd(P.o[r * 3 + 2], fmul(t, P.d[r * 3 + 2]));
-            }
-            dest[tid] = dst;
-            float *rw = raw + tid * 9;
-            rw[0] = px, rw[1] = py, rw[2] = pz;
-            rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
-        }
+        decode_tile(P, tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
         encode_tile(m, raw, lds.E, ke);
         __syncthreads();
@@ -469,6 +474,47 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int
             } else {
                 NEFII_FOR_ACC(acc, ntw, {
                     if (col == 0 && dest[row]) *dest[row] = val + L.bias[0];
+                })
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// split-precision variant (3 x fp16 MFMA per k-step, mlp_tile.h)
+__global__ __launch_bounds__(256, 2) void eval_kernel16(Params P, nefii_mlp m, int round) {
+    __shared__ Lds16 lds;
+    __shared__ float raw[TILE * 9];
+    __shared__ float *dest[TILE];
+    const int n_single = P.counters[round * 4 + 0];
+    const int n_dense = P.counters[round * 4 + 1];
+    const int n_tri = P.counters[round * 4 + 2];
+    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
+    const int64_t total = n_sd + (int64_t)n_tri * 7;
+    const int64_t n_tiles = (total + TILE - 1) / TILE;
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    const int Lm1 = m.n_layers - 1;
+    const float inv_scale = 1.f / W16_SCALE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        decode_tile(P, tile, total, n_single, n_sd, raw, dest);
+        __syncthreads();
+        encode_tile16(m, raw, lds, ke);
+        __syncthreads();
+        for (int l = 0; l <= Lm1; ++l) {
+            const nefii_layer &L = m.layer[l];
+            f32x16 acc[4];
+            int ntw;
+            layer_gemm16(L, lds, L.n_pad >> 5, acc, ntw);
+            __syncthreads();
+            if (l < Lm1) {
+                NEFII_FOR_ACC(acc, ntw, {
+                    const float hval = act_fwd(val * inv_scale + L.bias[col], m.act);
+                    split16(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                })
+            } else {
+                NEFII_FOR_ACC(acc, ntw, {
+                    if (col == 0 && dest[row]) *dest[row] = val * inv_scale + L.bias[0];
                 })
             }
             __syncthreads();
@@ -595,6 +641,10 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
         h_sdf->layer[0].k_x != 0)
         return NEFII_E_UNSUPPORTED;
     if (workspace_bytes < nefii_trace_workspace_bytes(n_rays, h_params)) return NEFII_E_SHAPE;
+    if (h_params->precision != 0 && h_params->precision != 1) return NEFII_E_ARG;
+    if (h_params->precision == 1)
+        for (int l = 0; l < h_sdf->n_layers; ++l)
+            if (!h_sdf->layer[l].w_f16x3) return NEFII_E_ARG;
     hipStream_t st = (hipStream_t)stream;
     const int rounds = nefii_trace_max_rounds(h_params);
     Params P;
@@ -636,7 +686,10 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
                 e1 = prof_event();
                 (void)hipEventRecord(e0, st);
             }
-            hipLaunchKernelGGL(eval_kernel, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);
+            if (h_params->precision == 1)
+                hipLaunchKernelGGL(eval_kernel16, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);
+            else
+                hipLaunchKernelGGL(eval_kernel, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);
             HIP_CHECK_LAUNCH();
             if (g_prof.on) (void)hipEventRecord(e1, st);
         }

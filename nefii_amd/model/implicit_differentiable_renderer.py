@@ -81,12 +81,12 @@ class ImplicitNetwork(nn.Module):
             bs.append(lin.bias)
         return ws, bs
 
-    def packed(self):
+    def packed(self, f16x3=False):
         """Packed MFMA-order weights; repacked only when a parameter changed (never, once geometry is frozen)."""
         ver = _params_version(self)
         dev = next(self.parameters()).device
-        if self._pm is None or self._pm.device != dev:
-            self._pm = ops.PackedMLP(self.specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, self.enc, 0, dev)
+        if self._pm is None or self._pm.device != dev or (f16x3 and not self._pm.f16x3):
+            self._pm = ops.PackedMLP(self.specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, self.enc, 0, dev, f16x3=f16x3)
             self._pm_version = None
         if self._pm_version != ver:
             with torch.no_grad():

@@ -1,5 +1,7 @@
 """RayTracing with the reference's constructor and forward signature (code/model/ray_tracing.py:6-101),
 executed by the round-based HIP tracer (csrc/nefii_tracer.hip)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -18,6 +20,8 @@ class RayTracing(nn.Module):
         self.n_steps = n_steps
         self.n_rootfind_steps = n_rootfind_steps
         self._net = None
+        # SDF arithmetic inside the tracer: 'f32' (f32-input MFMA, exact) or 'f16x3' (3x fp16 split MFMA)
+        self.precision = os.environ.get('NEFII_TRACER_PRECISION', 'f32')
         self._lin = None
         self.last_counters = None
         self.counter_sum = None       # summed over calls while collect_counters (primary + secondary traces)
@@ -63,8 +67,8 @@ class RayTracing(nn.Module):
                 # drawn on the host exactly like minimal_sdf_points (:316); always drawn (the reference draws only
                 # when some ray needs the search, a data-dependent host sync this build avoids)
                 steps = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
-        params = ops.make_tracer_params(self._cfg(), self.training)
-        res = ops.trace_rays(net.packed(), params, origins, dirs, object_mask.reshape(-1), self._lin, steps,
+        params = ops.make_tracer_params(self._cfg(), self.training, self.precision)
+        res = ops.trace_rays(net.packed(f16x3=(self.precision == 'f16x3')), params, origins, dirs, object_mask.reshape(-1), self._lin, steps,
                              want_counters=self.collect_counters)
         if self.collect_counters:
             self.last_counters = res[3]

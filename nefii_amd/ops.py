@@ -50,7 +50,7 @@ class LayerSpec:
 class PackedMLP:
     """Device-resident packed weights + the nefii_mlp descriptor of one fused MLP."""
 
-    def __init__(self, specs, act, head, enc_freqs, feat_width, device, need_bwd=True):
+    def __init__(self, specs, act, head, enc_freqs, feat_width, device, need_bwd=True, f16x3=False):
         assert 1 <= len(specs) <= _lib.MAX_LAYERS
         self.specs = specs
         self.act, self.head = act, head
@@ -58,7 +58,8 @@ class PackedMLP:
         self.feat_width = feat_width
         self.device = device
         self.need_bwd = need_bwd
-        self.w_fwd, self.w_bwd, self.bias = [], [], []
+        self.w_fwd, self.w_bwd, self.bias, self.w_f16 = [], [], [], []
+        self.f16x3 = f16x3
         m = Mlp()
         m.n_layers, m.act, m.head, m.feat_width = len(specs), act, head, feat_width
         for i in range(3):
@@ -68,11 +69,13 @@ class PackedMLP:
             self.w_fwd.append(torch.zeros(k * s.n_pad, device=device, dtype=torch.float32))
             self.w_bwd.append(torch.zeros(k * s.n_pad, device=device, dtype=torch.float32) if need_bwd else None)
             self.bias.append(torch.zeros(s.n_pad, device=device, dtype=torch.float32))
+            self.w_f16.append(torch.zeros(2 * k * s.n_pad, device=device, dtype=torch.float16) if f16x3 else None)
             L = m.layer[l]
             L.k_x, L.k_e, L.n_out, L.n_pad = s.k_x, s.k_e, s.n_out, s.n_pad
             L.w_fwd = self.w_fwd[l].data_ptr()
             L.w_bwd = self.w_bwd[l].data_ptr() if need_bwd else None
             L.bias = self.bias[l].data_ptr()
+            L.w_f16x3 = self.w_f16[l].data_ptr() if f16x3 else None
         self.struct = m
         self.hidden_stride = max(s.n_pad for s in specs)
         self.packed_version = None
@@ -97,6 +100,9 @@ class PackedMLP:
                                              s.scale, _ptr(self.w_fwd[l]),
                                              _ptr(self.w_bwd[l]) if self.need_bwd else None, _ptr(self.bias[l]), st),
                        'nefii_pack_linear')
+            if self.f16x3:
+                _lib.check(lib.nefii_pack_linear_f16x3(_ptr(w), s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0, s.e_len,
+                                                       s.scale, _ptr(self.w_f16[l]), st), 'nefii_pack_linear_f16x3')
 
 
 def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False):
@@ -205,8 +211,12 @@ def sdf_value_grad(pm, x, want_feat=False):
     return out, feat, grad
 
 
-def make_tracer_params(cfg, training):
+PRECISIONS = {'f32': 0, 'f16x3': 1}
+
+
+def make_tracer_params(cfg, training, precision='f32'):
     p = TracerParams()
+    p.precision = PRECISIONS[precision]
     p.object_bounding_sphere = cfg.get('object_bounding_sphere', 1.0)
     p.sdf_threshold = cfg.get('sdf_threshold', 5.0e-5)
     p.line_search_step = cfg.get('line_search_step', 0.5)

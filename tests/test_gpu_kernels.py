@@ -28,10 +28,10 @@ def ball_points(n, seed):
     return x / x.norm(dim=-1, keepdim=True) * torch.rand(n, 1, generator=g) ** (1 / 3)
 
 
-def build_sdf(mc, sd):
+def build_sdf(mc, sd, f16x3=False):
     from nefii_amd import ops
     specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
-    pm = ops.PackedMLP(specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, enc, 0, DEV)
+    pm = ops.PackedMLP(specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, enc, 0, DEV, f16x3=f16x3)
     ws, bs = [], []
     for l in range(len(specs)):
         w, b = nets.linear_params(sd, 'implicit_network.lin%d' % l)
@@ -145,10 +145,10 @@ def test_camera_rays(golden):
     assert torch.equal(o.cpu()[:, 0], c_ref)
 
 
-def run_gpu_trace(mc, sd, o, d, om, training, steps):
+def run_gpu_trace(mc, sd, o, d, om, training, steps, precision='f32'):
     from nefii_amd import ops
-    pm = build_sdf(mc, sd)
-    tp = ops.make_tracer_params(mc['ray_tracer'], training)
+    pm = build_sdf(mc, sd, f16x3=(precision == 'f16x3'))
+    tp = ops.make_tracer_params(mc['ray_tracer'], training, precision)
     lin = torch.linspace(0, 1, steps=tp.n_steps).to(DEV)
     st = steps.to(DEV) if steps is not None else torch.rand(tp.n_steps).to(DEV)
     return ops.trace_rays(pm, tp, o.to(DEV).contiguous(), d.to(DEV).contiguous(), om.to(DEV), lin, st,
@@ -209,8 +209,9 @@ def test_tracer_golden(golden, tag, name, hidden, bumpy):
     compare_trace(sdf, g['o2'], g['d2'], got, g['sec_hit'], g['sec_dists'], (tag, 'secondary'))
 
 
+@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
 @pytest.mark.parametrize('hidden,bumpy,n', [(64, 0.03, 5000), (64, 0.0, 3000), (512, 0.004, 1500)])
-def test_tracer_vs_oracle_and_counts(hidden, bumpy, n):
+def test_tracer_vs_oracle_and_counts(hidden, bumpy, n, precision):
     """Larger seeded batches incl. rays that miss the bounding sphere, ragged tile counts, masked-out rays;
     the kernel's per-round query counters must equal the oracle's SDF evaluation counts."""
     mc = syn.model_conf('physg', hidden=hidden)
@@ -226,8 +227,8 @@ def test_tracer_vs_oracle_and_counts(hidden, bumpy, n):
     steps = torch.rand(100, generator=g)
     for training in (False, True):
         ref = tracer.trace(sdf, o, d, om, mc['ray_tracer'], training, steps)
-        got = run_gpu_trace(mc, sd, o, d, om, training, steps)
-        compare_trace(sdf, o, d, got, ref['hit'], ref['dists'], (hidden, bumpy, training),
+        got = run_gpu_trace(mc, sd, o, d, om, training, steps, precision)
+        compare_trace(sdf, o, d, got, ref['hit'], ref['dists'], (hidden, bumpy, training, precision),
                       argmin_set(ref['hit'], om, training))
         cnt = got[3].cpu().long()
         gpu_evals = (cnt[:, 0] + cnt[:, 1] * 100 + cnt[:, 3]).sum().item()     # algorithmic (header: counters)
