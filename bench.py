@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (never the 2:1-sparse figure)
 
 
 def sdf_flops_per_eval(specs):
@@ -169,9 +170,16 @@ def main():
         f_eval = sdf_flops_per_eval(model.implicit_network.specs)
         achieved = queries * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
         hit_frac = out['network_object_mask'].float().mean().item()
-        roofline = {'bound': 'mfma', 'kernel': 'eval_kernel (fused SDF MLP over the tracer work list)',
-                    'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+        prec = model.ray_tracer.precision
+        split = prec.startswith('f16x3')
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        roofline = {'bound': 'mfma',
+                    'kernel': {'f32': 'eval_kernel', 'f16x3': 'eval_kernel16', 'f16x3w': 'eval_kernel16w'}[prec] +
+                              ' (fused SDF MLP over the tracer work list)',
+                    'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                    'arithmetic': ('3x v_mfma_f32_32x32x16_f16 per k-step on fp16 hi/lo operand pairs, fp32 accumulate: '
+                                   'achieved counts ALGORITHMIC flops (the matrix cores issue 3x that)') if split
+                                  else 'v_mfma_f32_32x32x2_f32 (exact fp32)',
                     'flops_per_sdf_eval': f_eval, 'sdf_evals_per_step': queries, 'sdf_evals_executed': executed,
                     'sdf_evals_per_primary_ray': queries / rays_per_rank,
                     'nonempty_launches_per_step': launches, 'launches_per_step': n_eval.value,
@@ -180,7 +188,8 @@ def main():
         result = {
             'metric': 'training rays/sec (Step-2 material opt)', 'value': value, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16x3' if model.ray_tracer.precision.startswith('f16x3') else 'f32', 'data': 'synthetic',
             'config': {'workload': '%s: robot-like synthetic scene (geometric-init SDF), %s model, num_pixels=%d per GPU'
                                    '%s, 128 SG lobes, %s, frozen geometry, fwd+IDRLoss+bwd+2xAdam'
                                    % (args.workload, {'physg': 'physg.conf', 'conf': 'conf.conf', 'neus': 'conf_neus.conf'}[w['model']],

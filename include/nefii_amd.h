@@ -122,7 +122,8 @@ typedef struct nefii_tracer_params {
     int32_t line_step_iters, sphere_tracing_iters, n_steps, n_rootfind_steps;
     int32_t training;
     int32_t precision;       /* SDF evaluation inside the tracer: 0 = f32-input MFMA (exact fp32),
-                                1 = 3x fp16 split MFMA (needs w_f16x3 in every layer) */
+                                1 = 3x fp16 split MFMA, 32-query tiles; 2 = the same arithmetic on 64-query tiles
+                                (8 waves, weight fragments shared by two row tiles); 1 and 2 need w_f16x3 */
 } nefii_tracer_params;
 
 size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *h_params);

@@ -309,6 +309,135 @@ __device__ __forceinline__ void layer_gemm16(const nefii_layer &L, const Lds16 &
                  ntw, acc);
 }
 
+// ---- wide variant: 64 rows per workgroup, 8 waves; a wave owns a 64-column pair of tiles for BOTH 32-row
+// halves, so every weight fragment it pulls from L2 feeds two MFMA row tiles (half the L2 bytes per query:
+// the 32-row kernel is bound by the ~41 GB/s/CU it can stream from L2, not by the matrix cores).
+constexpr int TILE_W = 64;
+constexpr int WG_W = 512;
+struct Lds16w {
+    _Float16 Xh[TILE_W * XS16], Xl[TILE_W * XS16];
+    _Float16 Eh[TILE_W * ES16], El[TILE_W * ES16];
+};
+
+__device__ __forceinline__ void encode_tile16w(const nefii_mlp &m, const float *raw, Lds16w &lds, int k_e) {
+    const int tid = threadIdx.x;
+    const int p = tid & 63, part = tid >> 6;
+    const int w0 = enc_width(m.enc_freqs[0]), w1 = enc_width(m.enc_freqs[1]), w2 = enc_width(m.enc_freqs[2]);
+    for (int c = part; c < k_e; c += 8) {
+        float val = 0.f;
+        if (c < w0) {
+            val = enc_value(raw + p * 9, c);
+        } else if (c < w0 + w1) {
+            val = enc_value(raw + p * 9 + 3, c - w0);
+        } else if (c < w0 + w1 + w2) {
+            val = enc_value(raw + p * 9 + 6, c - w0 - w1);
+        }
+        split16(val, lds.Eh[p * ES16 + c], lds.El[p * ES16 + c]);
+    }
+}
+
+// acc[rt*2 + ct] += A[rows 32rt..][16*ksteps] * W[tiles 2*wave + ct]   (nct = column tiles of this wave: 0..2)
+__device__ __forceinline__ void gemm_block16w(const _Float16 *Ah, const _Float16 *Al, int a_stride, int ksteps,
+                                              const half8 *__restrict__ wp, int NT, int wave, int lane, int nct,
+                                              f32x16 (&acc)[4]) {
+    if (ksteps <= 0 || nct <= 0) return;
+    const int r = lane & 31, h = lane >> 5;
+    const _Float16 *ah = Ah + r * a_stride + 8 * h;
+    const _Float16 *al = Al + r * a_stride + 8 * h;
+    const int rt_off = 32 * a_stride;
+    constexpr int D = 3;                       // weight fragments run D-1 k-steps ahead (4 spills registers)
+    half8 bh[D][2], bl[D][2];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) bh[d][c] = bl[d][c] = (half8)(_Float16)0;
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (d < ksteps)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < nct) {
+                    const size_t t = (size_t)d * NT + 2 * wave + c;
+                    bh[d][c] = wp[(t * 2) * 64 + lane];
+                    bl[d][c] = wp[(t * 2 + 1) * 64 + lane];
+                }
+    half8 a_hi[2], a_lo[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        a_hi[rt] = *reinterpret_cast<const half8 *>(ah + rt * rt_off);
+        a_lo[rt] = *reinterpret_cast<const half8 *>(al + rt * rt_off);
+    }
+    for (int s = 0; s < ksteps; ++s) {
+        if (s + D - 1 < ksteps) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < nct) {
+                    const size_t t = (size_t)(s + D - 1) * NT + 2 * wave + c;
+                    bh[D - 1][c] = wp[(t * 2) * 64 + lane];
+                    bl[D - 1][c] = wp[(t * 2 + 1) * 64 + lane];
+                }
+        }
+        half8 n_hi[2], n_lo[2];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            n_hi[rt] = a_hi[rt];
+            n_lo[rt] = a_lo[rt];
+            if (s + 1 < ksteps) {
+                n_hi[rt] = *reinterpret_cast<const half8 *>(ah + rt * rt_off + 16 * (s + 1));
+                n_lo[rt] = *reinterpret_cast<const half8 *>(al + rt * rt_off + 16 * (s + 1));
+            }
+        }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (c < nct) {
+                    f32x16 &a = acc[rt * 2 + c];
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], bh[0][c], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], bl[0][c], a, 0, 0, 0);
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[rt], bh[0][c], a, 0, 0, 0);
+                }
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            a_hi[rt] = n_hi[rt];
+            a_lo[rt] = n_lo[rt];
+        }
+#pragma unroll
+        for (int d = 0; d < D - 1; ++d)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                bh[d][c] = bh[d + 1][c];
+                bl[d][c] = bl[d + 1][c];
+            }
+    }
+}
+
+__device__ __forceinline__ void layer_gemm16w(const nefii_layer &L, const Lds16w &lds, int n_tiles, f32x16 (&acc)[4],
+                                              int &nct) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    nct = n_tiles - 2 * wave;
+    nct = nct < 0 ? 0 : (nct > 2 ? 2 : nct);
+    zero_acc(acc);
+    const half8 *wp = reinterpret_cast<const half8 *>(L.w_f16x3);
+    gemm_block16w(lds.Xh, lds.Xl, XS16, L.k_x >> 4, wp, n_tiles, wave, lane, nct, acc);
+    gemm_block16w(lds.Eh, lds.El, ES16, L.k_e >> 4, wp + (size_t)(L.k_x >> 4) * n_tiles * 2 * 64, n_tiles, wave, lane,
+                  nct, acc);
+}
+
+#define NEFII_FOR_ACC_W(acc, nct, BODY)                                                   \
+    {                                                                                     \
+        const int _wave = threadIdx.x >> 6, _lane = threadIdx.x & 63;                     \
+        _Pragma("unroll") for (int _rt = 0; _rt < 2; ++_rt)                               \
+        _Pragma("unroll") for (int _c = 0; _c < 2; ++_c) if (_c < (nct)) {                \
+            const int col = 32 * (2 * _wave + _c) + (_lane & 31);                         \
+            _Pragma("unroll") for (int _i = 0; _i < 16; ++_i) {                           \
+                const int row = 32 * _rt + (_i & 3) + 8 * (_i >> 2) + 4 * (_lane >> 5);   \
+                const float val = (acc)[_rt * 2 + _c][_i];                                \
+                BODY                                                                      \
+            }                                                                             \
+        }                                                                                 \
+    }
+
 // accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
 #define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \

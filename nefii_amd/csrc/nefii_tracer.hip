@@ -396,12 +396,13 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
 
 // ---- SDF evaluation of one round's work list -------------------------------------------------
 // decode the 32 queries of a tile into points (raw[32][9]) and result addresses (dest[32])
+template <int ROWS>
 __device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, int64_t total, int n_single, int64_t n_sd,
                                             float *raw, float **dest) {
     const int tid = threadIdx.x;
-    if (tid >= TILE) return;
+    if (tid >= ROWS) return;
     const int ns = P.p.n_steps;
-    int64_t q = tile * TILE + tid;
+    int64_t q = tile * ROWS + tid;
     float *dst = nullptr;
     float px = 0.f, py = 0.f, pz = 0.f;
     if (q < total) {
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
     const int Lm1 = m.n_layers - 1;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile(P, tile, total, n_single, n_sd, raw, dest);
+        decode_tile<TILE>(P, tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
         encode_tile(m, raw, lds.E, ke);
         __syncthreads();
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel16(Params P, nefii_mlp m, i
     const int Lm1 = m.n_layers - 1;
     const float inv_scale = 1.f / W16_SCALE;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile(P, tile, total, n_single, n_sd, raw, dest);
+        decode_tile<TILE>(P, tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
         encode_tile16(m, raw, lds, ke);
         __syncthreads();
@@ -514,6 +515,47 @@ __global__ __launch_bounds__(256, 2) void eval_kernel16(Params P, nefii_mlp m, i
                 })
             } else {
                 NEFII_FOR_ACC(acc, ntw, {
+                    if (col == 0 && dest[row]) *dest[row] = val * inv_scale + L.bias[0];
+                })
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// wide split-precision variant: 64 queries per workgroup of 8 waves (mlp_tile.h, Lds16w)
+__global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, int round) {
+    __shared__ Lds16w lds;
+    __shared__ float raw[TILE_W * 9];
+    __shared__ float *dest[TILE_W];
+    const int n_single = P.counters[round * 4 + 0];
+    const int n_dense = P.counters[round * 4 + 1];
+    const int n_tri = P.counters[round * 4 + 2];
+    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
+    const int64_t total = n_sd + (int64_t)n_tri * 7;
+    const int64_t n_tiles = (total + TILE_W - 1) / TILE_W;
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    const int Lm1 = m.n_layers - 1;
+    const float inv_scale = 1.f / W16_SCALE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        decode_tile<TILE_W>(P, tile, total, n_single, n_sd, raw, dest);
+        __syncthreads();
+        encode_tile16w(m, raw, lds, ke);
+        __syncthreads();
+        for (int l = 0; l <= Lm1; ++l) {
+            const nefii_layer &L = m.layer[l];
+            f32x16 acc[4];
+            int nct;
+            layer_gemm16w(L, lds, L.n_pad >> 5, acc, nct);
+            __syncthreads();
+            if (l < Lm1) {
+                NEFII_FOR_ACC_W(acc, nct, {
+                    const float hval = act_fwd(val * inv_scale + L.bias[col], m.act);
+                    split16(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                })
+            } else {
+                NEFII_FOR_ACC_W(acc, nct, {
                     if (col == 0 && dest[row]) *dest[row] = val * inv_scale + L.bias[0];
                 })
             }
@@ -641,8 +683,8 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
         h_sdf->layer[0].k_x != 0)
         return NEFII_E_UNSUPPORTED;
     if (workspace_bytes < nefii_trace_workspace_bytes(n_rays, h_params)) return NEFII_E_SHAPE;
-    if (h_params->precision != 0 && h_params->precision != 1) return NEFII_E_ARG;
-    if (h_params->precision == 1)
+    if (h_params->precision < 0 || h_params->precision > 2) return NEFII_E_ARG;
+    if (h_params->precision >= 1)
         for (int l = 0; l < h_sdf->n_layers; ++l)
             if (!h_sdf->layer[l].w_f16x3) return NEFII_E_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -669,6 +711,8 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
     int64_t max_q = n_rays * (int64_t)h_params->n_steps;      // n_steps >= 8 > 7 (bisection tree) > 2 (both ends)
     int64_t max_tiles = (max_q + TILE - 1) / TILE;
     const int eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
+    const int64_t max_tiles_w = (max_q + TILE_W - 1) / TILE_W;
+    const int eval_blocks_w = (int)(max_tiles_w < 512 ? max_tiles_w : 512);
     if (g_prof.on) {
         if (!g_prof.t0) {
             (void)hipEventCreate(&g_prof.t0);
@@ -686,7 +730,9 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
                 e1 = prof_event();
                 (void)hipEventRecord(e0, st);
             }
-            if (h_params->precision == 1)
+            if (h_params->precision == 2)
+                hipLaunchKernelGGL(eval_kernel16w, dim3(eval_blocks_w), dim3(WG_W), 0, st, P, *h_sdf, r);
+            else if (h_params->precision == 1)
                 hipLaunchKernelGGL(eval_kernel16, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);
             else
                 hipLaunchKernelGGL(eval_kernel, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);

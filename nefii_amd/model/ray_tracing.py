@@ -20,8 +20,9 @@ class RayTracing(nn.Module):
         self.n_steps = n_steps
         self.n_rootfind_steps = n_rootfind_steps
         self._net = None
-        # SDF arithmetic inside the tracer: 'f32' (f32-input MFMA, exact) or 'f16x3' (3x fp16 split MFMA)
-        self.precision = os.environ.get('NEFII_TRACER_PRECISION', 'f32')
+        # SDF arithmetic inside the tracer: 'f16x3w' (default: 3x fp16 hi/lo split MFMA, fp32-class accuracy,
+        # 64-query tiles), 'f16x3' (same arithmetic, 32-query tiles) or 'f32' (f32-input MFMA, bit-exact fp32 fma)
+        self.precision = os.environ.get('NEFII_TRACER_PRECISION', 'f16x3w')
         self._lin = None
         self.last_counters = None
         self.counter_sum = None       # summed over calls while collect_counters (primary + secondary traces)
@@ -68,7 +69,7 @@ class RayTracing(nn.Module):
                 # when some ray needs the search, a data-dependent host sync this build avoids)
                 steps = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
         params = ops.make_tracer_params(self._cfg(), self.training, self.precision)
-        res = ops.trace_rays(net.packed(f16x3=(self.precision == 'f16x3')), params, origins, dirs, object_mask.reshape(-1), self._lin, steps,
+        res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs, object_mask.reshape(-1), self._lin, steps,
                              want_counters=self.collect_counters)
         if self.collect_counters:
             self.last_counters = res[3]

@@ -211,7 +211,7 @@ def sdf_value_grad(pm, x, want_feat=False):
     return out, feat, grad
 
 
-PRECISIONS = {'f32': 0, 'f16x3': 1}
+PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}
 
 
 def make_tracer_params(cfg, training, precision='f32'):

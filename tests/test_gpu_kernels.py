@@ -147,7 +147,7 @@ def test_camera_rays(golden):
 
 def run_gpu_trace(mc, sd, o, d, om, training, steps, precision='f32'):
     from nefii_amd import ops
-    pm = build_sdf(mc, sd, f16x3=(precision == 'f16x3'))
+    pm = build_sdf(mc, sd, f16x3=precision.startswith('f16x3'))
     tp = ops.make_tracer_params(mc['ray_tracer'], training, precision)
     lin = torch.linspace(0, 1, steps=tp.n_steps).to(DEV)
     st = steps.to(DEV) if steps is not None else torch.rand(tp.n_steps).to(DEV)
@@ -209,7 +209,7 @@ def test_tracer_golden(golden, tag, name, hidden, bumpy):
     compare_trace(sdf, g['o2'], g['d2'], got, g['sec_hit'], g['sec_dists'], (tag, 'secondary'))
 
 
-@pytest.mark.parametrize('precision', ['f32', 'f16x3'])
+@pytest.mark.parametrize('precision', ['f32', 'f16x3', 'f16x3w'])
 @pytest.mark.parametrize('hidden,bumpy,n', [(64, 0.03, 5000), (64, 0.0, 3000), (512, 0.004, 1500)])
 def test_tracer_vs_oracle_and_counts(hidden, bumpy, n, precision):
     """Larger seeded batches incl. rays that miss the bounding sphere, ragged tile counts, masked-out rays;
