@@ -29,10 +29,11 @@ def build(force=False, verbose=True):
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    extra = os.environ.get('NEFII_EXTRA_HIPCC_FLAGS', '').split()
     objs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace('.hip', '.o'))
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o]
+        cmd = [hipcc] + FLAGS + extra + ['-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

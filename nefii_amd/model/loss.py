@@ -22,10 +22,12 @@ class IDRLoss(nn.Module):
         self.eikonal_weight = eikonal_weight
         self.mask_weight = mask_weight
         self.alpha = alpha
-        losses = {'L1': nn.L1Loss(reduction='mean'), 'L2': nn.MSELoss(reduction='mean'),
-                  'L1_smooth': nn.SmoothL1Loss(reduction='mean', beta=1.0)}
-        self.img_loss = losses[loss_type]
-        self.env_loss = {'L1': nn.L1Loss(reduction='mean'), 'L2': nn.MSELoss(reduction='mean')}[env_loss_type]
+        if loss_type not in ('L1', 'L2', 'L1_smooth'):
+            raise Exception('Unknown loss_type!')
+        if env_loss_type not in ('L1', 'L2'):
+            raise Exception('Unknown env_loss_type!')
+        self.loss_type = loss_type
+        self.env_loss_type = env_loss_type
         self.r_patch = int(r_patch)
         self.normalsmooth_weight = normalsmooth_weight
 
@@ -33,18 +35,33 @@ class IDRLoss(nn.Module):
     def _zero(ref):
         return torch.zeros((), device=ref.device, dtype=torch.float32)
 
+    # Masked reductions are written as (sum of masked terms) / max(count, 1): the same values as the reference's
+    # boolean-index + mean formulation, without its data-dependent shapes - no host synchronisation per term.
+    @staticmethod
+    def _masked_mean(per_elem, mask, width):
+        cnt = mask.sum()
+        return (per_elem * mask.unsqueeze(-1)).sum() / torch.clamp(cnt * width, min=1)
+
+    def _img_err(self, a, b, kind):
+        d = a - b
+        if kind == 'L1':
+            return d.abs()
+        if kind == 'L2':
+            return d * d
+        ad = d.abs()          # SmoothL1, beta = 1
+        return torch.where(ad < 1.0, 0.5 * d * d, ad - 0.5)
+
     def get_rgb_loss(self, idr_rgb_values, sg_rgb_values, rgb_gt, network_object_mask, object_mask):
-        mask = network_object_mask & object_mask
-        if mask.sum() == 0:
-            return self._zero(rgb_gt), self._zero(rgb_gt)
-        gt = rgb_gt.reshape(-1, 3)[mask]
-        return self.img_loss(idr_rgb_values[mask], gt), self.img_loss(sg_rgb_values[mask], gt)
+        mask = (network_object_mask & object_mask).to(rgb_gt.dtype)
+        gt = rgb_gt.reshape(-1, 3)
+        return (self._masked_mean(self._img_err(idr_rgb_values, gt, self.loss_type), mask, 3),
+                self._masked_mean(self._img_err(sg_rgb_values, gt, self.loss_type), mask, 3))
 
     def get_background_rgb_loss(self, sg_rgb_values, rgb_gt, network_object_mask, object_mask):
-        mask = (~network_object_mask) & (~object_mask)
-        if self.background_rgb_weight <= 0 or mask.sum() == 0:
+        if self.background_rgb_weight <= 0:
             return self._zero(rgb_gt)
-        return self.env_loss(sg_rgb_values[mask], rgb_gt.reshape(-1, 3)[mask])
+        mask = ((~network_object_mask) & (~object_mask)).to(rgb_gt.dtype)
+        return self._masked_mean(self._img_err(sg_rgb_values, rgb_gt.reshape(-1, 3), self.env_loss_type), mask, 3)
 
     def get_eikonal_loss(self, grad_theta, ref):
         if grad_theta is None or grad_theta.shape[0] == 0:
@@ -52,22 +69,18 @@ class IDRLoss(nn.Module):
         return ((grad_theta.norm(2, dim=1) - 1) ** 2).mean()
 
     def get_mask_loss(self, sdf_output, network_object_mask, object_mask):
-        mask = ~(network_object_mask & object_mask)
-        if mask.sum() == 0:
-            return self._zero(sdf_output)
-        sdf_pred = -self.alpha * sdf_output[mask]
-        gt = object_mask[mask].float()
-        return (1 / self.alpha) * F.binary_cross_entropy_with_logits(sdf_pred.squeeze(-1), gt, reduction='sum') / \
-            float(object_mask.shape[0])
+        mask = (~(network_object_mask & object_mask)).to(sdf_output.dtype)
+        sdf_pred = (-self.alpha * sdf_output).squeeze(-1)
+        bce = F.binary_cross_entropy_with_logits(sdf_pred, object_mask.to(sdf_output.dtype), reduction='none')
+        return (1 / self.alpha) * (bce * mask).sum() / float(object_mask.shape[0])
 
     def get_normalsmooth_loss(self, normal, network_object_mask, object_mask):
         if self.r_patch < 1 or self.normalsmooth_weight == 0.:
             return self._zero(normal)
         k = 4 * self.r_patch * self.r_patch
-        mask = (network_object_mask & object_mask).reshape(-1, k).all(dim=-1)
-        if mask.sum() == 0:
-            return self._zero(normal)
-        return torch.mean(torch.var(normal.view((-1, k, 3)), dim=1)[mask])
+        mask = (network_object_mask & object_mask).reshape(-1, k).all(dim=-1).to(normal.dtype)
+        var = torch.var(normal.view((-1, k, 3)), dim=1)
+        return self._masked_mean(var, mask, 3)
 
     def forward(self, model_outputs, ground_truth):
         rgb_gt = ground_truth['rgb']

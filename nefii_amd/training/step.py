@@ -47,9 +47,12 @@ class TrainStep:
         self.secondary_batch_size = secondary_batch_size // max(world_size, 1)
         self.num_rays = max(num_rays, 1)
         self.cur_iter = 0
+        # same Adam as the reference (idr_train.py:188-196); `fused` only selects torch's single-kernel
+        # implementation of the identical update when the parameters live on the GPU
+        fused = next(model.parameters()).is_cuda
         self.idr_optimizer = torch.optim.Adam(list(model.implicit_network.parameters()) +
-                                              list(model.rendering_network.parameters()), lr=idr_lr)
-        self.sg_optimizer = torch.optim.Adam(model.envmap_material_network.parameters(), lr=sg_lr)
+                                              list(model.rendering_network.parameters()), lr=idr_lr, fused=fused)
+        self.sg_optimizer = torch.optim.Adam(model.envmap_material_network.parameters(), lr=sg_lr, fused=fused)
         self.trainable = [p for p in model.parameters() if p.requires_grad]
 
     def __call__(self, model_input, ground_truth):
