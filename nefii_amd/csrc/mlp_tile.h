@@ -337,84 +337,90 @@ __device__ __forceinline__ void encode_tile16w(const nefii_mlp &m, const float *
 }
 
 // acc[rt*2 + ct] += A[rows 32rt..][16*ksteps] * W[tiles 2*wave + ct]   (nct = column tiles of this wave: 0..2)
-__device__ __forceinline__ void gemm_block16w(const _Float16 *Ah, const _Float16 *Al, int a_stride, int ksteps,
-                                              const half8 *__restrict__ wp, int NT, int wave, int lane, int nct,
-                                              f32x16 (&acc)[4]) {
-    if (ksteps <= 0 || nct <= 0) return;
+// Three statically named register stages for the weight fragments (two k-steps in flight) and for the A fragments
+// (one k-step ahead); the k-loop is unrolled by three so that no stage is ever copied (a rotating buffer costs
+// 48 v_mov per k-step, a third of the MFMA issue time).
+struct Stage16w {
+    half8 bh[2], bl[2];      // weight fragments of the wave's two column tiles
+    half8 ah[2], al[2];      // activation fragments of the two row tiles
+};
+
+template <bool TWO_COLS>
+__device__ __forceinline__ void load_b16w(Stage16w &st, const half8 *__restrict__ wp, int NT, int wave, int lane, int s) {
+    const size_t t = (size_t)s * NT + 2 * wave;
+    st.bh[0] = wp[(t * 2) * 64 + lane];
+    st.bl[0] = wp[(t * 2 + 1) * 64 + lane];
+    if (TWO_COLS) {
+        st.bh[1] = wp[((t + 1) * 2) * 64 + lane];
+        st.bl[1] = wp[((t + 1) * 2 + 1) * 64 + lane];
+    }
+}
+
+__device__ __forceinline__ void load_a16w(Stage16w &st, const _Float16 *ah, const _Float16 *al, int rt_off, int s) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        st.ah[rt] = *reinterpret_cast<const half8 *>(ah + rt * rt_off + 16 * s);
+        st.al[rt] = *reinterpret_cast<const half8 *>(al + rt * rt_off + 16 * s);
+    }
+}
+
+template <bool TWO_COLS>
+__device__ __forceinline__ void mfma16w(const Stage16w &st, f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c = 0; c < (TWO_COLS ? 2 : 1); ++c) {
+            f32x16 &a = acc[rt * 2 + c];
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.ah[rt], st.bh[c], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.ah[rt], st.bl[c], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.al[rt], st.bh[c], a, 0, 0, 0);
+        }
+}
+
+template <bool TWO_COLS>
+__device__ __forceinline__ void gemm_block16w_t(const _Float16 *Ah, const _Float16 *Al, int a_stride, int ksteps,
+                                                const half8 *__restrict__ wp, int NT, int wave, int lane,
+                                                f32x16 (&acc)[4]) {
     const int r = lane & 31, h = lane >> 5;
     const _Float16 *ah = Ah + r * a_stride + 8 * h;
     const _Float16 *al = Al + r * a_stride + 8 * h;
     const int rt_off = 32 * a_stride;
-    constexpr int D = 3;                       // weight fragments run D-1 k-steps ahead (4 spills registers)
-    half8 bh[D][2], bl[D][2];
-#pragma unroll
-    for (int d = 0; d < D; ++d)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) bh[d][c] = bl[d][c] = (half8)(_Float16)0;
-#pragma unroll
-    for (int d = 0; d < D - 1; ++d)
-        if (d < ksteps)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-                if (c < nct) {
-                    const size_t t = (size_t)d * NT + 2 * wave + c;
-                    bh[d][c] = wp[(t * 2) * 64 + lane];
-                    bl[d][c] = wp[(t * 2 + 1) * 64 + lane];
-                }
-    half8 a_hi[2], a_lo[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        a_hi[rt] = *reinterpret_cast<const half8 *>(ah + rt * rt_off);
-        a_lo[rt] = *reinterpret_cast<const half8 *>(al + rt * rt_off);
+    Stage16w s0, s1, s2;
+    load_b16w<TWO_COLS>(s0, wp, NT, wave, lane, 0);
+    if (ksteps > 1) load_b16w<TWO_COLS>(s1, wp, NT, wave, lane, 1);
+    load_a16w(s0, ah, al, rt_off, 0);
+    for (int s = 0; s < ksteps; s += 3) {
+        // k-step s on stage 0
+        if (s + 2 < ksteps) load_b16w<TWO_COLS>(s2, wp, NT, wave, lane, s + 2);
+        if (s + 1 < ksteps) load_a16w(s1, ah, al, rt_off, s + 1);
+        mfma16w<TWO_COLS>(s0, acc);
+        if (s + 1 >= ksteps) break;
+        // k-step s+1 on stage 1
+        if (s + 3 < ksteps) load_b16w<TWO_COLS>(s0, wp, NT, wave, lane, s + 3);
+        if (s + 2 < ksteps) load_a16w(s2, ah, al, rt_off, s + 2);
+        mfma16w<TWO_COLS>(s1, acc);
+        if (s + 2 >= ksteps) break;
+        // k-step s+2 on stage 2
+        if (s + 4 < ksteps) load_b16w<TWO_COLS>(s1, wp, NT, wave, lane, s + 4);
+        if (s + 3 < ksteps) load_a16w(s0, ah, al, rt_off, s + 3);
+        mfma16w<TWO_COLS>(s2, acc);
     }
-    for (int s = 0; s < ksteps; ++s) {
-        if (s + D - 1 < ksteps) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-                if (c < nct) {
-                    const size_t t = (size_t)(s + D - 1) * NT + 2 * wave + c;
-                    bh[D - 1][c] = wp[(t * 2) * 64 + lane];
-                    bl[D - 1][c] = wp[(t * 2 + 1) * 64 + lane];
-                }
-        }
-        half8 n_hi[2], n_lo[2];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            n_hi[rt] = a_hi[rt];
-            n_lo[rt] = a_lo[rt];
-            if (s + 1 < ksteps) {
-                n_hi[rt] = *reinterpret_cast<const half8 *>(ah + rt * rt_off + 16 * (s + 1));
-                n_lo[rt] = *reinterpret_cast<const half8 *>(al + rt * rt_off + 16 * (s + 1));
-            }
-        }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-                if (c < nct) {
-                    f32x16 &a = acc[rt * 2 + c];
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], bh[0][c], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[rt], bl[0][c], a, 0, 0, 0);
-                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[rt], bh[0][c], a, 0, 0, 0);
-                }
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            a_hi[rt] = n_hi[rt];
-            a_lo[rt] = n_lo[rt];
-        }
-#pragma unroll
-        for (int d = 0; d < D - 1; ++d)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                bh[d][c] = bh[d + 1][c];
-                bl[d][c] = bl[d + 1][c];
-            }
-    }
+}
+
+__device__ __forceinline__ void gemm_block16w(const _Float16 *Ah, const _Float16 *Al, int a_stride, int ksteps,
+                                              const half8 *__restrict__ wp, int NT, int wave, int lane, int nct,
+                                              f32x16 (&acc)[4]) {
+    if (ksteps <= 0 || nct <= 0) return;
+    if (nct == 2)
+        gemm_block16w_t<true>(Ah, Al, a_stride, ksteps, wp, NT, wave, lane, acc);
+    else
+        gemm_block16w_t<false>(Ah, Al, a_stride, ksteps, wp, NT, wave, lane, acc);
 }
 
 __device__ __forceinline__ void layer_gemm16w(const nefii_layer &L, const Lds16w &lds, int n_tiles, f32x16 (&acc)[4],
                                               int &nct) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // readfirstlane: tell the compiler the wave index is wave-uniform (scalar branches, no exec masking of MFMAs)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     nct = n_tiles - 2 * wave;
     nct = nct < 0 ? 0 : (nct > 2 ? 2 : nct);
     zero_acc(acc);
@@ -426,7 +432,7 @@ __device__ __forceinline__ void layer_gemm16w(const nefii_layer &L, const Lds16w
 
 #define NEFII_FOR_ACC_W(acc, nct, BODY)                                                   \
     {                                                                                     \
-        const int _wave = threadIdx.x >> 6, _lane = threadIdx.x & 63;                     \
+        const int _wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), _lane = threadIdx.x & 63; \
         _Pragma("unroll") for (int _rt = 0; _rt < 2; ++_rt)                               \
         _Pragma("unroll") for (int _c = 0; _c < 2; ++_c) if (_c < (nct)) {                \
             const int col = 32 * (2 * _wave + _c) + (_lane & 31);                         \
@@ -435,6 +441,7 @@ __device__ __forceinline__ void layer_gemm16w(const nefii_layer &L, const Lds16w
                 const float val = (acc)[_rt * 2 + _c][_i];                                \
                 BODY                                                                      \
             }                                                                             \
+            __builtin_amdgcn_sched_barrier(0); /* keep one tile's temporaries live at a time */ \
         }                                                                                 \
     }
 

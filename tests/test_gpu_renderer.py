@@ -255,3 +255,40 @@ def test_render_frame_chunks_match_direct_forward():
     assert torch.equal(merged['network_object_mask'], direct['network_object_mask'])
     for k in ('points', 'normal_values', 'sg_diffuse_albedo_values', 'sg_roughness_values', 'idr_rgb_values'):
         assert rel_l2(merged[k], direct[k]) < 1e-5, k
+
+
+def test_batch_of_two_cameras_and_no_hits():
+    """B = 2 poses in one call (rays of both images share the kernels) and a camera that looks away from the
+    object (no sphere hit at all: every output keeps its default, the shading kernels see n = 0)."""
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+    a, _ = syn.make_inputs(64, (64, 64), 100.0, (0.2, 0.1, 2.0), -1, seed=2)
+    b, _ = syn.make_inputs(64, (64, 64), 100.0, (-1.5, 0.8, 1.6), -1, seed=3)
+    both = {k: torch.cat([a[k], b[k]], 0) for k in a}
+    steps = torch.rand(100, generator=torch.Generator().manual_seed(0))
+    m = build_model(mc, sd, True)
+    m.ray_tracer.minsdf_steps_override = steps
+    with torch.no_grad():
+        out = m(to_dev(both))
+    ref = orr.Renderer({k: v.clone() for k, v in sd.items()}, mc, training=True).forward(both, steps)
+    compare_outputs(out, ref, max_flips=1, what='B=2')
+    # camera far outside, looking away: no ray reaches the unit sphere
+    away = dict(a)
+    pose = a['pose'].clone()
+    pose[0, :3, 3] = torch.tensor([0., 0., 5.0])
+    pose[0, :3, 2] = torch.tensor([0., 0., 1.0])
+    away['pose'] = pose
+    with torch.no_grad():
+        out = m(to_dev(away))
+    ref = orr.Renderer({k: v.clone() for k, v in sd.items()}, mc, training=True).forward(away, steps)
+    assert not out['network_object_mask'].any() and not ref['network_object_mask'].any()
+    assert torch.equal(out['sg_rgb_values'].cpu(), torch.ones(64, 3))
+    assert (out['points'].cpu() - ref['points']).abs().max().item() < 1e-5
+    m.eval()
+    with torch.no_grad():
+        out = m(to_dev(away))
+    # (rays whose LINE meets the sphere behind the camera still count as sphere hits with both depths clamped to
+    # 0.01 - rend_util.py:218 - and march one step; the others return the camera centre)
+    ref = orr.Renderer({k: v.clone() for k, v in sd.items()}, mc, training=False).forward(away, None)
+    assert (out['points'].cpu() - ref['points']).abs().max().item() < 1e-5
+    assert not out['network_object_mask'].any()
