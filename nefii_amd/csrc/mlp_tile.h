@@ -340,13 +340,24 @@ __device__ __forceinline__ void encode_tile16w(const nefii_mlp &m, const float *
 // Three statically named register stages for the weight fragments (two k-steps in flight) and for the A fragments
 // (one k-step ahead); the k-loop is unrolled by three so that no stage is ever copied (a rotating buffer costs
 // 48 v_mov per k-step, a third of the MFMA issue time).
-struct Stage16w {
+// Register pipeline of the wide kernel: NB statically named stages of weight fragments (NB-1 k-steps in flight:
+// the kernel is bound by how many bytes per CU it keeps in flight towards L2 - Little's law; measured on config 2:
+// NB 2 / 4 / 6 -> 9.25 / 8.94 / 8.39 ms of eval time per step) and two stages of activation fragments (one k-step
+// ahead, LDS latency).  The k-loop is unrolled NB times so that every stage index is a compile-time constant - a
+// rotating buffer would cost ~48 v_mov per k-step.
+#ifndef NEFII_WD
+#define NEFII_WD 6
+#endif
+struct BStage16w {
     half8 bh[2], bl[2];      // weight fragments of the wave's two column tiles
+};
+struct AStage16w {
     half8 ah[2], al[2];      // activation fragments of the two row tiles
 };
 
 template <bool TWO_COLS>
-__device__ __forceinline__ void load_b16w(Stage16w &st, const half8 *__restrict__ wp, int NT, int wave, int lane, int s) {
+__device__ __forceinline__ void load_b16w(BStage16w &st, const half8 *__restrict__ wp, int NT, int wave, int lane,
+                                          int s) {
     const size_t t = (size_t)s * NT + 2 * wave;
     st.bh[0] = wp[(t * 2) * 64 + lane];
     st.bl[0] = wp[(t * 2 + 1) * 64 + lane];
@@ -356,7 +367,7 @@ __device__ __forceinline__ void load_b16w(Stage16w &st, const half8 *__restrict_
     }
 }
 
-__device__ __forceinline__ void load_a16w(Stage16w &st, const _Float16 *ah, const _Float16 *al, int rt_off, int s) {
+__device__ __forceinline__ void load_a16w(AStage16w &st, const _Float16 *ah, const _Float16 *al, int rt_off, int s) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         st.ah[rt] = *reinterpret_cast<const half8 *>(ah + rt * rt_off + 16 * s);
@@ -365,15 +376,15 @@ __device__ __forceinline__ void load_a16w(Stage16w &st, const _Float16 *ah, cons
 }
 
 template <bool TWO_COLS>
-__device__ __forceinline__ void mfma16w(const Stage16w &st, f32x16 (&acc)[4]) {
+__device__ __forceinline__ void mfma16w(const AStage16w &sa, const BStage16w &sb, f32x16 (&acc)[4]) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int c = 0; c < (TWO_COLS ? 2 : 1); ++c) {
             f32x16 &a = acc[rt * 2 + c];
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.ah[rt], st.bh[c], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.ah[rt], st.bl[c], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.al[rt], st.bh[c], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa.ah[rt], sb.bh[c], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa.ah[rt], sb.bl[c], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa.al[rt], sb.bh[c], a, 0, 0, 0);
         }
 }
 
@@ -381,29 +392,28 @@ template <bool TWO_COLS>
 __device__ __forceinline__ void gemm_block16w_t(const _Float16 *Ah, const _Float16 *Al, int a_stride, int ksteps,
                                                 const half8 *__restrict__ wp, int NT, int wave, int lane,
                                                 f32x16 (&acc)[4]) {
+    constexpr int NB = NEFII_WD;
+    static_assert(NB >= 2 && NB % 2 == 0, "NB must be even (activation stages alternate)");
     const int r = lane & 31, h = lane >> 5;
     const _Float16 *ah = Ah + r * a_stride + 8 * h;
     const _Float16 *al = Al + r * a_stride + 8 * h;
     const int rt_off = 32 * a_stride;
-    Stage16w s0, s1, s2;
-    load_b16w<TWO_COLS>(s0, wp, NT, wave, lane, 0);
-    if (ksteps > 1) load_b16w<TWO_COLS>(s1, wp, NT, wave, lane, 1);
-    load_a16w(s0, ah, al, rt_off, 0);
-    for (int s = 0; s < ksteps; s += 3) {
-        // k-step s on stage 0
-        if (s + 2 < ksteps) load_b16w<TWO_COLS>(s2, wp, NT, wave, lane, s + 2);
-        if (s + 1 < ksteps) load_a16w(s1, ah, al, rt_off, s + 1);
-        mfma16w<TWO_COLS>(s0, acc);
-        if (s + 1 >= ksteps) break;
-        // k-step s+1 on stage 1
-        if (s + 3 < ksteps) load_b16w<TWO_COLS>(s0, wp, NT, wave, lane, s + 3);
-        if (s + 2 < ksteps) load_a16w(s2, ah, al, rt_off, s + 2);
-        mfma16w<TWO_COLS>(s1, acc);
-        if (s + 2 >= ksteps) break;
-        // k-step s+2 on stage 2
-        if (s + 4 < ksteps) load_b16w<TWO_COLS>(s1, wp, NT, wave, lane, s + 4);
-        if (s + 3 < ksteps) load_a16w(s0, ah, al, rt_off, s + 3);
-        mfma16w<TWO_COLS>(s2, acc);
+    BStage16w b[NB];
+    AStage16w a[2];
+#pragma unroll
+    for (int u = 0; u < NB - 1; ++u)
+        if (u < ksteps) load_b16w<TWO_COLS>(b[u], wp, NT, wave, lane, u);
+    load_a16w(a[0], ah, al, rt_off, 0);
+    for (int s0 = 0; s0 < ksteps; s0 += NB) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int s = s0 + u;
+            if (s < ksteps) {
+                if (s + NB - 1 < ksteps) load_b16w<TWO_COLS>(b[(u + NB - 1) % NB], wp, NT, wave, lane, s + NB - 1);
+                if (s + 1 < ksteps) load_a16w(a[(u + 1) % 2], ah, al, rt_off, s + 1);
+                mfma16w<TWO_COLS>(a[u % 2], b[u], acc);
+            }
+        }
     }
 }
 
