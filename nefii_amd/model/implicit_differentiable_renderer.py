@@ -277,8 +277,15 @@ class IDRNetwork(nn.Module):
         with torch.no_grad():
             points, network_object_mask, dists = self.ray_tracer(sdf=self.implicit_network, cam_loc=cam_loc,
                                                                  object_mask=object_mask, ray_directions=ray_dirs)
-            # the tracer already returns cam + dist * dir (reference recomputes it, :352)
-            sdf_output = self.implicit_network(points)[:, 0:1]
+            # the tracer already returns cam + dist * dir (reference recomputes it, :352).
+            # Small batches (<= one 32-point tile per CU) are latency-bound: one value+feature+gradient pass over ALL
+            # rays costs the same as the pass over the hits alone and replaces the separate SDF forward.
+            pre = None
+            if points.shape[0] <= 32 * 256:
+                pre = self.implicit_network.value_feature_gradient(points)
+                sdf_output = pre[0]
+            else:
+                sdf_output = self.implicit_network(points)[:, 0:1]
         ray_dirs = ray_dirs.reshape(-1, 3)
         surface_mask = network_object_mask
         n_all = points.shape[0]
@@ -293,7 +300,9 @@ class IDRNetwork(nn.Module):
         ret = {}
         idx = torch.nonzero(surface_mask).flatten()          # one host sync per call (compaction size)
         if idx.numel() > 0:
-            ret = self.get_rbg_value(points.index_select(0, idx), -ray_dirs.index_select(0, idx))
+            if pre is not None:
+                pre = (None, pre[1].index_select(0, idx) if pre[1] is not None else None, pre[2].index_select(0, idx))
+            ret = self.get_rbg_value(points.index_select(0, idx), -ray_dirs.index_select(0, idx), surface=pre)
 
             def put(key, src):
                 src = src.expand(idx.shape[0], out[key].shape[1]).to(out[key].dtype)
@@ -350,10 +359,12 @@ class IDRNetwork(nn.Module):
                 'sg_rgb_values': self.mean_pixel(ret['sg_rgb'], N, R)}
 
     # ---- get_rbg_value (:529-599) ------------------------------------------------------------------
-    def get_rbg_value(self, points, view_dirs, multi_ray_data_shape=None):
+    def get_rbg_value(self, points, view_dirs, multi_ray_data_shape=None, surface=None):
         with torch.no_grad():
             # one fused pass replaces the reference's three SDF evaluations of the same points (:354, :533, :537)
-            _, feature_vectors, g = self.implicit_network.value_feature_gradient(points)
+            if surface is None:
+                surface = self.implicit_network.value_feature_gradient(points)
+            _, feature_vectors, g = surface
             normals = g / (torch.norm(g, dim=-1, keepdim=True) + 1e-6)
             view_dirs = view_dirs / (torch.norm(view_dirs, dim=-1, keepdim=True) + 1e-6)
         ret = {'normals': normals}

@@ -86,8 +86,12 @@ class IDRLoss(nn.Module):
         rgb_gt = ground_truth['rgb']
         net = model_outputs['network_object_mask']
         obj = model_outputs['object_mask']
-        idr_rgb_loss, sg_rgb_loss = self.get_rgb_loss(model_outputs['idr_rgb_values'], model_outputs['sg_rgb_values'],
-                                                      rgb_gt, net, obj)
+        idr_rgb = model_outputs['idr_rgb_values']
+        if self.idr_rgb_weight == 0:
+            # a zero-weighted term contributes exact zeros to every gradient; detaching it skips the radiance
+            # network's backward pass instead of running it on zeros (physg.conf: idr_rgb_weight = 0.0)
+            idr_rgb = idr_rgb.detach()
+        idr_rgb_loss, sg_rgb_loss = self.get_rgb_loss(idr_rgb, model_outputs['sg_rgb_values'], rgb_gt, net, obj)
         mask_loss = self.get_mask_loss(model_outputs['sdf_output'], net, obj)
         eikonal_loss = self.get_eikonal_loss(model_outputs['grad_theta'], rgb_gt)
         normalsmooth_loss = self.get_normalsmooth_loss(model_outputs['normal_values'], net, obj)
