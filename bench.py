@@ -165,7 +165,8 @@ def main():
         # algorithmic evaluations (what the reference's recurrences need) vs executed (incl. the unused nodes of
         # the speculative 3-level bisection tree); the roofline credits only the algorithmic ones
         queries = int((cnt[:, 0] + cnt[:, 1] * n_steps + cnt[:, 3]).sum().item())
-        executed = int((cnt[:, 0] + cnt[:, 1] * n_steps + cnt[:, 2] * 7).sum().item())
+        nodes = 2 ** (model.ray_tracer.bisect_levels or (5 if rays_per_rank <= 16384 else 3)) - 1
+        executed = int((cnt[:, 0] + cnt[:, 1] * n_steps + cnt[:, 2] * nodes).sum().item())
         launches = int(((cnt[:, 0] + cnt[:, 1] + cnt[:, 2]) > 0).sum().item())
         f_eval = sdf_flops_per_eval(model.implicit_network.specs)
         achieved = queries * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0

@@ -121,6 +121,9 @@ typedef struct nefii_tracer_params {
     float object_bounding_sphere, sdf_threshold, line_search_step;
     int32_t line_step_iters, sphere_tracing_iters, n_steps, n_rootfind_steps;
     int32_t training;
+    int32_t bisect_levels;   /* bisection steps resolved per round by evaluating the next levels of the bisection tree
+                                speculatively (2^levels - 1 queries per ray per round, bit-identical result):
+                                1..5, 0 = default 3.  5 suits small latency-bound batches, 3 large ones. */
     int32_t precision;       /* SDF evaluation inside the tracer: 0 = f32-input MFMA (exact fp32),
                                 1 = 3x fp16 split MFMA, 32-query tiles; 2 = the same arithmetic on 64-query tiles
                                 (8 waves, weight fragments shared by two row tiles); 1 and 2 need w_f16x3 */
@@ -130,15 +133,26 @@ size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *h_
 int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
 /* lin_steps: the n_steps values of torch.linspace(0,1,n_steps); minsdf_steps: the n_steps uniforms of
  * minimal_sdf_points (only read when training).  counters (optional, int32 [max_rounds][4]) receives per round:
- * [r][0] single queries, [r][1] rays with n_steps dense queries, [r][2] rays in bisection (7 speculative queries each:
- * three levels of the bisection tree per round), [r][3] bisection evaluations actually consumed.
- * Executed SDF evaluations = [0] + n_steps*[1] + 7*[2]; algorithmic (what the reference's recurrence needs)
+ * [r][0] single queries, [r][1] rays with n_steps dense queries, [r][2] rays in bisection (2^levels - 1 speculative
+ * queries each), [r][3] bisection evaluations actually consumed.
+ * Executed SDF evaluations = [0] + n_steps*[1] + (2^levels - 1)*[2]; algorithmic (what the reference's recurrence needs)
  * = [0] + n_steps*[1] + [3]. */
 int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
                      const float *origins, const float *dirs, const uint8_t *object_mask, int64_t n_rays,
                      const float *lin_steps, const float *minsdf_steps,
                      float *out_points, uint8_t *out_hit, float *out_dists,
                      void *workspace, size_t workspace_bytes, int32_t *counters, void *stream);
+
+/* The same, restricted to rounds [round_begin, round_end) (round_end <= 0: up to nefii_trace_max_rounds).  Rounds
+ * after the last one that emitted a query are empty launches; a caller that synchronises anyway can run a prefix,
+ * read counters[round_end-1][0..2] and continue with round_begin = round_end only if any of them is non-zero
+ * (ray state and counters persist in `workspace` between the calls; outputs are complete once none is pending). */
+int nefii_trace_rays_rounds(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
+                            const float *origins, const float *dirs, const uint8_t *object_mask, int64_t n_rays,
+                            const float *lin_steps, const float *minsdf_steps,
+                            float *out_points, uint8_t *out_hit, float *out_dists,
+                            void *workspace, size_t workspace_bytes, int32_t *counters,
+                            int round_begin, int round_end, void *stream);
 
 /* Measurement hooks (bench.py): when enabled, nefii_trace_rays brackets every SDF-evaluation launch with HIP
  * events on the launch stream; nefii_trace_profile_read returns the summed launch durations (ms), the number

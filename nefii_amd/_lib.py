@@ -38,7 +38,8 @@ class TracerParams(ctypes.Structure):
     _fields_ = [('object_bounding_sphere', ctypes.c_float), ('sdf_threshold', ctypes.c_float),
                 ('line_search_step', ctypes.c_float), ('line_step_iters', ctypes.c_int32),
                 ('sphere_tracing_iters', ctypes.c_int32), ('n_steps', ctypes.c_int32),
-                ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32), ('precision', ctypes.c_int32)]
+                ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32), ('bisect_levels', ctypes.c_int32),
+                ('precision', ctypes.c_int32)]
 
 
 P = ctypes.c_void_p
@@ -60,6 +61,8 @@ SIGNATURES = {
     'nefii_trace_max_rounds': (I, [ctypes.POINTER(TracerParams)]),
     'nefii_trace_rays': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(TracerParams), P, P, P, I64, P, P, P, P, P, P,
                              ctypes.c_size_t, P, P]),
+    'nefii_trace_rays_rounds': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(TracerParams), P, P, P, I64, P, P, P, P, P, P,
+                                    ctypes.c_size_t, P, I, I, P]),
     'nefii_trace_profile_enable': (I, [I]),
     'nefii_trace_profile_read': (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I), ctypes.POINTER(ctypes.c_double)]),
     'nefii_trace_profile_launches': (I, [ctypes.POINTER(ctypes.c_float), I]),

@@ -58,6 +58,7 @@ struct Params {
     float *out_pts, *out_dist;
     uint8_t *out_hit;
     int *counters;           // [rounds][4]
+    int levels, tri_nodes;   // speculative bisection: levels per round, nodes = 2^levels - 1
     RayState s;
 };
 
@@ -100,20 +101,19 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
     __syncthreads();
 }
 
-// depth of node j (0..6) of the 3-level bisection tree over [lo, hi]; identical arithmetic to the sequential
-// recurrence mid = (lo + hi) / 2 (ray_tracing.py:262,275), so speculated points ARE the points bisection would visit
+// depth of heap node j (root 0, children 2j+1 / 2j+2) of the speculative bisection tree over [lo, hi]: replay the
+// recurrence mid = (lo + hi) / 2 (ray_tracing.py:262,275) along the node's path - the speculated points ARE the
+// points sequential bisection would visit.  Path bits, MSB first after the leading 1 of (j+1): 1 = "f(mid) > 0"
+// (lo = mid), 0 = hi = mid.
 __device__ __forceinline__ float tri_depth(float lo, float hi, int j) {
-    const float m1 = fmul(fadd(lo, hi), 0.5f);
-    if (j == 0) return m1;
-    const float m2a = fmul(fadd(lo, m1), 0.5f), m2b = fmul(fadd(m1, hi), 0.5f);
-    switch (j) {
-        case 1: return m2a;
-        case 2: return m2b;
-        case 3: return fmul(fadd(lo, m2a), 0.5f);
-        case 4: return fmul(fadd(m2a, m1), 0.5f);
-        case 5: return fmul(fadd(m1, m2b), 0.5f);
-        default: return fmul(fadd(m2b, hi), 0.5f);
+    const unsigned k = (unsigned)j + 1u;
+    const int level = 31 - __clz(k);
+    float mid = fmul(fadd(lo, hi), 0.5f);
+    for (int b = level - 1; b >= 0; --b) {
+        if ((k >> b) & 1u) lo = mid; else hi = mid;
+        mid = fmul(fadd(lo, hi), 0.5f);
     }
+    return mid;
 }
 
 __device__ __forceinline__ void finish(const Params &P, int64_t r, float dist, bool hit) {
@@ -314,15 +314,14 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
     }
 
     if (valid && ph == PH_BISECT) {
-        // up to three bisection steps per round (ray_tracing.py:264-277, per ray): the 7 nodes of the next three
-        // levels were evaluated speculatively last round; walk them with the sequential rule
+        // up to `bisect_levels` bisection steps per round (ray_tracing.py:264-277, per ray): the nodes of the next
+        // levels of the bisection tree were evaluated speculatively last round; walk them with the sequential rule
         float lo = P.s.lo[r], hi = P.s.hi[r], mid = P.s.mid[r];
         const float *f = P.s.big + (size_t)r * tp.n_steps;
         int it = (fl >> F_IT_SHIFT) & F_IT_MASK;
         int node = 0;
         bool more = true;
-#pragma unroll
-        for (int level = 0; level < 3 && more; ++level) {
+        for (int level = 0; level < P.levels && more; ++level) {
             const float f_mid = f[node];
             ++consumed;
             const int bit = f_mid > 0.f ? 1 : 0;
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             mid = fmul(fadd(lo, hi), 0.5f);
             ++it;
             more = (fsub(hi, lo) > 1e-6f) && (it < tp.n_rootfind_steps);
-            node = level == 0 ? 1 + bit : 3 + 2 * (node - 1) + bit;
+            node = 2 * node + 1 + bit;
         }
         P.s.mid[r] = mid;
         if (more) {
@@ -416,8 +415,8 @@ __device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, int64
             dst = kind == Q_END ? &P.s.res_e[r] : &P.s.res_s[r];
         } else if (q >= n_sd) {
             const int64_t qq = q - n_sd;
-            const int64_t ti = qq / 7;
-            const int j = (int)(qq - ti * 7);
+            const int64_t ti = qq / P.tri_nodes;
+            const int j = (int)(qq - ti * P.tri_nodes);
             r = P.s.tri[ti];
             t = tri_depth(P.s.lo[r], P.s.hi[r], j);
             dst = &P.s.big[(size_t)r * ns + j];
@@ -454,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int
     const int n_dense = P.counters[round * 4 + 1];
     const int n_tri = P.counters[round * 4 + 2];
     const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
-    const int64_t total = n_sd + (int64_t)n_tri * 7;
+    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
     const int64_t n_tiles = (total + TILE - 1) / TILE;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
@@ -491,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel16(Params P, nefii_mlp m, i
     const int n_dense = P.counters[round * 4 + 1];
     const int n_tri = P.counters[round * 4 + 2];
     const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
-    const int64_t total = n_sd + (int64_t)n_tri * 7;
+    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
     const int64_t n_tiles = (total + TILE - 1) / TILE;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
@@ -532,7 +531,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, 
     const int n_dense = P.counters[round * 4 + 1];
     const int n_tri = P.counters[round * 4 + 2];
     const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
-    const int64_t total = n_sd + (int64_t)n_tri * 7;
+    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
     const int64_t n_tiles = (total + TILE_W - 1) / TILE_W;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
@@ -654,8 +653,9 @@ extern "C" int nefii_trace_profile_launches(float *h_ms, int cap) {
 
 extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     if (!p) return 0;
-    // initial eval + iters*(step + back-offs) -> sampler -> bisection (3 levels per round) -> min-SDF -> bookkeeping
-    return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + (p->n_rootfind_steps + 2) / 3 + 1 + 2;
+    // initial eval + iters*(step + back-offs) -> sampler -> bisection (L levels per round) -> min-SDF -> bookkeeping
+    const int L = p->bisect_levels >= 1 && p->bisect_levels <= 5 ? p->bisect_levels : 3;
+    return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + (p->n_rootfind_steps + L - 1) / L + 1 + 2;
 }
 
 extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *p) {
@@ -666,17 +666,21 @@ extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer
     return bytes;
 }
 
-extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params, const float *origins,
-                                const float *dirs, const uint8_t *object_mask, int64_t n_rays, const float *lin_steps,
-                                const float *minsdf_steps, float *out_points, uint8_t *out_hit, float *out_dists,
-                                void *workspace, size_t workspace_bytes, int32_t *counters, void *stream) {
+extern "C" int nefii_trace_rays_rounds(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
+                                       const float *origins, const float *dirs, const uint8_t *object_mask,
+                                       int64_t n_rays, const float *lin_steps, const float *minsdf_steps,
+                                       float *out_points, uint8_t *out_hit, float *out_dists, void *workspace,
+                                       size_t workspace_bytes, int32_t *counters, int round_begin, int round_end,
+                                       void *stream) {
     if (!h_sdf || !h_params || !origins || !dirs || !object_mask || !lin_steps || !out_points || !out_hit ||
         !out_dists || !workspace)
         return NEFII_E_ARG;
     if (n_rays <= 0) return 0;
     if (n_rays >= (1ll << 29)) return NEFII_E_SHAPE;
     if (h_params->training && !minsdf_steps) return NEFII_E_ARG;
-    if (h_params->n_steps < 8 || h_params->sphere_tracing_iters > 250 || h_params->line_step_iters > 15 ||
+    const int levels = h_params->bisect_levels >= 1 && h_params->bisect_levels <= 5 ? h_params->bisect_levels : 3;
+    if (h_params->bisect_levels < 0 || h_params->bisect_levels > 5) return NEFII_E_ARG;
+    if (h_params->n_steps < (1 << levels) || h_params->sphere_tracing_iters > 250 || h_params->line_step_iters > 15 ||
         h_params->n_rootfind_steps > 250)
         return NEFII_E_SHAPE;
     if (h_sdf->enc_freqs[0] < 0 || h_sdf->enc_freqs[1] >= 0 || h_sdf->enc_freqs[2] >= 0 || h_sdf->feat_width != 0 ||
@@ -702,13 +706,20 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
     P.out_hit = out_hit;
     size_t off = carve(P.s, (char *)workspace, n_rays, h_params->n_steps);
     P.counters = (int *)((char *)workspace + off);
-    hipError_t e = hipMemsetAsync(P.counters, 0, sizeof(int) * 4 * rounds, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(P.s.flags, 0, sizeof(int) * n_rays, st);
-    if (e != hipSuccess) return (int)e;
+    P.levels = levels;
+    P.tri_nodes = (1 << levels) - 1;
+    if (round_end <= 0 || round_end > rounds) round_end = rounds;
+    if (round_begin < 0 || round_begin >= round_end) return NEFII_E_ARG;
+    hipError_t e = hipSuccess;
+    if (round_begin == 0) {      // a continuation (round_begin > 0) keeps the ray state and counters in the workspace
+        e = hipMemsetAsync(P.counters, 0, sizeof(int) * 4 * rounds, st);
+        if (e != hipSuccess) return (int)e;
+        e = hipMemsetAsync(P.s.flags, 0, sizeof(int) * n_rays, st);
+        if (e != hipSuccess) return (int)e;
+    }
     const int adv_blocks = (int)((n_rays + 255) / 256);
     // eval grid: enough workgroups for the largest possible round, capped at 2 per CU (grid-stride beyond)
-    int64_t max_q = n_rays * (int64_t)h_params->n_steps;      // n_steps >= 8 > 7 (bisection tree) > 2 (both ends)
+    int64_t max_q = n_rays * (int64_t)h_params->n_steps;      // n_steps >= 2^levels > bisection tree nodes > 2 ends
     int64_t max_tiles = (max_q + TILE - 1) / TILE;
     const int eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
     const int64_t max_tiles_w = (max_q + TILE_W - 1) / TILE_W;
@@ -720,7 +731,7 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
         }
         (void)hipEventRecord(g_prof.t0, st);
     }
-    for (int r = 0; r < rounds; ++r) {
+    for (int r = round_begin; r < round_end; ++r) {
         hipLaunchKernelGGL(advance_kernel, dim3(adv_blocks), dim3(256), 0, st, P, r);
         HIP_CHECK_LAUNCH();
         if (r + 1 < rounds) {
@@ -749,6 +760,14 @@ extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_param
         if (e != hipSuccess) return (int)e;
     }
     return 0;
+}
+
+extern "C" int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params, const float *origins,
+                                const float *dirs, const uint8_t *object_mask, int64_t n_rays, const float *lin_steps,
+                                const float *minsdf_steps, float *out_points, uint8_t *out_hit, float *out_dists,
+                                void *workspace, size_t workspace_bytes, int32_t *counters, void *stream) {
+    return nefii_trace_rays_rounds(h_sdf, h_params, origins, dirs, object_mask, n_rays, lin_steps, minsdf_steps,
+                                   out_points, out_hit, out_dists, workspace, workspace_bytes, counters, 0, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

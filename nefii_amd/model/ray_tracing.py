@@ -29,6 +29,9 @@ class RayTracing(nn.Module):
         self.collect_counters = False
         self.minsdf_steps_override = None     # parity tests replay the reference's captured uniforms
         self._calls = 0
+        self.bisect_levels = 0          # 0 = automatic: 5 for batches up to 16 k rays (latency-bound), else 3
+        self.adaptive_rounds = True     # skip the trailing empty rounds (ops.TraceRounds)
+        self._rounds_state = {}
 
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
@@ -68,9 +71,16 @@ class RayTracing(nn.Module):
                 # drawn on the host exactly like minimal_sdf_points (:316); always drawn (the reference draws only
                 # when some ray needs the search, a data-dependent host sync this build avoids)
                 steps = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
-        params = ops.make_tracer_params(self._cfg(), self.training, self.precision)
-        res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs, object_mask.reshape(-1), self._lin, steps,
-                             want_counters=self.collect_counters)
+        n_rays = dirs.shape[0]
+        levels = self.bisect_levels or (5 if n_rays <= 16384 else 3)
+        params = ops.make_tracer_params(self._cfg(), self.training, self.precision, levels)
+        state = None
+        if self.adaptive_rounds:      # one guess per (mode, batch size): primary and secondary traces differ
+            import math
+            state = self._rounds_state.setdefault((self.training, int(math.log2(n_rays + 1))), ops.TraceRounds())
+        res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs,
+                             object_mask.reshape(-1), self._lin, steps, want_counters=self.collect_counters,
+                             rounds_state=state)
         if self.collect_counters:
             self.last_counters = res[3]
             self.counter_sum = res[3].clone() if self.counter_sum is None else self.counter_sum + res[3]

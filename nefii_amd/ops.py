@@ -214,9 +214,10 @@ def sdf_value_grad(pm, x, want_feat=False):
 PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}
 
 
-def make_tracer_params(cfg, training, precision='f32'):
+def make_tracer_params(cfg, training, precision='f32', bisect_levels=3):
     p = TracerParams()
     p.precision = PRECISIONS[precision]
+    p.bisect_levels = bisect_levels
     p.object_bounding_sphere = cfg.get('object_bounding_sphere', 1.0)
     p.sdf_threshold = cfg.get('sdf_threshold', 5.0e-5)
     p.line_search_step = cfg.get('line_search_step', 0.5)
@@ -228,7 +229,18 @@ def make_tracer_params(cfg, training, precision='f32'):
     return p
 
 
-def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_steps=None, want_counters=False):
+class TraceRounds:
+    """Adaptive prefix of the tracer's rounds.  Every round after the last one that emitted a query is an empty
+    launch pair (~12 us); callers that synchronise right after the trace anyway (the renderer compacts the hits)
+    run rounds [0, guess), read three counters and continue only if a ray is still waiting - which the guess,
+    taken from the previous call, makes rare.  Results never depend on the guess."""
+
+    def __init__(self):
+        self.guess = None
+
+
+def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_steps=None, want_counters=False,
+               rounds_state=None):
     """RayTracing.forward for per-ray origins.  Returns points [n,3], hit (bool [n]), dists [n] (+ counters)."""
     lib = _lib.lib()
     n = origins.shape[0]
@@ -237,14 +249,30 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
     hit = torch.empty(n, device=dev, dtype=torch.uint8)
     dist = torch.empty(n, device=dev, dtype=torch.float32)
     rounds = lib.nefii_trace_max_rounds(ctypes.byref(params))
-    counters = torch.zeros(rounds, 4, device=dev, dtype=torch.int32) if want_counters else None
+    need_cnt = want_counters or rounds_state is not None
+    counters = torch.zeros(rounds, 4, device=dev, dtype=torch.int32) if need_cnt else None
     if n > 0:
         nbytes = lib.nefii_trace_workspace_bytes(n, ctypes.byref(params))
         ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         om = object_mask.to(torch.uint8).contiguous()
-        _lib.check(lib.nefii_trace_rays(ctypes.byref(pm_sdf.struct), ctypes.byref(params), _ptr(origins), _ptr(dirs),
-                                        _ptr(om), n, _ptr(lin_steps), _ptr(minsdf_steps), _ptr(pts), _ptr(hit),
-                                        _ptr(dist), _ptr(ws), nbytes, _ptr(counters), _stream()), 'nefii_trace_rays')
+
+        def run(r0, r1):
+            _lib.check(lib.nefii_trace_rays_rounds(ctypes.byref(pm_sdf.struct), ctypes.byref(params), _ptr(origins),
+                                                   _ptr(dirs), _ptr(om), n, _ptr(lin_steps), _ptr(minsdf_steps),
+                                                   _ptr(pts), _ptr(hit), _ptr(dist), _ptr(ws), nbytes, _ptr(counters),
+                                                   r0, r1, _stream()), 'nefii_trace_rays_rounds')
+        if rounds_state is None:
+            run(0, 0)
+        else:
+            g = rounds if rounds_state.guess is None else max(2, min(rounds, rounds_state.guess))
+            run(0, g)
+            host = counters.cpu()                            # the one host sync (the caller syncs next anyway)
+            if g < rounds and int(host[g - 1, :3].sum()) > 0:
+                run(g, 0)
+                host = counters.cpu()
+            busy = torch.nonzero(host[:, :3].sum(dim=1)).flatten()
+            last = int(busy[-1]) if busy.numel() else 0
+            rounds_state.guess = last + 3                    # last emitting round + its consumer + one spare
     if want_counters:
         return pts, hit.bool(), dist, counters
     return pts, hit.bool(), dist

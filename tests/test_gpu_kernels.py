@@ -387,3 +387,32 @@ def test_mc_shade_forward_backward_matches_oracle():
     for name, a, b in zip(names, res[DEV], res['cpu']):
         # d/d roughness runs through the same ill-conditioned GGX term as the pdf above
         assert rel_l2(a, b) < (5e-3 if name == 'g_rough' else 2e-4), (name, rel_l2(a, b))
+
+
+@pytest.mark.parametrize('levels', [1, 2, 5])
+def test_tracer_bisection_levels_and_round_ranges_are_bit_identical(levels):
+    """Speculative bisection depth and splitting the rounds into two host calls are scheduling choices only:
+    depths, hit mask and points must be bit-identical to the default single call with 3 levels."""
+    from nefii_amd import ops
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=2, bumpy=0.03)
+    g = torch.Generator().manual_seed(5)
+    n = 4000
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * 2.2
+    d = torch.randn(n, 3, generator=g) * 0.4 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    om = torch.ones(n, dtype=torch.bool)
+    steps = torch.rand(100, generator=g).to(DEV)
+    pm = build_sdf(mc, sd, f16x3=True)
+    lin = torch.linspace(0, 1, steps=100).to(DEV)
+    base = ops.trace_rays(pm, ops.make_tracer_params(mc['ray_tracer'], True, 'f16x3w', 3), o.to(DEV), d.to(DEV),
+                          om.to(DEV), lin, steps)
+    tp = ops.make_tracer_params(mc['ray_tracer'], True, 'f16x3w', levels)
+    got = ops.trace_rays(pm, tp, o.to(DEV), d.to(DEV), om.to(DEV), lin, steps)
+    state = ops.TraceRounds()
+    state.guess = 4                                 # far too small: forces the continuation call
+    split = ops.trace_rays(pm, tp, o.to(DEV), d.to(DEV), om.to(DEV), lin, steps, rounds_state=state)
+    for a, b, c in zip(base, got, split):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    assert state.guess > 4

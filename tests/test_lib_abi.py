@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     # nefii_layer: 4 x int32 + 4 pointers; nefii_mlp: 8 x int32 + 12 layers
     assert ctypes.sizeof(_lib.Layer) == 16 + 4 * 8
     assert ctypes.sizeof(_lib.Mlp) == 32 + 12 * ctypes.sizeof(_lib.Layer)
-    assert ctypes.sizeof(_lib.TracerParams) == 36
+    assert ctypes.sizeof(_lib.TracerParams) == 40
 
 
 def test_host_side_argument_checks_need_no_gpu():
@@ -41,8 +41,12 @@ def test_host_side_argument_checks_need_no_gpu():
     p = _lib.TracerParams()
     p.n_steps, p.sphere_tracing_iters, p.line_step_iters, p.n_rootfind_steps = 100, 10, 3, 32
     assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 11 + 1 + 2    # bisection: 3 levels per round
+    p.bisect_levels = 5
+    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2
     assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) > 4096 * 100 * 4
     assert lib.nefii_trace_rays(None, None, None, None, None, 0, None, None, None, None, None, None, 0, None, None) == -1
+    assert lib.nefii_trace_rays_rounds(None, None, None, None, None, 0, None, None, None, None, None, None, 0, None, 0, 0,
+                                       None) == -1
     assert lib.nefii_pack_linear(None, None, 1, 1, 0, 0, 0, 0, 1.0, None, None, None, None) == -1
 
 

@@ -24,6 +24,7 @@ inp, gt = syn.make_inputs(w['num_pixels'], w['image_hw'], w['focal'], w['cam_pos
 inp = {k: v.to(dev) for k, v in inp.items()}
 lib = _lib.lib()
 m.ray_tracer.collect_counters = True
+m.ray_tracer.adaptive_rounds = False
 from nefii_amd.utils import rend_util
 uv = inp['uv'] if inp['uv'].dim() == 3 else inp['uv'].reshape(1, -1, 2)
 dirs, cam = rend_util.get_camera_params(uv, inp['pose'], inp['intrinsics'])
@@ -37,10 +38,11 @@ for it in range(3):
     n = lib.nefii_trace_profile_launches(buf, 256)
     lib.nefii_trace_profile_enable(0)
 cnt = m.ray_tracer.last_counters.cpu().tolist()
+NODES = 2 ** (m.ray_tracer.bisect_levels or (5 if dirs.shape[1] <= 16384 else 3)) - 1
 tot = 0.0
 print('round  singles  dense  tri  consumed  queries   tiles   ms    us/tile')
 for r in range(n):
-    q = cnt[r][0] + cnt[r][1] * 100 + cnt[r][2] * 7
+    q = cnt[r][0] + cnt[r][1] * 100 + cnt[r][2] * NODES
     tiles = (q + 31) // 32
     tot += buf[r]
     if q:
