@@ -174,10 +174,21 @@ def main():
         prec = model.ray_tracer.precision
         split = prec.startswith('f16x3')
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        # HBM traffic of the same kernel from rocprofv3 PMC passes of this command (separate FETCH_SIZE / WRITE_SIZE runs,
+        # gfx950 correction applied by tools/pmc_traffic.py); only quoted for the workload/kernel it was measured on
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic_%s.json' % args.workload)
+        kname = {'f32': 'eval_kernel', 'f16x3': 'eval_kernel16', 'f16x3w': 'eval_kernel16w'}[model.ray_tracer.precision]
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get('kernel') == kname:
+                traffic = tj['hbm_bytes_per_launch']
         roofline = {'bound': 'mfma',
                     'kernel': {'f32': 'eval_kernel', 'f16x3': 'eval_kernel16', 'f16x3w': 'eval_kernel16w'}[prec] +
                               ' (fused SDF MLP over the tracer work list)',
-                    'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                    'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
+                    'traffic_unit': 'HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, averaged over all launches '
+                                    'of the kernel incl. empty rounds; profiles/r01/pmc_traffic_*.json)',
                     'arithmetic': ('3x v_mfma_f32_32x32x16_f16 per k-step on fp16 hi/lo operand pairs, fp32 accumulate: '
                                    'achieved counts ALGORITHMIC flops (the matrix cores issue 3x that)') if split
                                   else 'v_mfma_f32_32x32x2_f32 (exact fp32)',
