@@ -36,39 +36,81 @@ def sdf_flops_per_eval(specs):
     return sum(2 * s.k_in * s.n_out for s in specs)
 
 
-def cpu_baseline(workload, sample_pixels, steps, warmup):
-    """Oracle training step on the host cores, bounded sample of the workload (rank 0 only)."""
+def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
+    """Oracle training step on the host cores, bounded sample of the workload (rank 0 only).  Also returns the
+    parity of the HIP path against the oracle on that sample (identical rays and weights): relative L2 and PSNR
+    (evaluate.py:36-44: 20 log10(1/sqrt(MSE))) of rendered RGB and albedo over the hit pixels."""
     from nefii_amd import synthetic as syn
     from oracle import renderer as orr
-    # these small GEMMs stop scaling early: on the 2x64-core EPYC 9575F GPU host 16 threads was the measured
-    # optimum (1 thread 253, 8: 848, 16: 1029, 32: 853, 64: 396, 128: 151 rays/s; tools/cpu_threads_probe.py)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
     w = dict(syn.WORKLOADS[workload])
     mc = syn.model_conf(w['model'])
-    sd = syn.make_state_dict(mc, seed=0)
     lc = syn.loss_conf(w['model'])
     inp, gt = syn.make_inputs(sample_pixels, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
-    params = [v for k, v in sd.items() if not k.startswith('implicit')]
-    for v in params:
-        v.requires_grad_(True)
-    opt = torch.optim.Adam(params, lr=5e-4)
-    R = orr.Renderer(sd, mc, training=True)
     n_rays = inp['uv'].shape[1] * (w['num_rays'] if w['num_rays'] > 0 else 1)
-    best = None
-    for i in range(warmup + steps):
-        t0 = time.perf_counter()
-        out = R.forward(inp)
-        lo = orr.idr_loss(out, gt, lc)
-        opt.zero_grad()
-        lo['loss'].backward()
-        opt.step()
-        dt = time.perf_counter() - t0
-        if i >= warmup:
-            best = dt if best is None else min(best, dt)
-    return {'value': n_rays / best, 'unit': 'rays/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d of the workload\'s pixels, best of %d steps after %d warm-up, %d torch threads (measured '
-                      'optimum on the host; the reference itself pins 1 thread, idr_train.py:26)'
-                      % (sample_pixels, steps, warmup, torch.get_num_threads())}
+    ncpu = os.cpu_count() or 1
+
+    def run(threads, n_steps, n_warm):
+        torch.set_num_threads(threads)
+        sd = syn.make_state_dict(mc, seed=0)
+        params = [v for k, v in sd.items() if not k.startswith('implicit')]
+        for v in params:
+            v.requires_grad_(True)
+        opt = torch.optim.Adam(params, lr=5e-4)
+        R = orr.Renderer(sd, mc, training=True)
+        best, first = None, None
+        for i in range(n_warm + n_steps):
+            t0 = time.perf_counter()
+            out = R.forward(inp)
+            lo = orr.idr_loss(out, gt, lc)
+            opt.zero_grad()
+            lo['loss'].backward()
+            opt.step()
+            dt = time.perf_counter() - t0
+            if first is None:
+                first = {k: out[k].detach().clone() for k in ('sg_rgb_values', 'sg_diffuse_albedo_values',
+                                                              'network_object_mask')}
+                first['uniforms'], first['steps'] = out.get('_uniforms'), out.get('_minsdf_steps')
+                first['steps2'] = out.get('_minsdf_steps2')
+            if i >= n_warm:
+                best = dt if best is None else min(best, dt)
+        return n_rays / best, first
+
+    # these small GEMMs stop scaling early: on the 2x64-core EPYC 9575F GPU host 16 threads was the measured
+    # optimum (1 thread 253, 8: 848, 16: 1029, 32: 853, 64: 396, 128: 151 rays/s; tools/cpu_threads_probe.py)
+    threads = min(16, ncpu)
+    value, ref = run(threads, steps, warmup)
+    value1, _ = run(1, 1, 0)
+    res = {'value': value, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
+           'value_1_thread': value1,
+           'sample': '%d of the workload\'s pixels, best of %d steps after %d warm-up, %d torch threads (measured '
+                     'optimum on the host; value_1_thread = the reference\'s own setting, idr_train.py:26)'
+                     % (sample_pixels, steps, warmup, threads)}
+    parity = None
+    if device is not None:
+        from nefii_amd import conf
+        from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+        m = IDRNetwork(conf.from_dict(mc))
+        m.load_state_dict(syn.make_state_dict(mc, seed=0), strict=True)
+        m = m.to(device)
+        m.freeze_geometry()
+        m.train()
+        over = [x for x in (ref['steps'], ref['steps2']) if x is not None]
+        if over:
+            m.ray_tracer.minsdf_steps_override = over
+        if ref['uniforms'] is not None:
+            m.uniforms_override = ref['uniforms']
+        with torch.no_grad():
+            out = m({k: v.to(device) for k, v in inp.items()})
+        mask = ref['network_object_mask'] & out['network_object_mask'].cpu()
+        parity = {'pixels': int(mask.numel()), 'hit_pixels': int(mask.sum()),
+                  'hit_mask_mismatches': int((ref['network_object_mask'] != out['network_object_mask'].cpu()).sum())}
+        for k, name in (('sg_rgb_values', 'rgb'), ('sg_diffuse_albedo_values', 'albedo')):
+            a, b = out[k].cpu()[mask], ref[k][mask]
+            mse = ((a - b) ** 2).mean().item()
+            parity[name + '_rel_l2'] = ((a - b).norm() / (b.norm() + 1e-12)).item()
+            parity[name + '_psnr_db'] = float('inf') if mse == 0 else 20.0 * __import__('math').log10(1.0 / mse ** 0.5)
+        parity['tolerance_rel_l2'] = 1e-3
+    return res, parity
 
 
 def main():
@@ -213,7 +255,8 @@ def main():
             'roofline': roofline,
         }
         if not args.no_cpu_baseline:
-            result['cpu_baseline'] = cpu_baseline(args.workload, args.cpu_sample_pixels, steps=3, warmup=1)
+            result['cpu_baseline'], result['parity_vs_cpu_oracle'] = cpu_baseline(
+                args.workload, args.cpu_sample_pixels, steps=3, warmup=1, device=dev)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
