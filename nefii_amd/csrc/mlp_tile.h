@@ -212,6 +212,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr int XS16 = 520;               // halves per X row
 constexpr int ES16 = 104;               // halves per E row (16 B * 13)
 constexpr float W16_SCALE = 64.f;
+// activations are split as (16 x) so that the lo half of small values (softplus(~0)/100 ~ 7e-3) is a normal fp16
+// number instead of a subnormal with 6e-8 resolution; exact power-of-two scaling, undone with the weight scale
+constexpr float A16_SCALE = 16.f;
 
 struct Lds16 {
     _Float16 Xh[TILE * XS16], Xl[TILE * XS16];
@@ -222,6 +225,7 @@ __device__ __forceinline__ void split16(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
 }
+__device__ __forceinline__ void split16a(float v, _Float16 &hi, _Float16 &lo) { split16(v * A16_SCALE, hi, lo); }
 
 __device__ __forceinline__ void encode_tile16(const nefii_mlp &m, const float *raw, Lds16 &lds, int k_e) {
     const int tid = threadIdx.x;
@@ -236,7 +240,7 @@ __device__ __forceinline__ void encode_tile16(const nefii_mlp &m, const float *r
         } else if (c < w0 + w1 + w2) {
             val = enc_value(raw + p * 9 + 6, c - w0 - w1);
         }
-        split16(val, lds.Eh[p * ES16 + c], lds.El[p * ES16 + c]);
+        split16a(val, lds.Eh[p * ES16 + c], lds.El[p * ES16 + c]);
     }
 }
 
@@ -332,7 +336,7 @@ __device__ __forceinline__ void encode_tile16w(const nefii_mlp &m, const float *
         } else if (c < w0 + w1 + w2) {
             val = enc_value(raw + p * 9 + 6, c - w0 - w1);
         }
-        split16(val, lds.Eh[p * ES16 + c], lds.El[p * ES16 + c]);
+        split16a(val, lds.Eh[p * ES16 + c], lds.El[p * ES16 + c]);
     }
 }
 

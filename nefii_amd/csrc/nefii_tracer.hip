@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel16(Params P, nefii_mlp m, i
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
     const int Lm1 = m.n_layers - 1;
-    const float inv_scale = 1.f / W16_SCALE;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         decode_tile<TILE>(P, tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel16(Params P, nefii_mlp m, i
             if (l < Lm1) {
                 NEFII_FOR_ACC(acc, ntw, {
                     const float hval = act_fwd(val * inv_scale + L.bias[col], m.act);
-                    split16(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                    split16a(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
                 })
             } else {
                 NEFII_FOR_ACC(acc, ntw, {
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, 
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
     const int Lm1 = m.n_layers - 1;
-    const float inv_scale = 1.f / W16_SCALE;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         decode_tile<TILE_W>(P, tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, 
             if (l < Lm1) {
                 NEFII_FOR_ACC_W(acc, nct, {
                     const float hval = act_fwd(val * inv_scale + L.bias[col], m.act);
-                    split16(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                    split16a(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
                 })
             } else {
                 NEFII_FOR_ACC_W(acc, nct, {
