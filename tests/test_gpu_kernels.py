@@ -416,3 +416,32 @@ def test_tracer_bisection_levels_and_round_ranges_are_bit_identical(levels):
     for a, b, c in zip(base, got, split):
         assert torch.equal(a, b) and torch.equal(a, c)
     assert state.guess > 4
+
+
+def test_tracer_large_batch_properties_and_subset_vs_oracle():
+    """BASELINE-scale ray count (config 3 traces 262 144 primary rays per call): size-independent properties
+    on all rays, and - because the tracer is per-ray - a random subset must equal the oracle tracing just that
+    subset."""
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=2, bumpy=0.03)
+    sdf = lambda x: nets.sdf_forward(sd, mc['implicit_network'], x)[:, 0]
+    g = torch.Generator().manual_seed(9)
+    n = 300_000
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * (1.2 + 1.5 * torch.rand(n, 1, generator=g))
+    d = torch.randn(n, 3, generator=g) * 0.5 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    om = torch.rand(n, generator=g) < 0.9
+    steps = torch.rand(100, generator=g)
+    pts, hit, dist, cnt = run_gpu_trace(mc, sd, o, d, om, True, steps, 'f16x3w')
+    pts, hit, dist = pts.cpu(), hit.cpu(), dist.cpu()
+    assert torch.isfinite(pts).all() and torch.isfinite(dist).all()
+    assert (pts - (o + dist.unsqueeze(-1) * d)).abs().max().item() < 1e-6
+    assert 0.05 < hit.float().mean().item() < 0.95
+    assert (pts[hit].norm(dim=-1) <= 1.0 + 1e-4).all()                 # surface hits lie inside the bounding sphere
+    idx = torch.randperm(n, generator=g)[:2000]
+    vals = sdf(pts[idx][hit[idx] & om[idx]])
+    assert vals.abs().median().item() < 5e-5 and (vals.abs() < 2e-3).float().mean().item() > 0.99
+    ref = tracer.trace(sdf, o[idx], d[idx], om[idx], mc['ray_tracer'], True, steps)
+    compare_trace(sdf, o[idx], d[idx], (pts[idx], hit[idx], dist[idx], None), ref['hit'], ref['dists'], 'subset',
+                  argmin_set(ref['hit'], om[idx], True))
