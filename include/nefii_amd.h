@@ -97,10 +97,15 @@ int nefii_mlp_forward(const nefii_mlp *h_mlp, const float *in_a, const float *in
 
 /* Backward of nefii_mlp_forward wrt the hidden activations (the MLP inputs are not differentiated: geometry
  * is frozen in Step-2).  d_out [n, out_stride] is dL/d(head output).  Writes dz [n_layers][n][dz_stride]:
- * the gradient wrt every layer's pre-activation.  Parameter gradients follow as plain GEMMs
- * dW_l = dz_l^T * input_l, db_l = column sums of dz_l (input_0 from nefii_encode_inputs, input_l = stash[l-1]). */
+ * the gradient wrt every layer's pre-activation; parameter gradients follow with nefii_mlp_wgrad per layer. */
 int nefii_mlp_backward(const nefii_mlp *h_mlp, const float *d_out, int out_stride, const float *stash,
                        int stash_stride, int64_t n, float *dz, int dz_stride, void *stream);
+
+/* Parameter gradients of one layer from the buffers of nefii_mlp_forward (stash) / nefii_mlp_backward (dz):
+ * dW [n_out][k_in] = scale * dz[:, :n_out]^T x[:, :k_in] (PyTorch nn.Linear layout), db [n_out] = column sums of dz
+ * (db may be NULL).  x = nefii_encode_inputs output for layer 0, stash slot l-1 for layer l.  Overwrites dW / db. */
+int nefii_mlp_wgrad(const float *dz, int dz_stride, const float *x, int x_stride, int64_t n, int n_out, int k_in,
+                    float scale, float *dW, float *db, void *stream);
 
 /* The reference's layer-0 concatenation [PE(a) | PE(b) | PE(c) | feat] as a dense [n, width] matrix. */
 int nefii_encode_inputs(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,

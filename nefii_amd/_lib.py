@@ -54,6 +54,7 @@ SIGNATURES = {
     'nefii_pack_linear_f16x3': (I, [P, I, I, I, I, I, I, F, P, P]),
     'nefii_mlp_forward': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P]),
     'nefii_mlp_backward': (I, [ctypes.POINTER(Mlp), P, I, P, I, I64, P, I, P]),
+    'nefii_mlp_wgrad': (I, [P, I, P, I, I64, I, I, F, P, P, P]),
     'nefii_encode_inputs': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P]),
     'nefii_sdf_value_grad': (I, [ctypes.POINTER(Mlp), P, I64, P, I, P, I, P, P, P]),
     'nefii_sdf_value_grad_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp), I64]),

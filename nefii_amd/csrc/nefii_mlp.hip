@@ -322,6 +322,94 @@ extern "C" int nefii_mlp_backward(const nefii_mlp *h_mlp, const float *d_out, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// weight / bias gradients:  dW[n][k] = scale * sum_p dz[p][n] * x[p][k] ,  db[n] = sum_p dz[p][n]
+// One wave = a 32 x 128 strip of dW (4 accumulator tiles); the contraction runs over the points, two per
+// v_mfma_f32_32x32x2_f32 (A = dz^T fragment: lane (n, p&1), B = x fragment: lane (k, p&1), both 128-B coalesced rows).
+// Workgroup = 64 x 256 block; the point range is split over gridDim.z workgroups that combine with fp32 atomics
+// (few: <= 32 adders per element).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(const float *__restrict__ dz, int dz_stride,
+                                                        const float *__restrict__ x, int x_stride, int64_t P, int n_out,
+                                                        int k_in, float scale, float *__restrict__ dW,
+                                                        float *__restrict__ db, int atomic) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 64 + (wave & 1) * 32;
+    const int k0 = blockIdx.y * 256 + (wave >> 1) * 128;
+    const int64_t chunk = ((P + gridDim.z - 1) / gridDim.z + 1) & ~(int64_t)1;
+    const int64_t p_begin = (int64_t)blockIdx.z * chunk;
+    const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;
+    f32x16 acc[4];
+    zero_acc(acc);
+    const bool n_ok = (n0 + i) < n_out;
+    bool k_ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) k_ok[t] = (k0 + 32 * t + i) < k_in;
+    float bsum = 0.f;
+    if (n0 < n_out && k0 < k_in) {
+        constexpr int U = 8;                       // point pairs per batch: all loads of a batch are issued before its MFMAs
+        for (int64_t pb = p_begin; pb < p_end; pb += 2 * U) {
+            float a[U], b[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t p = pb + 2 * u + h;
+                const bool p_ok = p < p_end;
+                a[u] = (p_ok && n_ok) ? dz[p * dz_stride + n0 + i] : 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[u][t] = (p_ok && k_ok[t]) ? x[p * x_stride + k0 + 32 * t + i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                bsum += a[u];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + (r & 3) + 8 * (r >> 2) + 4 * h, k = k0 + 32 * t + i;
+                if (n < n_out && k < k_in) {
+                    const float v = acc[t][r] * scale;
+                    if (atomic) atomicAdd(&dW[(size_t)n * k_in + k], v);
+                    else dW[(size_t)n * k_in + k] = v;
+                }
+            }
+    }
+    if (db && blockIdx.y == 0 && (wave >> 1) == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0 && n_ok) {
+            if (atomic) atomicAdd(&db[n0 + i], bsum);
+            else db[n0 + i] = bsum;
+        }
+    }
+}
+
+extern "C" int nefii_mlp_wgrad(const float *dz, int dz_stride, const float *x, int x_stride, int64_t n, int n_out,
+                               int k_in, float scale, float *dW, float *db, void *stream) {
+    if (!dz || !x || !dW || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int split = (int)((n + 127) / 128);       // <= 128 points per workgroup: the kernel is load-latency bound
+    if (split < 1) split = 1;
+    if (split > 32) split = 32;
+    if (split > 1 || n <= 0) {
+        hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * (size_t)n_out * k_in, st);
+        if (e != hipSuccess) return (int)e;
+        if (db) {
+            e = hipMemsetAsync(db, 0, sizeof(float) * n_out, st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    if (n <= 0) return 0;
+    dim3 grid((n_out + 63) / 64, (k_in + 255) / 256, split);
+    hipLaunchKernelGGL(mlp_wgrad_kernel, grid, dim3(256), 0, st, dz, dz_stride, x, x_stride, n, n_out, k_in, scale, dW, db,
+                       split > 1 ? 1 : 0);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // SDF value + d sdf / d x  (forward keeps the hidden activations in a workspace; the backward
 // sweep runs in the same workgroup right after, so the workspace lines are still in L2)
 // ------------------------------------------------------------------------------------------------

@@ -175,21 +175,22 @@ class FusedMLPFn(torch.autograd.Function):
         d_out = d_out.contiguous()
         dz = mlp_backward(pm, d_out, stash)
         x0 = encode_inputs(pm, in_a, in_b, in_c, feat)
+        lib = _lib.lib()
+        n = d_out.shape[0]
         gw, gb = [], []
         for l, s in enumerate(pm.specs):
-            dzl = dz[l, :, :s.n_out]
             if l == 0:
-                xin = x0
+                xin, xs = x0, x0.shape[1]
             else:
                 if s.e_len:
                     raise NotImplementedError('weight gradients of skip layers (geometry is frozen in Step-2)')
-                xin = stash[l - 1, :, :s.k_in]
-            # plain library GEMM (rocBLAS): dW = dZ^T X ; db = column sums
-            g = dzl.t().mm(xin)
-            if s.scale != 1.0:
-                g = g * s.scale
+                xin, xs = stash[l - 1], pm.hidden_stride
+            g = torch.empty(s.n_out, s.k_in, device=d_out.device, dtype=torch.float32)
+            b = torch.empty(s.n_out, device=d_out.device, dtype=torch.float32)
+            _lib.check(lib.nefii_mlp_wgrad(_ptr(dz[l]), pm.hidden_stride, _ptr(xin), xs, n, s.n_out, s.k_in, s.scale,
+                                           _ptr(g), _ptr(b), _stream()), 'nefii_mlp_wgrad')
             gw.append(g)
-            gb.append(dzl.sum(0))
+            gb.append(b)
         return (None, None, None, None, None) + tuple(gw) + tuple(gb)
 
 
