@@ -8,7 +8,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'csrc', 'libnefii_hip.so')
+LIB_PATH = os.environ.get('NEFII_LIB_PATH', os.path.join(HERE, 'csrc', 'libnefii_hip.so'))    # override: A/B builds
 
 MAX_LAYERS = 12
 TILE_ROWS = 32

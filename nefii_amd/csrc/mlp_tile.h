@@ -139,45 +139,57 @@ __device__ __forceinline__ void encode_tile(const nefii_mlp &m, const float *raw
 // A fragment: lane (r = lane&31, h = lane>>5) reads A[r][8g + 4h .. +3] with one ds_read_b128;
 // MFMA step s multiplies k = 8g+4h+s: over h (the MFMA's own K=2) and s = 0..3 all 8 k of the group.
 // wp points at group 0 of this layer block: float4 index ((g*NT + t)*64 + lane).
+#ifndef NEFII_FD
+#define NEFII_FD 6
+#endif
+template <int NTW>
+__device__ __forceinline__ void gemm_block_t(const float *arow, int kgroups, const float4 *__restrict__ wp, int NT,
+                                             int wave, int lane, f32x16 (&acc)[4]) {
+    // NB statically indexed register stages of weight fragments (NB-1 k-groups in flight towards L2: the kernels are
+    // latency/bandwidth bound on that stream), two stages of the LDS A fragment; k-loop unrolled NB times so that no
+    // stage is ever copied.
+    constexpr int NB = NEFII_FD;
+    static_assert(NB >= 2 && NB % 2 == 0, "NB must be even");
+    float4 b[NB][NTW];
+    float4 a[2];
+    auto load_b = [&](int u, int g) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) b[u][j] = wp[((size_t)g * NT + wave + 4 * j) * 64 + lane];
+    };
+#pragma unroll
+    for (int u = 0; u < NB - 1; ++u)
+        if (u < kgroups) load_b(u, u);
+    a[0] = *reinterpret_cast<const float4 *>(arow);
+    for (int g0 = 0; g0 < kgroups; g0 += NB) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int g = g0 + u;
+            if (g < kgroups) {
+                if (g + NB - 1 < kgroups) load_b((u + NB - 1) % NB, g + NB - 1);
+                if (g + 1 < kgroups) a[(u + 1) % 2] = *reinterpret_cast<const float4 *>(arow + 8 * (g + 1));
+                const float4 av = a[u % 2];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b[u][j].x, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b[u][j].y, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b[u][j].z, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b[u][j].w, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void gemm_block(const float *A, int a_stride, int kgroups, const float4 *__restrict__ wp,
                                            int NT, int wave, int lane, int ntw, f32x16 (&acc)[4]) {
     if (kgroups <= 0 || ntw <= 0) return;
     const int r = lane & 31, h = lane >> 5;
     const float *arow = A + r * a_stride + 4 * h;
-    // weight fragments run TWO k-groups ahead of the MFMAs (an L2 miss served by the Infinity Cache costs
-    // ~550+ cycles; one group of 16 MFMAs covers 1024), the LDS A fragment one group ahead
-    float4 b0[4], b1[4], b2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        b0[j] = b1[j] = b2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < ntw) {
-            b0[j] = wp[(size_t)(wave + 4 * j) * 64 + lane];
-            if (kgroups > 1) b1[j] = wp[((size_t)NT + wave + 4 * j) * 64 + lane];
-        }
-    }
-    float4 a = *reinterpret_cast<const float4 *>(arow);
-    for (int g = 0; g < kgroups; ++g) {
-        if (g + 2 < kgroups) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < ntw) b2[j] = wp[((size_t)(g + 2) * NT + wave + 4 * j) * 64 + lane];
-        }
-        float4 an = a;
-        if (g + 1 < kgroups) an = *reinterpret_cast<const float4 *>(arow + 8 * (g + 1));
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < ntw) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0[j].x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0[j].y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0[j].z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0[j].w, acc[j], 0, 0, 0);
-            }
-        a = an;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            b0[j] = b1[j];
-            b1[j] = b2[j];
-        }
+    switch (ntw) {          // ntw is wave-uniform; each case has fully static register indexing
+        case 1: gemm_block_t<1>(arow, kgroups, wp, NT, wave, lane, acc); break;
+        case 2: gemm_block_t<2>(arow, kgroups, wp, NT, wave, lane, acc); break;
+        case 3: gemm_block_t<3>(arow, kgroups, wp, NT, wave, lane, acc); break;
+        default: gemm_block_t<4>(arow, kgroups, wp, NT, wave, lane, acc); break;   // callers pass ntw <= 4
     }
 }
 
@@ -191,7 +203,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[4]) {
 // One layer's matrix product for the whole workgroup: acc = [X | E] * W.  Caller does the epilogue.
 __device__ __forceinline__ void layer_gemm(const nefii_layer &L, const float *X, const float *E, const float *w,
                                            int n_tiles, f32x16 (&acc)[4], int &ntw) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     ntw = (n_tiles - wave + 3) >> 2;
     if (ntw < 0) ntw = 0;
     zero_acc(acc);

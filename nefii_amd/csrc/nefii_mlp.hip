@@ -135,7 +135,8 @@ __device__ __forceinline__ void load_tile_inputs(const nefii_mlp &m, const float
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void mlp_forward_kernel(nefii_mlp m, const float *__restrict__ in_a,
+// one workgroup per CU: the epilogue (stash + head functions) needs more than 256 registers next to the pipeline
+__global__ __launch_bounds__(256, 1) void mlp_forward_kernel(nefii_mlp m, const float *__restrict__ in_a,
                                                              const float *__restrict__ in_b,
                                                              const float *__restrict__ in_c,
                                                              const float *__restrict__ feat, int64_t n,
@@ -206,7 +207,7 @@ extern "C" int nefii_mlp_forward(const nefii_mlp *h_mlp, const float *in_a, cons
     if (n <= 0) return 0;
     if (!out) return NEFII_E_ARG;
     const int64_t n_tiles = (n + TILE - 1) / TILE;
-    hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid_for(n_tiles, 2)), dim3(WG), 0, (hipStream_t)stream, *h_mlp, in_a,
+    hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid_for(n_tiles, 1)), dim3(WG), 0, (hipStream_t)stream, *h_mlp, in_a,
                        in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash, stash_stride);
     HIP_CHECK_LAUNCH();
     return 0;
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void mlp_backward_kernel(nefii_mlp m, const
             // dH_{l-1}[32 x k_x] = dZ_l[32 x n_pad] * W_l   (only the hidden block of the inputs)
             f32x16 acc[4];
             int ntw;
-            const int wave = tid >> 6, lane = tid & 63;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
             const int NTs = (L.k_x + L.k_e) >> 5, ntc = L.k_x >> 5;
             ntw = (ntc - wave + 3) >> 2;
             if (ntw < 0) ntw = 0;
@@ -456,13 +457,23 @@ __global__ __launch_bounds__(256, 1) void sdf_value_grad_kernel(nefii_mlp m, con
         // ---- backward to the encoded input
         for (int l = Lm1; l >= 0; --l) {
             const nefii_layer &L = m.layer[l];
-            const int wave = tid >> 6, lane = tid & 63;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
             const int NTs = (L.k_x + L.k_e) >> 5;
-            int ntw = (NTs - wave + 3) >> 2;
-            if (ntw < 0) ntw = 0;
+            const float4 *wb = reinterpret_cast<const float4 *>(L.w_bwd);
             f32x16 acc[4];
+            if (NTs > 16) {
+                // the skip layer of a 512-wide net has 17-18 input tiles ([X | E] = 480 + 64): the tiles past the 16
+                // that fit the accumulators are all encoding columns; do them first (they only touch GE, not lds.X)
+                int ntb = (NTs - 16 - wave + 3) >> 2;
+                if (ntb < 0) ntb = 0;
+                zero_acc(acc);
+                gemm_block(lds.X, XS, L.n_pad >> 3, wb + 16 * 64, NTs, wave, lane, ntb, acc);
+                NEFII_FOR_ACC(acc, ntb, { GE[row * ES + (col + 512 - L.k_x)] += val; })
+            }
+            int ntw = ((NTs < 16 ? NTs : 16) - wave + 3) >> 2;
+            if (ntw < 0) ntw = 0;
             zero_acc(acc);
-            gemm_block(lds.X, XS, L.n_pad >> 3, reinterpret_cast<const float4 *>(L.w_bwd), NTs, wave, lane, ntw, acc);
+            gemm_block(lds.X, XS, L.n_pad >> 3, wb, NTs, wave, lane, ntw, acc);
             __syncthreads();
             NEFII_FOR_ACC(acc, ntw, {
                 if (col < L.k_x) {

@@ -64,6 +64,26 @@ def test_sdf_forward_and_gradient(name, hidden, n):
     assert rel_l2(feat, hid) < 1e-7
 
 
+@pytest.mark.parametrize('name,hidden,n', [('physg', 64, 200), ('conf', 512, 1000), ('physg', 512, 77)])
+def test_sdf_gradient_trained_like_skip_weights(name, hidden, n):
+    """Geometric init zeroes the skip layer's sin/cos columns (implicit_differentiable_renderer.py:70-71); a trained
+    checkpoint does not.  With every skip-layer input column live the 512-wide net has 17 input tiles at the skip."""
+    from nefii_amd import ops
+    mc = syn.model_conf(name, hidden=hidden)
+    sd = syn.make_state_dict(mc, seed=2, bumpy=0.004)
+    g = torch.Generator().manual_seed(9)
+    for l in mc['implicit_network']['skip_in']:
+        w = sd['implicit_network.lin%d.weight_v' % l]
+        w[:, -36:] = torch.randn(w.shape[0], 36, generator=g) * 0.02
+    pm = build_sdf(mc, sd)
+    x = ball_points(n, 3)
+    ref = nets.sdf_forward(sd, mc['implicit_network'], x)
+    gref = nets.sdf_gradient(sd, mc['implicit_network'], x)
+    out, feat, grad = ops.sdf_value_grad(pm, x.to(DEV), want_feat=True)
+    assert rel_l2(out, ref[:, :1]) < 1e-5
+    assert rel_l2(grad, gref) < 2e-5
+
+
 @pytest.mark.parametrize('name,hidden,n', [('physg', 64, 500), ('conf', 64, 301), ('conf', 512, 200), ('physg', 512, 64)])
 def test_radiance_and_material_mlp(name, hidden, n):
     from nefii_amd import ops
