@@ -397,10 +397,13 @@ __device__ __forceinline__ void mfma16w(const AStage16w &sa, const BStage16w &sb
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int c = 0; c < (TWO_COLS ? 2 : 1); ++c) {
+            // weights are the MFMA's A operand, activations its B operand: the accumulator holds the TRANSPOSED
+            // product, lane = query (lane&31), registers = 4 consecutive features x 4 groups - so the epilogue packs
+            // four halves of one LDS row per store and loads biases as float4
             f32x16 &a = acc[rt * 2 + c];
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa.ah[rt], sb.bh[c], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa.ah[rt], sb.bl[c], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sa.al[rt], sb.bh[c], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb.bh[c], sa.ah[rt], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb.bl[c], sa.ah[rt], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb.bh[c], sa.al[rt], a, 0, 0, 0);
         }
 }
 
@@ -456,18 +459,36 @@ __device__ __forceinline__ void layer_gemm16w(const nefii_layer &L, const Lds16w
                   nct, acc);
 }
 
-#define NEFII_FOR_ACC_W(acc, nct, BODY)                                                   \
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// 16 * Softplus(beta=100)(v) from zs = 16 v (the A16_SCALE'd value), for the tracer's split-precision epilogue:
+//   softplus(v) = (max(z,0) + log1p(exp(-|z|)))/100, z = 100 v; exp2/log2 on the transcendental units.
+// Absolute error ~1e-9 (the 1+e rounding only matters where the result is ~1e-7), which is far below the fp32
+// round-off of the 512-term dot products around it; 5 VALU + 2 transcendental instructions per value.
+__device__ __forceinline__ float softplus100_s16(float zs) {
+    const float C_T = -1.44269504088896340736f * 100.f / A16_SCALE;     // -(log2 e) * 100/16
+    const float C_L = 0.69314718055994530942f * A16_SCALE / 100.f;      // ln2 * 16/100
+    const float t = __builtin_fabsf(zs) * C_T;
+    const float u = 1.f + __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(__builtin_amdgcn_logf(u), C_L, __builtin_fmaxf(zs, 0.f));
+}
+
+// transposed accumulator walk of the wide kernel: BODY sees `query` (row of the tile), `f0` (first of 4 consecutive
+// features) and `v` (float4v: the 4 accumulator values)
+#define NEFII_FOR_ACC_WT(acc, nct, BODY)                                                  \
     {                                                                                     \
         const int _wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), _lane = threadIdx.x & 63; \
-        _Pragma("unroll") for (int _rt = 0; _rt < 2; ++_rt)                               \
         _Pragma("unroll") for (int _c = 0; _c < 2; ++_c) if (_c < (nct)) {                \
-            const int col = 32 * (2 * _wave + _c) + (_lane & 31);                         \
-            _Pragma("unroll") for (int _i = 0; _i < 16; ++_i) {                           \
-                const int row = 32 * _rt + (_i & 3) + 8 * (_i >> 2) + 4 * (_lane >> 5);   \
-                const float val = (acc)[_rt * 2 + _c][_i];                                \
-                BODY                                                                      \
+            _Pragma("unroll") for (int _g = 0; _g < 4; ++_g) {                            \
+                const int f0 = 32 * (2 * _wave + _c) + 8 * _g + 4 * (_lane >> 5);         \
+                _Pragma("unroll") for (int _rt = 0; _rt < 2; ++_rt) {                     \
+                    const int query = 32 * _rt + (_lane & 31);                            \
+                    const f32x16 &_a = (acc)[_rt * 2 + _c];                               \
+                    const float4v v = {_a[4 * _g], _a[4 * _g + 1], _a[4 * _g + 2], _a[4 * _g + 3]}; \
+                    BODY                                                                  \
+                }                                                                         \
             }                                                                             \
-            __builtin_amdgcn_sched_barrier(0); /* keep one tile's temporaries live at a time */ \
         }                                                                                 \
     }
 

@@ -549,13 +549,23 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, 
             layer_gemm16w(L, lds, L.n_pad >> 5, acc, nct);
             __syncthreads();
             if (l < Lm1) {
-                NEFII_FOR_ACC_W(acc, nct, {
-                    const float hval = act_fwd(val * inv_scale + L.bias[col], m.act);
-                    split16a(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                const float k16 = inv_scale * A16_SCALE;
+                NEFII_FOR_ACC_WT(acc, nct, {
+                    const float4v b = *reinterpret_cast<const float4v *>(L.bias + f0);
+                    float4v hs;       // A16_SCALE * activation
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {
+                        const float zs = __builtin_fmaf(v[k], k16, b[k] * A16_SCALE);
+                        hs[k] = m.act == NEFII_ACT_SOFTPLUS100 ? softplus100_s16(zs)
+                                                               : act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
+                    }
+                    const half4 hi = __builtin_convertvector(hs, half4);
+                    const half4 lo = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+                    *reinterpret_cast<half4 *>(&lds.Xh[query * XS16 + f0]) = hi;
+                    *reinterpret_cast<half4 *>(&lds.Xl[query * XS16 + f0]) = lo;
                 })
             } else {
-                NEFII_FOR_ACC_W(acc, nct, {
-                    if (col == 0 && dest[row]) *dest[row] = val * inv_scale + L.bias[0];
+                NEFII_FOR_ACC_WT(acc, nct, {
+                    if (f0 == 0 && dest[query]) *dest[query] = v[0] * inv_scale + L.bias[0];
                 })
             }
             __syncthreads();
