@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 1
+#define NEFII_ABI_VERSION 2
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -61,15 +61,21 @@ typedef struct nefii_mlp {
                                 (embedder.py:38-50: x, sin(2^k x), cos(2^k x), k < L) */
     int32_t feat_width;      /* per-point feature vector loaded into X before layer 0 (0 = none) */
     int32_t reserved;
+    const void *w_stream;    /* optional (SDF nets, split precision): the hidden layers' w_f16x3 fragments re-packed as one
+                                stream per wave for the pipelined tile evaluator (nefii_pack_sdf_stream), or NULL */
     nefii_layer layer[NEFII_MAX_LAYERS];
 } nefii_mlp;
 
 int nefii_abi_version(void);
 
+/* Padded width of a hidden/output block of v columns: multiples of 32 up to 32, multiples of 64 beyond (every
+ * 16-deep k-step count of the split-precision kernels is then a multiple of 4).  Encoded-input blocks pad to 32. */
+int nefii_padded_width(int v);
+
 /* Re-order one layer's effective weight W [n_out][k_in] (PyTorch nn.Linear layout, after weight-norm)
  * into MFMA fragment order, multiplying by `scale` (1/sqrt(2) for skip layers).
  * Input columns [x_src0, x_src0+x_len) feed the X block, [e_src0, e_src0+e_len) the E block
- * (block widths are padded up to multiples of 32 with zeros).  Writes w_fwd ( (kx+ke)*n_pad floats ),
+ * (X block and n_out padded with zeros to nefii_padded_width, E block to a multiple of 32).  Writes w_fwd ( (kx+ke)*n_pad floats ),
  * optionally w_bwd ( n_pad*(kx+ke) floats ) and bias_pad ( n_pad floats, from bias or zeros ). */
 int nefii_pack_linear(const float *W, const float *bias, int n_out, int k_in,
                       int x_src0, int x_len, int e_src0, int e_len, float scale,
@@ -133,6 +139,20 @@ typedef struct nefii_tracer_params {
                                 1 = 3x fp16 split MFMA, 32-query tiles; 2 = the same arithmetic on 64-query tiles
                                 (8 waves, weight fragments shared by two row tiles); 1 and 2 need w_f16x3 */
 } nefii_tracer_params;
+
+/* The pipelined evaluator behind nefii_trace_rays (precision 2) and nefii_sdf_eval reads the hidden layers' fragments as
+ * ONE stream per wave: [8 waves][k-steps of layer 0, 1, ... back to back][hi/lo of the wave's two column tiles][64][8].
+ * nefii_sdf_stream_bytes: size of that buffer, 0 if the net's shape does not qualify (every hidden layer 512 wide,
+ * k_x in {0,512}, k_e in {0,64}, 512-deep last layer) - such nets run on the generic kernel and leave w_stream NULL.
+ * nefii_pack_sdf_stream: device-side copy from the layers' w_f16x3 (call after nefii_pack_linear_f16x3). */
+size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf);
+int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, void *stream);
+
+/* sdf_out[i] = implicit_network(x[i])[:, 0] (implicit_differentiable_renderer.py:85-108) with the tracer's
+ * split-precision tile evaluator (the arithmetic of precision 2): the bulk SDF query the reference issues from
+ * ray_tracing.py:128-131,211-216,322-327 and pixel_pair_generator.py:52, as a stand-alone call.  x [n][3], needs
+ * w_f16x3 in every layer (and uses w_stream when set); bias arrays hold n_pad floats, 16-byte aligned. */
+int nefii_sdf_eval(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream);
 
 size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *h_params);
 int nefii_trace_max_rounds(const nefii_tracer_params *h_params);

@@ -14,7 +14,7 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
 HEAD_NONE, HEAD_TANH01, HEAD_POW2, HEAD_SIGMOID, HEAD_RELU, HEAD_ABS, HEAD_RELU_INIT = range(7)
@@ -31,7 +31,7 @@ class Layer(ctypes.Structure):
 class Mlp(ctypes.Structure):
     _fields_ = [('n_layers', ctypes.c_int32), ('act', ctypes.c_int32), ('head', ctypes.c_int32),
                 ('enc_freqs', ctypes.c_int32 * 3), ('feat_width', ctypes.c_int32), ('reserved', ctypes.c_int32),
-                ('layer', Layer * MAX_LAYERS)]
+                ('w_stream', ctypes.c_void_p), ('layer', Layer * MAX_LAYERS)]
 
 
 class TracerParams(ctypes.Structure):
@@ -50,6 +50,7 @@ F = ctypes.c_float
 # name -> (restype, argtypes); every symbol include/nefii_amd.h declares
 SIGNATURES = {
     'nefii_abi_version': (I, []),
+    'nefii_padded_width': (I, [I]),
     'nefii_pack_linear': (I, [P, P, I, I, I, I, I, I, F, P, P, P, P]),
     'nefii_pack_linear_f16x3': (I, [P, I, I, I, I, I, I, F, P, P]),
     'nefii_mlp_forward': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P]),
@@ -58,6 +59,9 @@ SIGNATURES = {
     'nefii_encode_inputs': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P]),
     'nefii_sdf_value_grad': (I, [ctypes.POINTER(Mlp), P, I64, P, I, P, I, P, P, P]),
     'nefii_sdf_value_grad_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp), I64]),
+    'nefii_sdf_stream_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp)]),
+    'nefii_pack_sdf_stream': (I, [ctypes.POINTER(Mlp), P, P]),
+    'nefii_sdf_eval': (I, [ctypes.POINTER(Mlp), P, I64, P, P]),
     'nefii_trace_workspace_bytes': (ctypes.c_size_t, [I64, ctypes.POINTER(TracerParams)]),
     'nefii_trace_max_rounds': (I, [ctypes.POINTER(TracerParams)]),
     'nefii_trace_rays': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(TracerParams), P, P, P, I64, P, P, P, P, P, P,

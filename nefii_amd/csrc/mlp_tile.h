@@ -492,6 +492,296 @@ __device__ __forceinline__ float softplus100_s16(float zs) {
         }                                                                                 \
     }
 
+// ================================================================================================
+// Pipelined wide variant ("16p"): the arithmetic of the wide kernel, restructured around what bounds it - the
+// ~70 GB/s per CU at which weight fragments arrive from L2 (MI355X_MICROARCH.md, "Indexed rows"): a 64-query tile
+// pulls the whole 7.3 MB network through that pipe, which takes as long as its matrix-core work.  Both only overlap
+// if the fragment stream never drains and runs far enough ahead of the MFMAs that consume it:
+//   * ONE activation image per half (hi / lo), 584 halves per row = hidden columns [0,512) | encoding [512,576):
+//     a layer's input is the contiguous column range [512 - k_x, 512 + k_e), its k-loop one uniform run;
+//   * the hidden layers' fragments re-packed as ONE stream per wave (nefii_pack_sdf_stream: layers back to back,
+//     wrapping to the next tile's first layer), read by a free-running cursor: the prefetch distance (NB-1 k-steps)
+//     does not know about layer boundaries;
+//   * NB statically named register stages; with 8 stages a layer starts at stage 0 or 4 (all k-step counts are
+//     multiples of 4), hence two instantiations of the k-loop;
+//   * no conditional loads: every k-step issues exactly four 1-KiB loads, so the s_waitcnt vmcnt() the compiler
+//     derives is static ("all but the youngest NB-1 stages") instead of a vmcnt(0) drain at every join - sched_barriers keep
+//     its scheduler from sinking the prefetches back to their uses;
+//   * a layer's 64 biases per wave travel in ONE register (lane j holds bias[64 wave + j], fetched at the top of the
+//     layer, older than all its prefetches) and reach their lanes through ds_bpermute in the epilogue.
+// Shapes: every hidden layer 512 wide (n_pad), k_x in {0,512}, k_e in {0,64}, 512-deep last layer - fits16p();
+// other nets take the generic wide kernel.
+// ================================================================================================
+constexpr int XP16 = 584;               // halves per row (1168 B = 16 B * 73: ds_read_b128 stays conflict-free)
+constexpr int EP16 = 512;               // first encoding column
+struct Lds16p {
+    _Float16 Xh[TILE_W * XP16], Xl[TILE_W * XP16];
+    _Float16 tail[64];                  // the A-fragment prefetch of a layer's (non-existent) next k-step lands here
+};
+// Workgroup shape: NW = 8 waves (two per SIMD, 256 registers each, 2 column tiles per wave, 4 stages = 96 KiB of
+// fragments in flight per CU).  The 4-wave shape (one wave per SIMD, 512 registers, 8 stages) is written out below but
+// not instantiated: hipcc 7.2 spills ~540 registers on it.
+template <int NW>
+struct P16 {
+    static constexpr int NC = 16 / NW;              // column tiles per wave
+    static constexpr int NB = NW == 4 ? 8 : 4;      // fragment stages (6 with two waves per SIMD: hipcc spills)
+    static constexpr int STEP = 2 * NC * 64;        // half8 per k-step of one wave's stream
+    struct Stage {
+        half8 f[2 * NC];                            // hi, lo of each column tile
+    };
+};
+// free-running read position in the wave's fragment stream
+struct PCursor {
+    const half8 *base;                  // lane's pointer to k-step 0
+    unsigned off, bytes;                // current byte offset, stream length
+};
+
+template <int NW>
+__device__ __forceinline__ void pload(typename P16<NW>::Stage &st, PCursor &c) {
+    const half8 *p = reinterpret_cast<const half8 *>(reinterpret_cast<const char *>(c.base) + c.off);
+#pragma unroll
+    for (int i = 0; i < 2 * P16<NW>::NC; ++i) st.f[i] = p[64 * i];
+    c.off += P16<NW>::STEP * 16;
+    c.off = c.off == c.bytes ? 0u : c.off;
+}
+
+__device__ __forceinline__ void pload_a(AStage16w &st, const _Float16 *ah, const _Float16 *al, int s) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        st.ah[rt] = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP16 + 16 * s);
+        st.al[rt] = *reinterpret_cast<const half8 *>(al + rt * 32 * XP16 + 16 * s);
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void pmfma(const AStage16w &sa, const typename P16<NW>::Stage &sb,
+                                      f32x16 (&acc)[2 * P16<NW>::NC]) {
+    constexpr int NC = P16<NW>::NC;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            f32x16 &a = acc[rt * NC + c];
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb.f[2 * c], sa.ah[rt], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb.f[2 * c + 1], sa.ah[rt], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(sb.f[2 * c], sa.al[rt], a, 0, 0, 0);
+        }
+}
+
+// one k-step: prefetch the fragments NB-1 steps ahead into the stage consumed last step, read the next step's
+// activation fragments, multiply this step's.  J = stage of this step, U = its parity (activation double buffer).
+template <int NW, int J, int U>
+__device__ __forceinline__ void pstep(typename P16<NW>::Stage (&b)[P16<NW>::NB], AStage16w (&a)[2], PCursor &cur,
+                                      const _Float16 *ah, const _Float16 *al, int s,
+                                      f32x16 (&acc)[2 * P16<NW>::NC]) {
+    constexpr int NB = P16<NW>::NB;
+    // Issue order inside the step: the MFMAs lead and the step's memory instructions (prefetch of the stage consumed last
+    // step, next step's activation fragments) are spread between them, two MFMAs per instruction.  Issuing the eight
+    // memory instructions in a block ahead of the MFMAs leaves the matrix pipe idle while they issue and cost 13 % of
+    // the tile time (s_memtime stamps, tools/stamps.py); the closing sched_barrier keeps the compiler from sinking
+    // a prefetch past the step (it otherwise moves every load down to its use and drains the pipeline).
+    pload<NW>(b[(J + NB - 1) % NB], cur);
+    pload_a(a[(U + 1) & 1], ah, al, s + 1);
+    pmfma<NW>(a[U & 1], b[J], acc);
+#pragma unroll
+    for (int i = 0; i < 2 * P16<NW>::NC; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // 2 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);    // 1 VMEM read
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, P16<NW>::NC, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NW, int J0>
+__device__ __forceinline__ void pstep4(typename P16<NW>::Stage (&b)[P16<NW>::NB], AStage16w (&a)[2], PCursor &cur,
+                                       const _Float16 *ah, const _Float16 *al, int s,
+                                       f32x16 (&acc)[2 * P16<NW>::NC]) {
+    pstep<NW, J0, 0>(b, a, cur, ah, al, s, acc);
+    pstep<NW, J0 + 1, 1>(b, a, cur, ah, al, s + 1, acc);
+    pstep<NW, J0 + 2, 0>(b, a, cur, ah, al, s + 2, acc);
+    pstep<NW, J0 + 3, 1>(b, a, cur, ah, al, s + 3, acc);
+}
+
+// k-loop of one layer whose first k-step sits in stage PH; ks is a multiple of 4 (PH is 0, or 4 with 8 stages)
+template <int NW, int PH>
+__device__ __forceinline__ void pgemm(int ks, typename P16<NW>::Stage (&b)[P16<NW>::NB], AStage16w (&a)[2],
+                                      PCursor &cur, const _Float16 *ah, const _Float16 *al,
+                                      f32x16 (&acc)[2 * P16<NW>::NC]) {
+    constexpr int NB = P16<NW>::NB;
+    static_assert((NB == 4 && PH == 0) || (NB == 8 && (PH == 0 || PH == 4)), "stage bookkeeping");
+    int s = 0;
+    if constexpr (NB == 4) {
+        for (; s < ks; s += 4) pstep4<NW, 0>(b, a, cur, ah, al, s, acc);
+    } else {
+        if (PH == 4) {
+            pstep4<NW, 4>(b, a, cur, ah, al, 0, acc);
+            s = 4;
+        }
+        for (; s + 8 <= ks; s += 8) {
+            pstep4<NW, 0>(b, a, cur, ah, al, s, acc);
+            pstep4<NW, 4>(b, a, cur, ah, al, s + 4, acc);
+        }
+        if (s < ks) pstep4<NW, 0>(b, a, cur, ah, al, s, acc);
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ void encode_tile16p(const nefii_mlp &m, const float *raw, Lds16p &lds, int k_e) {
+    const int tid = threadIdx.x;
+    const int p = tid & 63, part = tid >> 6;
+    const int w0 = enc_width(m.enc_freqs[0]);
+    for (int c = part; c < k_e; c += NW) {
+        const float val = c < w0 ? enc_value(raw + p * 9, c) : 0.f;
+        split16a(val, lds.Xh[p * XP16 + EP16 + c], lds.Xl[p * XP16 + EP16 + c]);
+    }
+}
+
+// start of a workgroup: stages 0..NB-2 <- k-steps 0..NB-2 of the stream
+template <int NW>
+__device__ __forceinline__ void prime16p(const nefii_mlp &m, typename P16<NW>::Stage (&b)[P16<NW>::NB],
+                                         PCursor &cur) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int G = 0;
+    for (int l = 0; l < m.n_layers - 1; ++l) G += (m.layer[l].k_x + m.layer[l].k_e) >> 4;
+    cur.bytes = (unsigned)G * P16<NW>::STEP * 16;
+    cur.base = reinterpret_cast<const half8 *>(m.w_stream) + (size_t)wave * G * P16<NW>::STEP + lane;
+    cur.off = 0;
+#pragma unroll
+    for (int u = 0; u < P16<NW>::NB - 1; ++u) pload<NW>(b[u], cur);
+}
+
+// One 64-query tile through the whole SDF network.  Stage/cursor state runs on from tile to tile (ph = stage of the
+// next k-step).  raw[64][9]: the points (overwritten with the last layer's partial sums); dest[64]: where each SDF
+// value goes (nullptr = padding row).
+#ifdef NEFII_STAMPS     /* timing instrumentation: s_memtime at 5 points per layer, workgroup 0, into g_stamps */
+__device__ unsigned long long g_stamps[2 * 8 * 12 * 5];
+__device__ int g_stamp_tile;
+#define NEFII_STAMP(i)                                                                                   \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && g_stamp_tile < 2)                                  \
+        g_stamps[((g_stamp_tile * 8 + wave) * 12 + l) * 5 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define NEFII_STAMP(i)
+#endif
+
+template <int NW>
+__device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, float *raw, float *const *dest,
+                                            typename P16<NW>::Stage (&b)[P16<NW>::NB], PCursor &cur, int &ph, int ke) {
+    constexpr int NC = P16<NW>::NC, NB = P16<NW>::NB;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int NH = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    const float k16 = inv_scale * A16_SCALE;
+    encode_tile16p<NW>(m, raw, lds, ke);
+    __syncthreads();
+    const _Float16 *ah0 = lds.Xh + r * XP16 + 8 * h, *al0 = lds.Xl + r * XP16 + 8 * h;
+    for (int l = 0; l < NH; ++l) {
+        const nefii_layer &L = m.layer[l];
+        const int ks = (L.k_x + L.k_e) >> 4;
+        const _Float16 *ah = ah0 + (EP16 - L.k_x), *al = al0 + (EP16 - L.k_x);
+        const float *bp = L.bias + 32 * NC * wave + lane;
+        // everything prefetched so far has had a whole epilogue to land: an explicit drain here costs nothing and gives
+        // the compiler's waitcnt pass a known state at the loop headers
+        asm volatile("" ::"s"(ks), "v"(ah), "v"(al), "v"(bp));
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+        NEFII_STAMP(0);
+        float bvec[NC / 2];
+#pragma unroll
+        for (int i = 0; i < NC / 2; ++i) bvec[i] = bp[64 * i];
+        f32x16 acc[2 * NC];
+#pragma unroll
+        for (int j = 0; j < 2 * NC; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+        AStage16w a[2];
+        pload_a(a[0], ah, al, 0);
+        if (NB == 4 || ph == 0)
+            pgemm<NW, 0>(ks, b, a, cur, ah, al, acc);
+        else
+            pgemm<NW, (NB == 8 ? 4 : 0)>(ks, b, a, cur, ah, al, acc);
+        ph = (ph + ks) % NB;
+        NEFII_STAMP(1);
+        __syncthreads();
+        NEFII_STAMP(2);
+        // epilogue: activation, hi/lo split, four halves of one row per store (transposed accumulator, see mfma16w)
+        _Float16 *xh = lds.Xh + (EP16 - L.n_pad), *xl = lds.Xl + (EP16 - L.n_pad);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int bsrc = __builtin_bit_cast(int, bvec[c >> 1] * A16_SCALE);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = 32 * (NC * wave + c) + 8 * g + 4 * h;
+                float4v bs;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    bs[k] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_ds_bpermute(4 * (32 * (c & 1) + 8 * g + 4 * h + k), bsrc));
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int query = 32 * rt + r;
+                    const f32x16 &av = acc[rt * NC + c];
+                    float4v hs;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float zs = __builtin_fmaf(av[4 * g + k], k16, bs[k]);
+                        hs[k] = m.act == NEFII_ACT_SOFTPLUS100 ? softplus100_s16(zs)
+                                                               : act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
+                    }
+                    const half4 hi = __builtin_convertvector(hs, half4);
+                    const half4 lo = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+                    *reinterpret_cast<half4 *>(xh + query * XP16 + f0) = hi;
+                    *reinterpret_cast<half4 *>(xl + query * XP16 + f0) = lo;
+                }
+            }
+        }
+        NEFII_STAMP(3);
+        __syncthreads();
+        NEFII_STAMP(4);
+    }
+    // last layer, column 0 only (the SDF value): its 512-deep dot product is split over the waves, partial sums
+    // meet in LDS
+    {
+        const nefii_layer &L = m.layer[NH];
+        const int NT = L.n_pad >> 5;
+        const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
+        const _Float16 *ah = ah0 + (EP16 - L.k_x), *al = al0 + (EP16 - L.k_x);
+        const int ksw = (L.k_x >> 4) / NW;          // k-steps per wave
+        f32x16 acc2[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc2[0][i] = acc2[1][i] = 0.f;
+        for (int u = 0; u < ksw; ++u) {
+            const int s = wave * ksw + u;
+            const half8 wh = wl[(size_t)s * NT * 128], wlo = wl[(size_t)s * NT * 128 + 64];
+            AStage16w a;
+            pload_a(a, ah, al, s);
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a.ah[rt], acc2[rt], 0, 0, 0);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, a.ah[rt], acc2[rt], 0, 0, 0);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a.al[rt], acc2[rt], 0, 0, 0);
+            }
+        }
+        if (h == 0) {       // feature 0 = register 0 of lanes 0..31
+            raw[wave * TILE_W + r] = acc2[0][0];
+            raw[wave * TILE_W + 32 + r] = acc2[1][0];
+        }
+        __syncthreads();
+        if (threadIdx.x < TILE_W) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += raw[w * TILE_W + threadIdx.x];
+            float *d = dest[threadIdx.x];
+            if (d) *d = sum * inv_scale + L.bias[0];
+        }
+        __syncthreads();
+    }
+}
+
 // accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
 #define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \

@@ -11,6 +11,10 @@ using namespace nefii;
     } while (0)
 
 static inline int round32(int v) { return (v + 31) & ~31; }
+// hidden / output widths: multiples of 64 once wider than one 32-column tile, so that every 16-deep k-step count of
+// the split-precision kernels is a multiple of 4 (their 4-stage fragment pipeline never needs a remainder loop)
+static inline int pad_hidden(int v) { return v <= 32 ? round32(v) : (v + 63) & ~63; }
+extern "C" int nefii_padded_width(int v) { return v < 0 ? NEFII_E_ARG : pad_hidden(v); }
 
 extern "C" int nefii_abi_version(void) { return NEFII_ABI_VERSION; }
 
@@ -51,7 +55,7 @@ extern "C" int nefii_pack_linear(const float *W, const float *bias, int n_out, i
                                  int e_src0, int e_len, float scale, float *w_fwd, float *w_bwd, float *bias_pad,
                                  void *stream) {
     if (!W || !w_fwd || !bias_pad || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
-    const int kx = round32(x_len), ke = round32(e_len), n_pad = round32(n_out);
+    const int kx = pad_hidden(x_len), ke = round32(e_len), n_pad = pad_hidden(n_out);
     if (n_pad > NEFII_MAX_WIDTH || kx > NEFII_MAX_WIDTH || ke > NEFII_MAX_ENC || kx + ke == 0) return NEFII_E_SHAPE;
     if (x_src0 + x_len > k_in || e_src0 + e_len > k_in) return NEFII_E_SHAPE;
     const int total = (kx + ke) * n_pad;
@@ -89,7 +93,7 @@ __global__ void pack_linear_f16x3_kernel(const float *__restrict__ W, int n_out,
 extern "C" int nefii_pack_linear_f16x3(const float *W, int n_out, int k_in, int x_src0, int x_len, int e_src0, int e_len,
                                        float scale, void *w_f16x3, void *stream) {
     if (!W || !w_f16x3 || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
-    const int kx = round32(x_len), ke = round32(e_len), n_pad = round32(n_out);
+    const int kx = pad_hidden(x_len), ke = round32(e_len), n_pad = pad_hidden(n_out);
     if (n_pad > NEFII_MAX_WIDTH || kx > NEFII_MAX_WIDTH || ke > NEFII_MAX_ENC || kx + ke == 0) return NEFII_E_SHAPE;
     if (x_src0 + x_len > k_in || e_src0 + e_len > k_in) return NEFII_E_SHAPE;
     const int total = ((kx + ke) >> 4) * (n_pad >> 5) * 64;

@@ -523,6 +523,43 @@ __global__ __launch_bounds__(256, 2) void eval_kernel16(Params P, nefii_mlp m, i
 }
 
 // wide split-precision variant: 64 queries per workgroup of 8 waves (mlp_tile.h, Lds16w)
+// One tile: raw[64][9] holds the points, dest[64] where each SDF value goes (nullptr = padding row).
+__device__ __forceinline__ void sdf_tile16w(const nefii_mlp &m, Lds16w &lds, const float *raw, float *const *dest,
+                                            int ke) {
+    const int Lm1 = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    encode_tile16w(m, raw, lds, ke);
+    __syncthreads();
+    for (int l = 0; l <= Lm1; ++l) {
+        const nefii_layer &L = m.layer[l];
+        f32x16 acc[4];
+        int nct;
+        layer_gemm16w(L, lds, L.n_pad >> 5, acc, nct);
+        __syncthreads();
+        if (l < Lm1) {
+            const float k16 = inv_scale * A16_SCALE;
+            NEFII_FOR_ACC_WT(acc, nct, {
+                const float4v b = *reinterpret_cast<const float4v *>(L.bias + f0);
+                float4v hs;       // A16_SCALE * activation
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) {
+                    const float zs = __builtin_fmaf(v[k], k16, b[k] * A16_SCALE);
+                    hs[k] = m.act == NEFII_ACT_SOFTPLUS100 ? softplus100_s16(zs)
+                                                           : act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
+                }
+                const half4 hi = __builtin_convertvector(hs, half4);
+                const half4 lo = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+                *reinterpret_cast<half4 *>(&lds.Xh[query * XS16 + f0]) = hi;
+                *reinterpret_cast<half4 *>(&lds.Xl[query * XS16 + f0]) = lo;
+            })
+        } else {
+            NEFII_FOR_ACC_WT(acc, nct, {
+                if (f0 == 0 && dest[query]) *dest[query] = v[0] * inv_scale + L.bias[0];
+            })
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, int round) {
     __shared__ Lds16w lds;
     __shared__ float raw[TILE_W * 9];
@@ -535,41 +572,133 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, 
     const int64_t n_tiles = (total + TILE_W - 1) / TILE_W;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
-    const int Lm1 = m.n_layers - 1;
-    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         decode_tile<TILE_W>(P, tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
-        encode_tile16w(m, raw, lds, ke);
+        sdf_tile16w(m, lds, raw, dest, ke);
+    }
+}
+
+// pipelined variant (mlp_tile.h "16p"): 512-wide hidden layers, fragment stream never drains
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Params P, nefii_mlp m, int round) {
+    __shared__ Lds16p lds;
+    __shared__ float raw[TILE_W * 9];
+    __shared__ float *dest[TILE_W];
+    const int n_single = P.counters[round * 4 + 0];
+    const int n_dense = P.counters[round * 4 + 1];
+    const int n_tri = P.counters[round * 4 + 2];
+    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
+    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
+    const int64_t n_tiles = (total + TILE_W - 1) / TILE_W;
+    if (blockIdx.x >= n_tiles) return;
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    typename P16<NW>::Stage b[P16<NW>::NB];
+    PCursor cur;
+    int ph = 0;
+    prime16p<NW>(m, b, cur);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        decode_tile<TILE_W>(P, tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
-        for (int l = 0; l <= Lm1; ++l) {
-            const nefii_layer &L = m.layer[l];
-            f32x16 acc[4];
-            int nct;
-            layer_gemm16w(L, lds, L.n_pad >> 5, acc, nct);
-            __syncthreads();
-            if (l < Lm1) {
-                const float k16 = inv_scale * A16_SCALE;
-                NEFII_FOR_ACC_WT(acc, nct, {
-                    const float4v b = *reinterpret_cast<const float4v *>(L.bias + f0);
-                    float4v hs;       // A16_SCALE * activation
-                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {
-                        const float zs = __builtin_fmaf(v[k], k16, b[k] * A16_SCALE);
-                        hs[k] = m.act == NEFII_ACT_SOFTPLUS100 ? softplus100_s16(zs)
-                                                               : act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
-                    }
-                    const half4 hi = __builtin_convertvector(hs, half4);
-                    const half4 lo = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
-                    *reinterpret_cast<half4 *>(&lds.Xh[query * XS16 + f0]) = hi;
-                    *reinterpret_cast<half4 *>(&lds.Xl[query * XS16 + f0]) = lo;
-                })
-            } else {
-                NEFII_FOR_ACC_WT(acc, nct, {
-                    if (f0 == 0 && dest[query]) *dest[query] = v[0] * inv_scale + L.bias[0];
-                })
-            }
-            __syncthreads();
+        sdf_tile16p<NW>(m, lds, raw, dest, b, cur, ph, ke);
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void sdf_points_kernel16p(nefii_mlp m,
+                                                                                const float *__restrict__ x,
+                                                                                int64_t n, float *__restrict__ out) {
+    __shared__ Lds16p lds;
+    __shared__ float raw[TILE_W * 9];
+    __shared__ float *dest[TILE_W];
+    const int64_t n_tiles = (n + TILE_W - 1) / TILE_W;
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    typename P16<NW>::Stage b[P16<NW>::NB];
+    PCursor cur;
+    int ph = 0;
+    prime16p<NW>(m, b, cur);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tid = threadIdx.x;
+        if (tid < TILE_W) {
+            const int64_t q = tile * TILE_W + tid;
+            float *rw = raw + tid * 9;
+            const bool live = q < n;
+            rw[0] = live ? x[q * 3] : 0.f, rw[1] = live ? x[q * 3 + 1] : 0.f, rw[2] = live ? x[q * 3 + 2] : 0.f;
+            rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
+            dest[tid] = live ? out + q : nullptr;
         }
+        __syncthreads();
+        sdf_tile16p<NW>(m, lds, raw, dest, b, cur, ph, ke);
+#ifdef NEFII_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamp_tile = g_stamp_tile + 1;
+        __syncthreads();
+#endif
+    }
+}
+
+#ifdef NEFII_STAMPS
+extern "C" int nefii_debug_stamps(unsigned long long *host_out) {
+    int zero = 0;
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 2 * 8 * 12 * 5);
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_tile), &zero, sizeof(int));
+    return (int)e;
+}
+#endif
+
+constexpr int P16W = 8;      // waves per workgroup of the pipelined kernels
+
+// shapes the pipelined kernel takes: every hidden layer 512 wide, k-step counts multiples of 4, a 512-deep last layer
+bool shape16p(const nefii_mlp *m) {
+    const int NH = m->n_layers - 1;
+    if (NH < 1) return false;
+    for (int l = 0; l < NH; ++l) {
+        const nefii_layer &L = m->layer[l];
+        if (L.n_pad != 512 || (L.k_x != 0 && L.k_x != 512) || (L.k_e != 0 && L.k_e != 64) || L.k_x + L.k_e == 0)
+            return false;
+    }
+    const nefii_layer &Ll = m->layer[NH];
+    return Ll.k_x == 512 && Ll.k_e == 0;
+}
+bool fits16p(const nefii_mlp *m) { return m->w_stream && shape16p(m); }
+
+int stream_steps(const nefii_mlp *m) {
+    int G = 0;
+    for (int l = 0; l < m->n_layers - 1; ++l) G += (m->layer[l].k_x + m->layer[l].k_e) >> 4;
+    return G;
+}
+
+// dst[(wave*G + g)*256 + i] <- the 4 KiB fragment block of (k-step s, column tiles 2 wave, 2 wave + 1)
+__global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int G) {
+    const int g = blockIdx.x, wave = blockIdx.y;
+    int l = 0, s = g;
+    while (s >= ((m.layer[l].k_x + m.layer[l].k_e) >> 4)) s -= (m.layer[l].k_x + m.layer[l].k_e) >> 4, ++l;
+    const half8 *src = reinterpret_cast<const half8 *>(m.layer[l].w_f16x3) + ((size_t)s * 16 + 2 * wave) * 2 * 64;
+    dst[((size_t)wave * G + g) * 256 + threadIdx.x] = src[threadIdx.x];
+}
+
+// the same tile evaluator over an explicit point list (nefii_sdf_eval)
+__global__ __launch_bounds__(512, 2) void sdf_points_kernel16w(nefii_mlp m, const float *__restrict__ x, int64_t n,
+                                                              float *__restrict__ out) {
+    __shared__ Lds16w lds;
+    __shared__ float raw[TILE_W * 9];
+    __shared__ float *dest[TILE_W];
+    const int64_t n_tiles = (n + TILE_W - 1) / TILE_W;
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tid = threadIdx.x;
+        if (tid < TILE_W) {
+            const int64_t q = tile * TILE_W + tid;
+            float *rw = raw + tid * 9;
+            const bool live = q < n;
+            rw[0] = live ? x[q * 3] : 0.f, rw[1] = live ? x[q * 3 + 1] : 0.f, rw[2] = live ? x[q * 3 + 2] : 0.f;
+            rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
+            dest[tid] = live ? out + q : nullptr;
+        }
+        __syncthreads();
+        sdf_tile16w(m, lds, raw, dest, ke);
     }
 }
 
@@ -661,6 +790,42 @@ extern "C" int nefii_trace_profile_launches(float *h_ms, int cap) {
     return n;
 }
 
+extern "C" size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf) {
+    if (!h_sdf || h_sdf->n_layers < 2 || h_sdf->n_layers > NEFII_MAX_LAYERS || !shape16p(h_sdf)) return 0;
+    return (size_t)8 * stream_steps(h_sdf) * 256 * sizeof(half8);
+}
+
+extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, void *stream) {
+    if (!h_sdf || !w_stream) return NEFII_E_ARG;
+    if (nefii_sdf_stream_bytes(h_sdf) == 0) return NEFII_E_UNSUPPORTED;
+    for (int l = 0; l < h_sdf->n_layers - 1; ++l)
+        if (!h_sdf->layer[l].w_f16x3) return NEFII_E_ARG;
+    const int G = stream_steps(h_sdf);
+    hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, (half8 *)w_stream, G);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nefii_sdf_eval(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream) {
+    if (!h_sdf || h_sdf->n_layers < 1 || h_sdf->n_layers > NEFII_MAX_LAYERS) return NEFII_E_ARG;
+    if (n <= 0) return 0;
+    if (!x || !sdf_out) return NEFII_E_ARG;
+    if (h_sdf->enc_freqs[0] < 0 || h_sdf->enc_freqs[1] >= 0 || h_sdf->enc_freqs[2] >= 0 || h_sdf->feat_width != 0 ||
+        h_sdf->layer[0].k_x != 0)
+        return NEFII_E_UNSUPPORTED;
+    for (int l = 0; l < h_sdf->n_layers; ++l)
+        if (!h_sdf->layer[l].w_f16x3 || !h_sdf->layer[l].bias) return NEFII_E_ARG;
+    const int64_t n_tiles = (n + TILE_W - 1) / TILE_W;
+    if (fits16p(h_sdf))
+        hipLaunchKernelGGL(sdf_points_kernel16p<P16W>, dim3((int)(n_tiles < 512 ? n_tiles : 512)), dim3(64 * P16W), 0,
+                           (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    else
+        hipLaunchKernelGGL(sdf_points_kernel16w, dim3((int)(n_tiles < 512 ? n_tiles : 512)), dim3(WG_W), 0,
+                           (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     if (!p) return 0;
     // initial eval + iters*(step + back-offs) -> sampler -> bisection (L levels per round) -> min-SDF -> bookkeeping
@@ -732,6 +897,7 @@ extern "C" int nefii_trace_rays_rounds(const nefii_mlp *h_sdf, const nefii_trace
     int64_t max_q = n_rays * (int64_t)h_params->n_steps;      // n_steps >= 2^levels > bisection tree nodes > 2 ends
     int64_t max_tiles = (max_q + TILE - 1) / TILE;
     const int eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
+    const bool pipelined = h_params->precision == 2 && fits16p(h_sdf);
     const int64_t max_tiles_w = (max_q + TILE_W - 1) / TILE_W;
     const int eval_blocks_w = (int)(max_tiles_w < 512 ? max_tiles_w : 512);
     if (g_prof.on) {
@@ -751,7 +917,9 @@ extern "C" int nefii_trace_rays_rounds(const nefii_mlp *h_sdf, const nefii_trace
                 e1 = prof_event();
                 (void)hipEventRecord(e0, st);
             }
-            if (h_params->precision == 2)
+            if (h_params->precision == 2 && pipelined)
+                hipLaunchKernelGGL(eval_kernel16p<P16W>, dim3(eval_blocks_w), dim3(64 * P16W), 0, st, P, *h_sdf, r);
+            else if (h_params->precision == 2)
                 hipLaunchKernelGGL(eval_kernel16w, dim3(eval_blocks_w), dim3(WG_W), 0, st, P, *h_sdf, r);
             else if (h_params->precision == 1)
                 hipLaunchKernelGGL(eval_kernel16, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);

@@ -18,6 +18,11 @@ def _round32(v):
     return (v + 31) // 32 * 32
 
 
+def _pad_hidden(v):
+    """nefii_padded_width: hidden/output widths are multiples of 64 once wider than one 32-column tile."""
+    return _round32(v) if v <= 32 else (v + 63) // 64 * 64
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -44,7 +49,7 @@ class LayerSpec:
     def __init__(self, n_out, k_in, x_src0=0, x_len=0, e_src0=0, e_len=0, scale=1.0):
         self.n_out, self.k_in = n_out, k_in
         self.x_src0, self.x_len, self.e_src0, self.e_len, self.scale = x_src0, x_len, e_src0, e_len, scale
-        self.k_x, self.k_e, self.n_pad = _round32(x_len), _round32(e_len), _round32(n_out)
+        self.k_x, self.k_e, self.n_pad = _pad_hidden(x_len), _round32(e_len), _pad_hidden(n_out)
 
 
 class PackedMLP:
@@ -77,6 +82,14 @@ class PackedMLP:
             L.bias = self.bias[l].data_ptr()
             L.w_f16x3 = self.w_f16[l].data_ptr() if f16x3 else None
         self.struct = m
+        # SDF nets of the qualifying shape also keep their hidden layers as one fragment stream per wave (the
+        # pipelined tile evaluator of the tracer); other nets leave w_stream NULL and run on the generic kernel
+        self.w_stream = None
+        if f16x3 and torch.device(device).type == 'cuda':
+            nbytes = _lib.lib().nefii_sdf_stream_bytes(ctypes.byref(m))
+            if nbytes and feat_width == 0 and self.enc_freqs[1] < 0 and self.enc_freqs[2] < 0:
+                self.w_stream = torch.zeros(nbytes // 2, device=device, dtype=torch.float16)
+                m.w_stream = self.w_stream.data_ptr()
         self.hidden_stride = max(s.n_pad for s in specs)
         self.packed_version = None
 
@@ -103,6 +116,9 @@ class PackedMLP:
             if self.f16x3:
                 _lib.check(lib.nefii_pack_linear_f16x3(_ptr(w), s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0, s.e_len,
                                                        s.scale, _ptr(self.w_f16[l]), st), 'nefii_pack_linear_f16x3')
+        if self.w_stream is not None:
+            _lib.check(lib.nefii_pack_sdf_stream(ctypes.byref(self.struct), _ptr(self.w_stream), st),
+                       'nefii_pack_sdf_stream')
 
 
 def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False):
@@ -210,6 +226,17 @@ def sdf_value_grad(pm, x, want_feat=False):
                                             feat.shape[1] if feat is not None else 0, _ptr(grad), _ptr(ws), _stream()),
                    'nefii_sdf_value_grad')
     return out, feat, grad
+
+
+def sdf_eval(pm, x):
+    """implicit_network(x)[:, 0] with the tracer's split-precision tile evaluator (needs PackedMLP(f16x3=True))."""
+    lib = _lib.lib()
+    x = x.contiguous()
+    n = x.shape[0]
+    out = torch.empty(n, device=x.device, dtype=torch.float32)
+    if n > 0:
+        _lib.check(lib.nefii_sdf_eval(ctypes.byref(pm.struct), _ptr(x), n, _ptr(out), _stream()), 'nefii_sdf_eval')
+    return out
 
 
 PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}

@@ -84,6 +84,30 @@ def test_sdf_gradient_trained_like_skip_weights(name, hidden, n):
     assert rel_l2(grad, gref) < 2e-5
 
 
+@pytest.mark.parametrize('name,hidden,n', [('physg', 512, 1), ('physg', 512, 64), ('conf', 512, 1000), ('neus', None, 333),
+                                           ('physg', 64, 129), ('conf', 512, 70000)])
+def test_sdf_eval_split_precision(name, hidden, n):
+    """nefii_sdf_eval = implicit_network(x)[:, 0] on the tracer's split-precision tile evaluators: the pipelined
+    stream kernel for 512-wide nets (PackedMLP.w_stream), the generic wide kernel for the others."""
+    from nefii_amd import ops
+    mc = syn.model_conf(name, hidden=hidden)
+    sd = syn.make_state_dict(mc, seed=3, bumpy=0.02 if hidden == 64 else 0.004)
+    g = torch.Generator().manual_seed(11)
+    for l in mc['implicit_network']['skip_in']:       # trained-like skip weights (see the test above)
+        w = sd['implicit_network.lin%d.weight_v' % l]
+        w[:, -36:] = torch.randn(w.shape[0], 36, generator=g) * 0.02
+    pm = build_sdf(mc, sd, f16x3=True)
+    assert (pm.w_stream is not None) == (hidden == 512)
+    x = ball_points(n, 3)
+    out = ops.sdf_eval(pm, x.to(DEV)).cpu()
+    m = min(n, 4000)
+    ref = nets.sdf_forward({k: v.double() for k, v in sd.items()}, mc['implicit_network'], x[:m].double())[:, 0]
+    assert (out[:m].double() - ref).abs().max().item() < 5e-6
+    if n > m:       # every tile of a multi-tile launch agrees with the f32 kernel
+        f32 = ops.mlp_forward(pm, x.to(DEV), None, None, None)[0][:, 0].cpu()
+        assert (out - f32).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize('name,hidden,n', [('physg', 64, 500), ('conf', 64, 301), ('conf', 512, 200), ('physg', 512, 64)])
 def test_radiance_and_material_mlp(name, hidden, n):
     from nefii_amd import ops

@@ -31,7 +31,7 @@ def test_struct_layout_matches_header():
     from nefii_amd import _lib
     # nefii_layer: 4 x int32 + 4 pointers; nefii_mlp: 8 x int32 + 12 layers
     assert ctypes.sizeof(_lib.Layer) == 16 + 4 * 8
-    assert ctypes.sizeof(_lib.Mlp) == 32 + 12 * ctypes.sizeof(_lib.Layer)
+    assert ctypes.sizeof(_lib.Mlp) == 40 + 12 * ctypes.sizeof(_lib.Layer)
     assert ctypes.sizeof(_lib.TracerParams) == 40
 
 
@@ -55,3 +55,24 @@ def test_ops_fail_loudly_without_gpu_tensor():
     from nefii_amd import ops
     with pytest.raises(RuntimeError):
         ops.camera_rays(torch.zeros(1, 4, 2), torch.eye(4)[None], torch.eye(4)[None])
+
+
+def test_padded_width_rule_matches_host():
+    from nefii_amd import _lib, ops
+    lib = _lib.lib()
+    for v in [0, 1, 3, 31, 32, 33, 39, 64, 65, 217, 256, 257, 473, 480, 512]:
+        assert lib.nefii_padded_width(v) == ops._pad_hidden(v)
+    assert lib.nefii_padded_width(473) == 512 and lib.nefii_padded_width(25) == 32
+
+
+def test_sdf_stream_size():
+    from nefii_amd import _lib, ops, synthetic as syn
+    lib = _lib.lib()
+    for name, hidden, want in [('physg', 512, 8 * (4 + 32 * 3 + 36 + 32 * 3) * 4096), ('physg', 64, 0), ('neus', None, 0)]:
+        mc = syn.model_conf(name, hidden=hidden)
+        specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
+        m = _lib.Mlp()
+        m.n_layers = len(specs)
+        for l, s in enumerate(specs):
+            m.layer[l].k_x, m.layer[l].k_e, m.layer[l].n_out, m.layer[l].n_pad = s.k_x, s.k_e, s.n_out, s.n_pad
+        assert lib.nefii_sdf_stream_bytes(ctypes.byref(m)) == want
