@@ -166,8 +166,10 @@ def main():
     rays_per_rank = inp['uv'].shape[1] * (w['num_rays'] if w['num_rays'] > 0 else 1)
     indirect = mc.get('render_type', 'sg') != 'sg'
     # conf.conf runs: secondary-consistency step every 10 iterations on 1024/world points (robot/run_s2.sh:25-26)
+    # closed-form shading: the step's tail replays as a hipGraph after 3 eager iterations (NEFII_BENCH_GRAPH=0: eager)
+    use_graph = os.environ.get('NEFII_BENCH_GRAPH', '1') != '0' and not indirect
     step = TrainStep(model, lc, world_size=world, secondary_train_interval=10 if indirect else 0,
-                     secondary_batch_size=1024, num_rays=w['num_rays'])
+                     secondary_batch_size=1024, num_rays=w['num_rays'], graph=use_graph)
 
     for _ in range(args.warmup):
         step(inp, gt)
@@ -221,13 +223,14 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic_%s.json' % args.workload)
         kname = {'f32': 'eval_kernel', 'f16x3': 'eval_kernel16', 'f16x3w': 'eval_kernel16w'}[model.ray_tracer.precision]
+        if prec == 'f16x3w' and model.implicit_network.packed(f16x3=True).w_stream is not None:
+            kname = 'eval_kernel16p'        # 512-wide nets: the pipelined stream kernel (mlp_tile.h "16p")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get('kernel') == kname:
                 traffic = tj['hbm_bytes_per_launch']
         roofline = {'bound': 'mfma',
-                    'kernel': {'f32': 'eval_kernel', 'f16x3': 'eval_kernel16', 'f16x3w': 'eval_kernel16w'}[prec] +
-                              ' (fused SDF MLP over the tracer work list)',
+                    'kernel': kname + ' (fused SDF MLP over the tracer work list)',
                     'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
                     'traffic_unit': 'HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, averaged over all launches '
                                     'of the kernel incl. empty rounds; profiles/r01/pmc_traffic_*.json)',

@@ -260,6 +260,13 @@ class IDRNetwork(nn.Module):
 
     # ---- forward_with_uv (:312-501) ------------------------------------------------------------------
     def forward_with_uv(self, input):
+        ctx = self.trace_head(input)
+        idx = torch.nonzero(ctx['network_object_mask']).flatten()          # one host sync per call (compaction size)
+        return self.shade_tail(ctx, idx)
+
+    def trace_head(self, input):
+        """Camera rays -> surface points (no autograd): everything of forward_with_uv (:312-356) ahead of the
+        compaction of the hit rays.  Returns the tensors shade_tail needs, all of the static shape [B*S*R, .]."""
         if self.training and not self.state_freeze_geo:
             raise NotImplementedError('training with trainable geometry is outside the Step-2 hot path; '
                                       'call freeze_geometry()')
@@ -268,12 +275,13 @@ class IDRNetwork(nn.Module):
         pose = input['pose']
         object_mask = input['object_mask'].reshape(-1)
         multi = uv.dim() == 4
+        shape = None
         if multi:
             B, S, R, _ = uv.shape
+            shape = (B, S, R)
             uv = uv.reshape(B, S * R, 2)
             object_mask = object_mask.reshape(B, S, 1).expand(B, S, R).reshape(-1)
         ray_dirs, cam_loc = rend_util.get_camera_params(uv, pose, intrinsics)
-        batch_size, num_pixels, _ = ray_dirs.shape
         with torch.no_grad():
             points, network_object_mask, dists = self.ray_tracer(sdf=self.implicit_network, cam_loc=cam_loc,
                                                                  object_mask=object_mask, ray_directions=ray_dirs)
@@ -286,27 +294,38 @@ class IDRNetwork(nn.Module):
                 sdf_output = pre[0]
             else:
                 sdf_output = self.implicit_network(points)[:, 0:1]
-        ray_dirs = ray_dirs.reshape(-1, 3)
+        return {'points': points, 'network_object_mask': network_object_mask, 'object_mask': object_mask,
+                'sdf_output': sdf_output, 'pre': pre, 'ray_dirs': ray_dirs.reshape(-1, 3), 'multi': shape}
+
+    def shade_tail(self, ctx, idx, dst=None):
+        """Shading of the compacted hit rays `idx` and assembly of the output dict (:358-501).
+        dst (optional, same length as idx): row of the output each entry is scattered to.  A caller that pads idx to
+        a fixed length (graph capture, training/step.py) points the padding entries at row n_all, a scratch row that
+        is sliced off again, and gets shapes that do not depend on the hit count; background colours are then
+        evaluated for all rays and blended by mask instead of gathered."""
+        points, network_object_mask, object_mask = ctx['points'], ctx['network_object_mask'], ctx['object_mask']
+        sdf_output, pre, ray_dirs = ctx['sdf_output'], ctx['pre'], ctx['ray_dirs']
         surface_mask = network_object_mask
         n_all = points.shape[0]
+        rows = n_all + (1 if dst is not None else 0)
         dev = points.device
         def ones():
-            return torch.ones(n_all, 3, device=dev)
+            return torch.ones(rows, 3, device=dev)
         out = {'idr_rgb_values': ones(), 'sg_rgb_values': ones(), 'normal_values': ones(),
                'sg_diffuse_rgb_values': ones(), 'sg_diffuse_albedo_values': ones(),
-               'sg_specular_rgb_values': torch.zeros(n_all, 3, device=dev),
-               'sg_roughness_values': torch.zeros(n_all, 1, device=dev),
-               'sg_specular_reflection_values': torch.zeros(n_all, 3, device=dev)}
+               'sg_specular_rgb_values': torch.zeros(rows, 3, device=dev),
+               'sg_roughness_values': torch.zeros(rows, 1, device=dev),
+               'sg_specular_reflection_values': torch.zeros(rows, 3, device=dev)}
         ret = {}
-        idx = torch.nonzero(surface_mask).flatten()          # one host sync per call (compaction size)
         if idx.numel() > 0:
             if pre is not None:
                 pre = (None, pre[1].index_select(0, idx) if pre[1] is not None else None, pre[2].index_select(0, idx))
             ret = self.get_rbg_value(points.index_select(0, idx), -ray_dirs.index_select(0, idx), surface=pre)
+            where = idx if dst is None else dst
 
             def put(key, src):
                 src = src.expand(idx.shape[0], out[key].shape[1]).to(out[key].dtype)
-                out[key] = out[key].index_put((idx,), src)
+                out[key] = out[key].index_put((where,), src)
             put('idr_rgb_values', ret['idr_rgb'])
             put('sg_rgb_values', ret['sg_rgb'])
             put('normal_values', ret['normals'])
@@ -315,11 +334,17 @@ class IDRNetwork(nn.Module):
             put('sg_specular_rgb_values', ret['sg_specular_rgb'])
             put('sg_roughness_values', ret['sg_roughness'])
             put('sg_specular_reflection_values', ret['sg_specular_reflectance'])
+        if dst is not None:
+            out = {k: v[:n_all] for k, v in out.items()}
         if self.render_background:
-            bidx = torch.nonzero(~surface_mask).flatten()
-            if bidx.numel() > 0:
-                bg = self.get_background_rgb(ray_dirs.index_select(0, bidx))
-                out['sg_rgb_values'] = out['sg_rgb_values'].index_put((bidx,), bg)
+            if dst is None:
+                bidx = torch.nonzero(~surface_mask).flatten()
+                if bidx.numel() > 0:
+                    bg = self.get_background_rgb(ray_dirs.index_select(0, bidx))
+                    out['sg_rgb_values'] = out['sg_rgb_values'].index_put((bidx,), bg)
+            else:
+                out['sg_rgb_values'] = torch.where(surface_mask.unsqueeze(-1), out['sg_rgb_values'],
+                                                   self.get_background_rgb(ray_dirs))
         output = {
             'points': points,
             'idr_rgb_values': out['idr_rgb_values'],
@@ -338,7 +363,8 @@ class IDRNetwork(nn.Module):
             'secondary_mask': ret.get('secondary_mask', None),
             'secondary_dir': ret.get('secondary_dir', None),
         }
-        if multi:
+        if ctx['multi'] is not None:
+            B, S, R = ctx['multi']
             for key in ['idr_rgb_values', 'sg_rgb_values', 'network_object_mask', 'object_mask',
                         'sg_diffuse_rgb_values', 'sg_diffuse_albedo_values', 'sg_specular_rgb_values', 'sdf_output',
                         'points', 'sg_roughness_values', 'sg_specular_reflection_values']:

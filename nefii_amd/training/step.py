@@ -35,9 +35,59 @@ def allreduce_mean_gradients(params, world_size, group=None):
     return flat.numel() * flat.element_size()
 
 
+def _detached(d):
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+class _StepGraph:
+    """One captured hipGraph of the step's tail for a fixed padded hit count: shading of the compacted hit rays,
+    IDRLoss, backward and - single process - both Adam updates.  Inputs live in static buffers."""
+
+    def __init__(self, step, ctx, idx_pad, dst_pad, ground_truth):
+        self.static_ctx = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in ctx.items() if k != 'pre'}
+        pre = ctx['pre']
+        self.static_ctx['pre'] = None if pre is None else tuple(None if t is None else t.clone() for t in pre)
+        self.idx, self.dst = idx_pad.clone(), dst_pad.clone()
+        self.gt = {k: v.clone() for k, v in ground_truth.items() if torch.is_tensor(v)}
+        self.graph = torch.cuda.CUDAGraph()
+        step.idr_optimizer.zero_grad(set_to_none=True)
+        step.sg_optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.out = step.model.shade_tail(self.static_ctx, self.idx, self.dst)
+            self.lo = step.loss(self.out, self.gt)
+            self.lo['loss'].backward()
+            if step.world_size <= 1:
+                step.idr_optimizer.step()
+                step.sg_optimizer.step()
+        self.grads = [(p, p.grad) for p in step.trainable]      # the tensors every replay writes its gradients to
+        # keep the static result tensors, not the autograd graph behind them: AccumulateGrad nodes that outlive their
+        # iteration are re-used by the next backward on THEIR stream, which breaks the next capture
+        self.out = _detached(self.out)
+        self.lo = _detached(self.lo)
+
+    def load(self, ctx, idx_pad, dst_pad, ground_truth):
+        for k, v in ctx.items():
+            if k == 'pre' and v is not None:
+                for d, t in zip(self.static_ctx['pre'], v):
+                    if t is not None:
+                        d.copy_(t)
+            elif torch.is_tensor(v):
+                self.static_ctx[k].copy_(v)
+        self.idx.copy_(idx_pad)
+        self.dst.copy_(dst_pad)
+        for k, v in self.gt.items():
+            v.copy_(ground_truth[k])
+
+
 class TrainStep:
     def __init__(self, model, loss_conf, idr_lr=5e-4, sg_lr=5e-4, world_size=1, secondary_train_interval=0,
-                 secondary_batch_size=1024, num_rays=1):
+                 secondary_batch_size=1024, num_rays=1, graph=False, graph_bucket=256, graph_after=3):
+        """graph=True: after `graph_after` eager iterations the part of the step behind the tracer - whose launch count
+        (~170 small kernels) rather than its GPU time bounds it - replays as a captured hipGraph.  The hit count varies
+        from batch to batch, so the compacted index list is padded to a multiple of `graph_bucket` (padding rows
+        scatter into a scratch output row and receive zero gradient: same loss and gradients as the eager step up to
+        summation order) and one graph is kept per padded size.  Only the closed-form `sg` shading qualifies (the
+        Monte-Carlo path traces secondary rays, with data-dependent shapes of its own)."""
         self.model = model
         self.loss = IDRLoss(**loss_conf)
         self.world_size = world_size
@@ -50,12 +100,48 @@ class TrainStep:
         # same Adam as the reference (idr_train.py:188-196); `fused` only selects torch's single-kernel
         # implementation of the identical update when the parameters live on the GPU
         fused = next(model.parameters()).is_cuda
+        self.graph = bool(graph) and fused and getattr(model, 'render_type', None) == 'sg'
+        self.graph_bucket, self.graph_after = int(graph_bucket), int(graph_after)
+        self._graphs = {}
+        kw = dict(fused=fused, capturable=True) if self.graph else dict(fused=fused)
         self.idr_optimizer = torch.optim.Adam(list(model.implicit_network.parameters()) +
-                                              list(model.rendering_network.parameters()), lr=idr_lr, fused=fused)
-        self.sg_optimizer = torch.optim.Adam(model.envmap_material_network.parameters(), lr=sg_lr, fused=fused)
+                                              list(model.rendering_network.parameters()), lr=idr_lr, **kw)
+        self.sg_optimizer = torch.optim.Adam(model.envmap_material_network.parameters(), lr=sg_lr, **kw)
         self.trainable = [p for p in model.parameters() if p.requires_grad]
 
+    def _graph_step(self, model_input, ground_truth):
+        ctx = self.model.trace_head(model_input)
+        idx = torch.nonzero(ctx['network_object_mask']).flatten()      # the step's one host sync
+        n_hit, n_all = idx.numel(), ctx['points'].shape[0]
+        if n_hit == 0:
+            return None
+        P = -(-n_hit // self.graph_bucket) * self.graph_bucket
+        pad = P - n_hit
+        idx_pad = torch.cat([idx, idx[:1].expand(pad)]) if pad else idx
+        dst_pad = torch.cat([idx, idx.new_full((pad,), n_all)]) if pad else idx
+        key = (P, n_all)
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._graphs[key] = _StepGraph(self, ctx, idx_pad, dst_pad, ground_truth)
+        else:
+            g.load(ctx, idx_pad, dst_pad, ground_truth)
+        g.graph.replay()
+        for p, grad in g.grads:       # an eager step in between may have re-pointed .grad
+            p.grad = grad
+        if self.world_size > 1:
+            allreduce_mean_gradients(self.trainable, self.world_size)
+            self.idr_optimizer.step()
+            self.sg_optimizer.step()
+        return g.out, g.lo
+
     def __call__(self, model_input, ground_truth):
+        if self.graph and self.cur_iter >= self.graph_after and self.model.training:
+            res = self._graph_step(model_input, ground_truth)
+            if res is not None:
+                if self.secondary_train_interval > 0 and self.cur_iter % self.secondary_train_interval == 0:
+                    self.train_with_secondary(res[0])
+                self.cur_iter += 1
+                return res
         out = self.model(model_input)
         lo = self.loss(out, ground_truth)
         self.idr_optimizer.zero_grad()
@@ -67,7 +153,7 @@ class TrainStep:
         if self.secondary_train_interval > 0 and self.cur_iter % self.secondary_train_interval == 0:
             self.train_with_secondary(out)
         self.cur_iter += 1
-        return out, lo
+        return _detached(out), _detached(lo)
 
     def train_with_secondary(self, model_outputs):
         """L1(sg_rgb, idr_rgb) at secondary hit points, seen from the direction they were hit from

@@ -143,6 +143,41 @@ def test_train_step_full_size_vs_oracle(wl):
     assert abs(gpu_evals - cpu_evals) <= 0.01 * cpu_evals, (gpu_evals, cpu_evals)
 
 
+@pytest.mark.parametrize('hidden,npix,multi', [(64, 512, -1), (64, 64, 4)])
+def test_graph_step_matches_eager_step(hidden, npix, multi):
+    """TrainStep(graph=True): the captured tail (shading of the padded hit list, IDRLoss, backward, both Adam updates)
+    gives the eager step's losses and parameter trajectory; different inputs per iteration change the hit count and
+    so the padded size / the graph that replays."""
+    from nefii_amd.training.step import TrainStep
+    mc = syn.model_conf('physg', hidden=hidden)
+    mc['render_background'] = True
+    sd = syn.make_state_dict(mc, seed=4, bumpy=0.02)
+    lc = syn.loss_conf('physg')
+    lc['idr_rgb_weight'] = 1.0
+    batches = []
+    for it in range(7):
+        inp, gt = syn.make_inputs(npix, (64, 64), 100.0 + 7 * it, (0.2, 0.1, 2.0 + 0.05 * it), multi, seed=20 + it)
+        batches.append((to_dev(inp), {'rgb': gt.to(DEV)}))
+    runs = []
+    for graph in (False, True):
+        m = build_model(mc, sd, True)
+        m.ray_tracer.minsdf_steps_override = [torch.rand(100, generator=torch.Generator().manual_seed(3)) for _ in range(99)]
+        st = TrainStep(m, lc, graph=graph, graph_bucket=64, graph_after=2)
+        losses = []
+        for inp, gt in batches:
+            out, lo = st(inp, gt)
+            losses.append({k: v.item() for k, v in lo.items()})
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, st))
+    (l0, p0, _), (l1, p1, st1) = runs
+    assert len(st1._graphs) >= 2          # the hit count did change the padded size
+    for a, b in zip(l0, l1):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-4 * max(abs(a[k]), 1e-3), (k, a[k], b[k])
+    for k in p0:
+        if p0[k].dtype.is_floating_point:
+            assert rel_l2(p1[k], p0[k]) < 1e-4, (k, rel_l2(p1[k], p0[k]))
+
+
 def test_state_dict_roundtrip_and_eval_mode():
     mc = syn.model_conf('physg', hidden=64)
     sd = syn.make_state_dict(mc, seed=5, bumpy=0.02)
