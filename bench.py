@@ -173,6 +173,12 @@ def main():
 
     for _ in range(args.warmup):
         step(inp, gt)
+    # the graph of the step's tail is captured once per padded hit count, after 3 eager steps: with fewer warm-up steps
+    # than that, run the missing ones (still untimed) so that no capture lands in the timed region
+    priming = 0
+    while use_graph and not step._graphs and priming < 6:
+        step(inp, gt)
+        priming += 1
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -244,7 +250,8 @@ def main():
                     'profiled_step_ms': prof_step_ms, 'hit_fraction': hit_frac}
         result = {
             'metric': 'training rays/sec (Step-2 material opt)', 'value': value, 'unit': 'rays/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'graph_priming_steps': priming,
+            'ms_per_step': ms_per_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f16x3' if model.ray_tracer.precision.startswith('f16x3') else 'f32', 'data': 'synthetic',
             'config': {'workload': '%s: robot-like synthetic scene (geometric-init SDF), %s model, num_pixels=%d per GPU'

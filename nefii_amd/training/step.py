@@ -52,7 +52,7 @@ class _StepGraph:
         self.graph = torch.cuda.CUDAGraph()
         step.idr_optimizer.zero_grad(set_to_none=True)
         step.sg_optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):   # RCCL's watchdog thread stays legal
             self.out = step.model.shade_tail(self.static_ctx, self.idx, self.dst)
             self.lo = step.loss(self.out, self.gt)
             self.lo['loss'].backward()
@@ -81,13 +81,20 @@ class _StepGraph:
 
 class TrainStep:
     def __init__(self, model, loss_conf, idr_lr=5e-4, sg_lr=5e-4, world_size=1, secondary_train_interval=0,
-                 secondary_batch_size=1024, num_rays=1, graph=False, graph_bucket=256, graph_after=3):
+                 secondary_batch_size=1024, num_rays=1, graph=False, graph_bucket=256, graph_after=3,
+                 idr_sched_milestones=(), idr_sched_factor=0.0, sg_sched_milestones=(), sg_sched_factor=0.0,
+                 alpha_milestones=(), alpha_factor=0.0, roughness_warmup=-1, specular_warmup=-1, start_iter=0):
         """graph=True: after `graph_after` eager iterations the part of the step behind the tracer - whose launch count
         (~170 small kernels) rather than its GPU time bounds it - replays as a captured hipGraph.  The hit count varies
         from batch to batch, so the compacted index list is padded to a multiple of `graph_bucket` (padding rows
         scatter into a scratch output row and receive zero gradient: same loss and gradients as the eager step up to
         summation order) and one graph is kept per padded size.  Only the closed-form `sg` shading qualifies (the
-        Monte-Carlo path traces secondary rays, with data-dependent shapes of its own)."""
+        Monte-Carlo path traces secondary rays, with data-dependent shapes of its own).
+
+        The per-iteration hooks of the reference's loop (idr_train.py:692-713,799-802) are part of the step: the mask
+        loss's alpha doubles (x alpha_factor) at alpha_milestones, the material network reports fake roughness /
+        specular while cur_iter < roughness_warmup / specular_warmup, and both MultiStepLR schedulers
+        (train.{idr,sg}_sched_milestones / _factor, idr_train.py:190-198) advance once per iteration."""
         self.model = model
         self.loss = IDRLoss(**loss_conf)
         self.world_size = world_size
@@ -96,18 +103,51 @@ class TrainStep:
         self.secondary_train_interval = secondary_train_interval
         self.secondary_batch_size = secondary_batch_size // max(world_size, 1)
         self.num_rays = max(num_rays, 1)
-        self.cur_iter = 0
+        self.cur_iter = int(start_iter)
+        self.alpha_milestones, self.alpha_factor = tuple(alpha_milestones), alpha_factor
+        self.roughness_warmup, self.specular_warmup = int(roughness_warmup), int(specular_warmup)
+        for acc in self.alpha_milestones:          # resuming past a milestone (idr_train.py:325-327)
+            if self.cur_iter > acc:
+                self.loss.alpha = self.loss.alpha * self.alpha_factor
         # same Adam as the reference (idr_train.py:188-196); `fused` only selects torch's single-kernel
         # implementation of the identical update when the parameters live on the GPU
         fused = next(model.parameters()).is_cuda
         self.graph = bool(graph) and fused and getattr(model, 'render_type', None) == 'sg'
         self.graph_bucket, self.graph_after = int(graph_bucket), int(graph_after)
         self._graphs = {}
+        self._eager_steps = 0     # captures need an initialised optimiser state: the first steps run eagerly
         kw = dict(fused=fused, capturable=True) if self.graph else dict(fused=fused)
+        if self.graph:      # a captured Adam reads its learning rate from device memory: the schedulers fill it in place
+            dev = next(model.parameters()).device
+            idr_lr, sg_lr = torch.tensor(float(idr_lr), device=dev), torch.tensor(float(sg_lr), device=dev)
         self.idr_optimizer = torch.optim.Adam(list(model.implicit_network.parameters()) +
                                               list(model.rendering_network.parameters()), lr=idr_lr, **kw)
         self.sg_optimizer = torch.optim.Adam(model.envmap_material_network.parameters(), lr=sg_lr, **kw)
+        self.idr_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.idr_optimizer, list(idr_sched_milestones),
+                                                                  gamma=idr_sched_factor)
+        self.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.sg_optimizer, list(sg_sched_milestones),
+                                                                 gamma=sg_sched_factor)
         self.trainable = [p for p in model.parameters() if p.requires_grad]
+
+    def _pre_iteration(self):
+        """idr_train.py:692-713, in the reference's order."""
+        if self.cur_iter in self.alpha_milestones:
+            self.loss.alpha = self.loss.alpha * self.alpha_factor
+        mat = self.model.envmap_material_network
+        if self.cur_iter < self.roughness_warmup:
+            mat.set_roughness_fake(True)
+        elif self.cur_iter == self.roughness_warmup:
+            mat.set_roughness_fake(False)
+        if self.cur_iter < self.specular_warmup:
+            mat.set_specular_fake(True)
+        elif self.cur_iter == self.specular_warmup:
+            mat.set_specular_fake(False)
+
+    def _post_iteration(self):
+        """idr_train.py:799-802."""
+        self.cur_iter += 1
+        self.idr_scheduler.step()
+        self.sg_scheduler.step()
 
     def _graph_step(self, model_input, ground_truth):
         ctx = self.model.trace_head(model_input)
@@ -119,7 +159,10 @@ class TrainStep:
         pad = P - n_hit
         idx_pad = torch.cat([idx, idx[:1].expand(pad)]) if pad else idx
         dst_pad = torch.cat([idx, idx.new_full((pad,), n_all)]) if pad else idx
-        key = (P, n_all)
+        mat = self.model.envmap_material_network
+        # everything a capture bakes in: shapes, the python-side switches of the material network, the loss's alpha
+        key = (P, n_all, bool(getattr(mat, 'fake_roughness', False)), bool(getattr(mat, 'fake_specular', False)),
+               float(self.loss.alpha))
         g = self._graphs.get(key)
         if g is None:
             g = self._graphs[key] = _StepGraph(self, ctx, idx_pad, dst_pad, ground_truth)
@@ -135,13 +178,15 @@ class TrainStep:
         return g.out, g.lo
 
     def __call__(self, model_input, ground_truth):
-        if self.graph and self.cur_iter >= self.graph_after and self.model.training:
+        self._pre_iteration()
+        if self.graph and self._eager_steps >= self.graph_after and self.model.training:
             res = self._graph_step(model_input, ground_truth)
             if res is not None:
                 if self.secondary_train_interval > 0 and self.cur_iter % self.secondary_train_interval == 0:
                     self.train_with_secondary(res[0])
-                self.cur_iter += 1
+                self._post_iteration()
                 return res
+        self._eager_steps += 1
         out = self.model(model_input)
         lo = self.loss(out, ground_truth)
         self.idr_optimizer.zero_grad()
@@ -152,7 +197,7 @@ class TrainStep:
         self.sg_optimizer.step()
         if self.secondary_train_interval > 0 and self.cur_iter % self.secondary_train_interval == 0:
             self.train_with_secondary(out)
-        self.cur_iter += 1
+        self._post_iteration()
         return _detached(out), _detached(lo)
 
     def train_with_secondary(self, model_outputs):
