@@ -201,6 +201,7 @@ def main():
         # ---- roofline of the dominant kernel: one extra, un-timed step with per-launch HIP events
         model.ray_tracer.collect_counters = True
         model.ray_tracer.counter_sum = None
+        model.ray_tracer.stream_groups = 1      # the profiled step runs the rounds back to back on one stream
         lib.nefii_trace_profile_enable(1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -178,6 +178,18 @@ int nefii_trace_rays_rounds(const nefii_mlp *h_sdf, const nefii_tracer_params *h
                             float *out_points, uint8_t *out_hit, float *out_dists,
                             void *workspace, size_t workspace_bytes, int32_t *counters,
                             int round_begin, int round_end, void *stream);
+/* The same for n_groups contiguous chunks of the ray batch (rays [group_begin[g], group_begin[g+1]) ), each with its own
+ * workspace and hipStream_t, enqueued round-major so that all chunks advance together.  Rays are independent: results
+ * are those of one nefii_trace_rays_rounds call over the whole batch.  What it buys: the latency-bound rounds of a small
+ * batch (fewer 64-query tiles than CUs - one tile time per round, however few the queries) of different chunks overlap
+ * on the chip.  counters: [n_groups][max_rounds][4].  The caller orders the streams against its own (events). */
+int nefii_trace_rays_groups(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
+                            const float *origins, const float *dirs, const uint8_t *object_mask,
+                            int n_groups, const int64_t *group_begin,
+                            const float *lin_steps, const float *minsdf_steps,
+                            float *out_points, uint8_t *out_hit, float *out_dists,
+                            void *const *workspaces, const size_t *workspace_bytes, int32_t *counters,
+                            int round_begin, int round_end, void *const *streams);
 
 /* Measurement hooks (bench.py): when enabled, nefii_trace_rays brackets every SDF-evaluation launch with HIP
  * events on the launch stream; nefii_trace_profile_read returns the summed launch durations (ms), the number

@@ -68,6 +68,8 @@ SIGNATURES = {
                              ctypes.c_size_t, P, P]),
     'nefii_trace_rays_rounds': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(TracerParams), P, P, P, I64, P, P, P, P, P, P,
                                     ctypes.c_size_t, P, I, I, P]),
+    'nefii_trace_rays_groups': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(TracerParams), P, P, P, I, P, P, P, P, P, P, P, P,
+                                    P, I, I, P]),
     'nefii_trace_profile_enable': (I, [I]),
     'nefii_trace_profile_read': (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I), ctypes.POINTER(ctypes.c_double)]),
     'nefii_trace_profile_launches': (I, [ctypes.POINTER(ctypes.c_float), I]),

@@ -841,17 +841,25 @@ extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer
     return bytes;
 }
 
-extern "C" int nefii_trace_rays_rounds(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
-                                       const float *origins, const float *dirs, const uint8_t *object_mask,
-                                       int64_t n_rays, const float *lin_steps, const float *minsdf_steps,
-                                       float *out_points, uint8_t *out_hit, float *out_dists, void *workspace,
-                                       size_t workspace_bytes, int32_t *counters, int round_begin, int round_end,
-                                       void *stream) {
+// One tracer invocation (a ray batch on a stream), split into prepare / one round / finish so that several batches can be
+// enqueued round by round on separate streams (nefii_trace_rays_groups).
+struct TraceJob {
+    Params P;
+    const nefii_mlp *sdf;
+    int precision, rounds, adv_blocks, eval_blocks, eval_blocks_w;
+    bool pipelined;
+    hipStream_t st;
+    int32_t *counters;
+};
+
+int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *h_params, const float *origins,
+                const float *dirs, const uint8_t *object_mask, int64_t n_rays, const float *lin_steps,
+                const float *minsdf_steps, float *out_points, uint8_t *out_hit, float *out_dists, void *workspace,
+                size_t workspace_bytes, int32_t *counters, bool reset, void *stream) {
     if (!h_sdf || !h_params || !origins || !dirs || !object_mask || !lin_steps || !out_points || !out_hit ||
         !out_dists || !workspace)
         return NEFII_E_ARG;
-    if (n_rays <= 0) return 0;
-    if (n_rays >= (1ll << 29)) return NEFII_E_SHAPE;
+    if (n_rays <= 0 || n_rays >= (1ll << 29)) return NEFII_E_SHAPE;
     if (h_params->training && !minsdf_steps) return NEFII_E_ARG;
     const int levels = h_params->bisect_levels >= 1 && h_params->bisect_levels <= 5 ? h_params->bisect_levels : 3;
     if (h_params->bisect_levels < 0 || h_params->bisect_levels > 5) return NEFII_E_ARG;
@@ -866,9 +874,12 @@ extern "C" int nefii_trace_rays_rounds(const nefii_mlp *h_sdf, const nefii_trace
     if (h_params->precision >= 1)
         for (int l = 0; l < h_sdf->n_layers; ++l)
             if (!h_sdf->layer[l].w_f16x3) return NEFII_E_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int rounds = nefii_trace_max_rounds(h_params);
-    Params P;
+    J.sdf = h_sdf;
+    J.st = (hipStream_t)stream;
+    J.precision = h_params->precision;
+    J.rounds = nefii_trace_max_rounds(h_params);
+    J.counters = counters;
+    Params &P = J.P;
     P.p = *h_params;
     P.n = n_rays;
     P.o = origins;
@@ -883,59 +894,116 @@ extern "C" int nefii_trace_rays_rounds(const nefii_mlp *h_sdf, const nefii_trace
     P.counters = (int *)((char *)workspace + off);
     P.levels = levels;
     P.tri_nodes = (1 << levels) - 1;
-    if (round_end <= 0 || round_end > rounds) round_end = rounds;
-    if (round_begin < 0 || round_begin >= round_end) return NEFII_E_ARG;
-    hipError_t e = hipSuccess;
-    if (round_begin == 0) {      // a continuation (round_begin > 0) keeps the ray state and counters in the workspace
-        e = hipMemsetAsync(P.counters, 0, sizeof(int) * 4 * rounds, st);
+    if (reset) {      // a continuation keeps the ray state and counters in the workspace
+        hipError_t e = hipMemsetAsync(P.counters, 0, sizeof(int) * 4 * J.rounds, J.st);
         if (e != hipSuccess) return (int)e;
-        e = hipMemsetAsync(P.s.flags, 0, sizeof(int) * n_rays, st);
+        e = hipMemsetAsync(P.s.flags, 0, sizeof(int) * n_rays, J.st);
         if (e != hipSuccess) return (int)e;
     }
-    const int adv_blocks = (int)((n_rays + 255) / 256);
+    J.adv_blocks = (int)((n_rays + 255) / 256);
     // eval grid: enough workgroups for the largest possible round, capped at 2 per CU (grid-stride beyond)
-    int64_t max_q = n_rays * (int64_t)h_params->n_steps;      // n_steps >= 2^levels > bisection tree nodes > 2 ends
-    int64_t max_tiles = (max_q + TILE - 1) / TILE;
-    const int eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
-    const bool pipelined = h_params->precision == 2 && fits16p(h_sdf);
+    const int64_t max_q = n_rays * (int64_t)h_params->n_steps;   // n_steps >= 2^levels > bisection tree nodes > 2 ends
+    const int64_t max_tiles = (max_q + TILE - 1) / TILE;
+    J.eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
+    J.pipelined = h_params->precision == 2 && fits16p(h_sdf);
     const int64_t max_tiles_w = (max_q + TILE_W - 1) / TILE_W;
-    const int eval_blocks_w = (int)(max_tiles_w < 512 ? max_tiles_w : 512);
+    J.eval_blocks_w = (int)(max_tiles_w < 512 ? max_tiles_w : 512);
+    return 0;
+}
+
+int launch_round(const TraceJob &J, int r, bool profile) {
+    hipStream_t st = J.st;
+    hipLaunchKernelGGL(advance_kernel, dim3(J.adv_blocks), dim3(256), 0, st, J.P, r);
+    HIP_CHECK_LAUNCH();
+    if (r + 1 < J.rounds) {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profile) {
+            e0 = prof_event();
+            e1 = prof_event();
+            (void)hipEventRecord(e0, st);
+        }
+        if (J.precision == 2 && J.pipelined)
+            hipLaunchKernelGGL(eval_kernel16p<P16W>, dim3(J.eval_blocks_w), dim3(64 * P16W), 0, st, J.P, *J.sdf, r);
+        else if (J.precision == 2)
+            hipLaunchKernelGGL(eval_kernel16w, dim3(J.eval_blocks_w), dim3(WG_W), 0, st, J.P, *J.sdf, r);
+        else if (J.precision == 1)
+            hipLaunchKernelGGL(eval_kernel16, dim3(J.eval_blocks), dim3(WG), 0, st, J.P, *J.sdf, r);
+        else
+            hipLaunchKernelGGL(eval_kernel, dim3(J.eval_blocks), dim3(WG), 0, st, J.P, *J.sdf, r);
+        HIP_CHECK_LAUNCH();
+        if (profile) (void)hipEventRecord(e1, st);
+    }
+    return 0;
+}
+
+int finish_job(const TraceJob &J) {
+    if (J.counters) {
+        hipError_t e = hipMemcpyAsync(J.counters, J.P.counters, sizeof(int) * 4 * J.rounds, hipMemcpyDeviceToDevice, J.st);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+extern "C" int nefii_trace_rays_rounds(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
+                                       const float *origins, const float *dirs, const uint8_t *object_mask,
+                                       int64_t n_rays, const float *lin_steps, const float *minsdf_steps,
+                                       float *out_points, uint8_t *out_hit, float *out_dists, void *workspace,
+                                       size_t workspace_bytes, int32_t *counters, int round_begin, int round_end,
+                                       void *stream) {
+    if (n_rays == 0 && h_sdf && h_params) return 0;
+    TraceJob J;
+    int rc = prepare_job(J, h_sdf, h_params, origins, dirs, object_mask, n_rays, lin_steps, minsdf_steps, out_points,
+                         out_hit, out_dists, workspace, workspace_bytes, counters, round_begin == 0, stream);
+    if (rc) return rc;
+    if (round_end <= 0 || round_end > J.rounds) round_end = J.rounds;
+    if (round_begin < 0 || round_begin >= round_end) return NEFII_E_ARG;
     if (g_prof.on) {
         if (!g_prof.t0) {
             (void)hipEventCreate(&g_prof.t0);
             (void)hipEventCreate(&g_prof.t1);
         }
-        (void)hipEventRecord(g_prof.t0, st);
+        (void)hipEventRecord(g_prof.t0, J.st);
     }
     for (int r = round_begin; r < round_end; ++r) {
-        hipLaunchKernelGGL(advance_kernel, dim3(adv_blocks), dim3(256), 0, st, P, r);
-        HIP_CHECK_LAUNCH();
-        if (r + 1 < rounds) {
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (g_prof.on) {
-                e0 = prof_event();
-                e1 = prof_event();
-                (void)hipEventRecord(e0, st);
-            }
-            if (h_params->precision == 2 && pipelined)
-                hipLaunchKernelGGL(eval_kernel16p<P16W>, dim3(eval_blocks_w), dim3(64 * P16W), 0, st, P, *h_sdf, r);
-            else if (h_params->precision == 2)
-                hipLaunchKernelGGL(eval_kernel16w, dim3(eval_blocks_w), dim3(WG_W), 0, st, P, *h_sdf, r);
-            else if (h_params->precision == 1)
-                hipLaunchKernelGGL(eval_kernel16, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);
-            else
-                hipLaunchKernelGGL(eval_kernel, dim3(eval_blocks), dim3(WG), 0, st, P, *h_sdf, r);
-            HIP_CHECK_LAUNCH();
-            if (g_prof.on) (void)hipEventRecord(e1, st);
-        }
+        rc = launch_round(J, r, g_prof.on);
+        if (rc) return rc;
     }
     if (g_prof.on) {
-        (void)hipEventRecord(g_prof.t1, st);
+        (void)hipEventRecord(g_prof.t1, J.st);
         g_prof.have_span = true;
     }
-    if (counters) {
-        e = hipMemcpyAsync(counters, P.counters, sizeof(int) * 4 * rounds, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return (int)e;
+    return finish_job(J);
+}
+
+extern "C" int nefii_trace_rays_groups(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
+                                       const float *origins, const float *dirs, const uint8_t *object_mask,
+                                       int n_groups, const int64_t *group_begin, const float *lin_steps,
+                                       const float *minsdf_steps, float *out_points, uint8_t *out_hit,
+                                       float *out_dists, void *const *workspaces, const size_t *workspace_bytes,
+                                       int32_t *counters, int round_begin, int round_end, void *const *streams) {
+    if (n_groups < 1 || n_groups > 16 || !group_begin || !workspaces || !workspace_bytes || !streams) return NEFII_E_ARG;
+    if (!h_params) return NEFII_E_ARG;
+    TraceJob J[16];
+    const int rounds = nefii_trace_max_rounds(h_params);
+    if (round_end <= 0 || round_end > rounds) round_end = rounds;
+    if (round_begin < 0 || round_begin >= round_end) return NEFII_E_ARG;
+    for (int g = 0; g < n_groups; ++g) {
+        const int64_t lo = group_begin[g], n = group_begin[g + 1] - lo;
+        if (lo < 0 || n <= 0) return NEFII_E_ARG;
+        int rc = prepare_job(J[g], h_sdf, h_params, origins + 3 * lo, dirs + 3 * lo, object_mask + lo, n, lin_steps,
+                             minsdf_steps, out_points + 3 * lo, out_hit + lo, out_dists + lo, workspaces[g],
+                             workspace_bytes[g], counters ? counters + (size_t)g * rounds * 4 : nullptr,
+                             round_begin == 0, streams[g]);
+        if (rc) return rc;
+    }
+    for (int r = round_begin; r < round_end; ++r)       // round-major: every chunk advances together
+        for (int g = 0; g < n_groups; ++g) {
+            int rc = launch_round(J[g], r, false);
+            if (rc) return rc;
+        }
+    for (int g = 0; g < n_groups; ++g) {
+        int rc = finish_job(J[g]);
+        if (rc) return rc;
     }
     return 0;
 }

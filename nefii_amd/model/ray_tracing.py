@@ -32,6 +32,9 @@ class RayTracing(nn.Module):
         self.bisect_levels = 0          # 0 = automatic: 5 for batches up to 16 k rays (latency-bound), else 3
         self.adaptive_rounds = True     # skip the trailing empty rounds (ops.TraceRounds)
         self._rounds_state = {}
+        # concurrent ray chunks on separate streams (ops.trace_rays): measured on config 2, 1/2/3/4 chunks give
+        # 8.16/8.34/8.37/9.17 ms per step - the dense rounds lose what the latency rounds gain - so the default is 1
+        self.stream_groups = int(os.environ.get('NEFII_TRACER_GROUPS', '0'))
 
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
@@ -80,7 +83,8 @@ class RayTracing(nn.Module):
             state = self._rounds_state.setdefault((self.training, int(math.log2(n_rays + 1))), ops.TraceRounds())
         res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs,
                              object_mask.reshape(-1), self._lin, steps, want_counters=self.collect_counters,
-                             rounds_state=state)
+                             rounds_state=state,
+                             groups=self.stream_groups or 1)
         if self.collect_counters:
             self.last_counters = res[3]
             self.counter_sum = res[3].clone() if self.counter_sum is None else self.counter_sum + res[3]

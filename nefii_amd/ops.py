@@ -267,9 +267,25 @@ class TraceRounds:
         self.guess = None
 
 
+_TRACE_STREAMS = {}
+
+
+def _trace_streams(dev, n):
+    pool = _TRACE_STREAMS.setdefault(dev, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_steps=None, want_counters=False,
-               rounds_state=None):
-    """RayTracing.forward for per-ray origins.  Returns points [n,3], hit (bool [n]), dists [n] (+ counters)."""
+               rounds_state=None, groups=1):
+    """RayTracing.forward for per-ray origins.  Returns points [n,3], hit (bool [n]), dists [n] (+ counters).
+
+    groups > 1: the rays are cut into that many contiguous chunks that run their rounds on separate HIP streams
+    (nefii_trace_rays_groups).  Rays are independent, so the results are bit-identical; the latency-bound rounds of a
+    small batch (fewer 64-query tiles than CUs, one tile time per round regardless) of different chunks then overlap
+    on the chip.  On MI355X the dense rounds lose as much as that gains (RayTracing.stream_groups), so it is off by
+    default."""
     lib = _lib.lib()
     n = origins.shape[0]
     dev = origins.device
@@ -278,31 +294,74 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
     dist = torch.empty(n, device=dev, dtype=torch.float32)
     rounds = lib.nefii_trace_max_rounds(ctypes.byref(params))
     need_cnt = want_counters or rounds_state is not None
-    counters = torch.zeros(rounds, 4, device=dev, dtype=torch.int32) if need_cnt else None
+    groups = max(1, min(int(groups), n // 64)) if n > 0 else 1
+    counters = torch.zeros(groups, rounds, 4, device=dev, dtype=torch.int32) if need_cnt else None
     if n > 0:
-        nbytes = lib.nefii_trace_workspace_bytes(n, ctypes.byref(params))
-        ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         om = object_mask.to(torch.uint8).contiguous()
+        per = -(-n // groups)
+        per = -(-per // 64) * 64
+        bounds = [(g * per, min(n, (g + 1) * per)) for g in range(groups) if g * per < n]
+        cur = torch.cuda.current_stream(dev)
+        streams = [cur] if len(bounds) == 1 else _trace_streams(dev, len(bounds))
+        if len(bounds) > 1:
+            start = cur.record_event()
+        work = []
+        for g, (lo, hi) in enumerate(bounds):
+            with torch.cuda.stream(streams[g]):
+                if len(bounds) > 1:
+                    streams[g].wait_event(start)
+                nbytes = lib.nefii_trace_workspace_bytes(hi - lo, ctypes.byref(params))
+                work.append((torch.empty(nbytes, device=dev, dtype=torch.uint8), nbytes))
 
-        def run(r0, r1):
-            _lib.check(lib.nefii_trace_rays_rounds(ctypes.byref(pm_sdf.struct), ctypes.byref(params), _ptr(origins),
-                                                   _ptr(dirs), _ptr(om), n, _ptr(lin_steps), _ptr(minsdf_steps),
-                                                   _ptr(pts), _ptr(hit), _ptr(dist), _ptr(ws), nbytes, _ptr(counters),
-                                                   r0, r1, _stream()), 'nefii_trace_rays_rounds')
+        G = len(bounds)
+        begin = (ctypes.c_int64 * (G + 1))(*([lo for lo, _ in bounds] + [n]))
+        ws_ptrs = (ctypes.c_void_p * G)(*[w.data_ptr() for w, _ in work])
+        ws_bytes = (ctypes.c_size_t * G)(*[b for _, b in work])
+        st_ptrs = (ctypes.c_void_p * G)(*[st.cuda_stream for st in streams])
+
+        def run(sel, r0, r1):
+            """rounds [r0, r1) of the chunks in `sel`, enqueued round-major by one library call"""
+            if len(sel) == G and G > 1:
+                b_, w_, wb_, s_, c_ = begin, ws_ptrs, ws_bytes, st_ptrs, counters
+                _lib.check(lib.nefii_trace_rays_groups(
+                    ctypes.byref(pm_sdf.struct), ctypes.byref(params), _ptr(origins), _ptr(dirs), _ptr(om), G, b_,
+                    _ptr(lin_steps), _ptr(minsdf_steps), _ptr(pts), _ptr(hit), _ptr(dist), w_, wb_,
+                    _ptr(c_) if c_ is not None else None, r0, r1, s_), 'nefii_trace_rays_groups')
+                return
+            for g in sel:
+                lo, hi = bounds[g]
+                ws, nbytes = work[g]
+                _lib.check(lib.nefii_trace_rays_rounds(
+                    ctypes.byref(pm_sdf.struct), ctypes.byref(params), _ptr(origins[lo:hi]), _ptr(dirs[lo:hi]),
+                    _ptr(om[lo:hi]), hi - lo, _ptr(lin_steps), _ptr(minsdf_steps), _ptr(pts[lo:hi]), _ptr(hit[lo:hi]),
+                    _ptr(dist[lo:hi]), _ptr(ws), nbytes, _ptr(counters[g]) if counters is not None else None,
+                    r0, r1, streams[g].cuda_stream), 'nefii_trace_rays_rounds')
+
+        def join():
+            for st in streams:
+                if st is not cur:
+                    cur.wait_event(st.record_event())
+
+        everyone = list(range(G))
         if rounds_state is None:
-            run(0, 0)
+            run(everyone, 0, 0)
+            join()
         else:
-            g = rounds if rounds_state.guess is None else max(2, min(rounds, rounds_state.guess))
-            run(0, g)
+            guess = rounds if rounds_state.guess is None else max(2, min(rounds, rounds_state.guess))
+            run(everyone, 0, guess)
+            join()
             host = counters.cpu()                            # the one host sync (the caller syncs next anyway)
-            if g < rounds and int(host[g - 1, :3].sum()) > 0:
-                run(g, 0)
-                host = counters.cpu()
-            busy = torch.nonzero(host[:, :3].sum(dim=1)).flatten()
+            if guess < rounds:
+                again = [g for g in everyone if int(host[g, guess - 1, :3].sum()) > 0]
+                if again:
+                    run(again, guess, 0)
+                    join()
+                    host = counters.cpu()
+            busy = torch.nonzero(host[:, :, :3].sum(dim=(0, 2))).flatten()
             last = int(busy[-1]) if busy.numel() else 0
             rounds_state.guess = last + 3                    # last emitting round + its consumer + one spare
     if want_counters:
-        return pts, hit.bool(), dist, counters
+        return pts, hit.bool(), dist, counters.sum(dim=0)
     return pts, hit.bool(), dist
 
 

@@ -462,6 +462,34 @@ def test_tracer_bisection_levels_and_round_ranges_are_bit_identical(levels):
     assert state.guess > 4
 
 
+@pytest.mark.parametrize('hidden,n', [(64, 5000), (512, 4096), (64, 130)])
+@pytest.mark.parametrize('training', [True, False])
+def test_tracer_stream_groups_are_bit_identical(hidden, n, training):
+    """ops.trace_rays(groups=g): ray chunks traced concurrently on separate streams give exactly the single-stream
+    result (rays are independent) and the same total query counters; also with the adaptive round prefix."""
+    from nefii_amd import ops
+    mc = syn.model_conf('physg', hidden=hidden)
+    sd = syn.make_state_dict(mc, seed=2, bumpy=0.03 if hidden == 64 else 0.004)
+    g = torch.Generator().manual_seed(5)
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * (1.2 + 1.5 * torch.rand(n, 1, generator=g))
+    d = torch.randn(n, 3, generator=g) * 0.5 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    om = torch.rand(n, generator=g) < 0.9
+    pm = build_sdf(mc, sd, f16x3=True)
+    tp = ops.make_tracer_params(mc['ray_tracer'], training, 'f16x3w', 5)
+    lin = torch.linspace(0, 1, steps=tp.n_steps).to(DEV)
+    st = torch.rand(tp.n_steps, generator=g).to(DEV)
+    args = (pm, tp, o.to(DEV).contiguous(), d.to(DEV).contiguous(), om.to(DEV), lin, st)
+    ref = ops.trace_rays(*args, want_counters=True)
+    for groups, state in [(4, None), (3, ops.TraceRounds()), (3, None)]:
+        for rep in range(2 if state is not None else 1):        # second call uses the learned round prefix
+            got = ops.trace_rays(*args, want_counters=True, rounds_state=state, groups=groups)
+            for a, b in zip(ref[:3], got[:3]):
+                assert torch.equal(a, b)
+            assert torch.equal(ref[3].sum(dim=0), got[3].sum(dim=0))
+
+
 def test_tracer_large_batch_properties_and_subset_vs_oracle():
     """BASELINE-scale ray count (config 3 traces 262 144 primary rays per call): size-independent properties
     on all rays, and - because the tracer is per-ray - a random subset must equal the oracle tracing just that
