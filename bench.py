@@ -196,6 +196,20 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = rays_per_rank * world / (elapsed / args.steps)
 
+    # side measurement, NOT the headline: the same step without the min-SDF search that is dead work under frozen
+    # geometry (RayTracing.skip_min_sdf_search; same gradients, different mask_loss value)
+    model.ray_tracer.skip_min_sdf_search = True
+    for _ in range(3):
+        step(inp, gt)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(max(args.steps // 2, 1)):
+        step(inp, gt)
+    torch.cuda.synchronize()
+    ms_skip = (time.perf_counter() - t2) / max(args.steps // 2, 1) * 1e3
+    model.ray_tracer.skip_min_sdf_search = False
+    step(inp, gt)
+
     result = None
     if rank == 0:
         # ---- roofline of the dominant kernel: one extra, un-timed step with per-launch HIP events
@@ -253,6 +267,7 @@ def main():
             'metric': 'training rays/sec (Step-2 material opt)', 'value': value, 'unit': 'rays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'graph_priming_steps': priming,
             'ms_per_step': ms_per_step,
+            'ms_per_step_without_dead_min_sdf_search': ms_skip,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f16x3' if model.ray_tracer.precision.startswith('f16x3') else 'f32', 'data': 'synthetic',
             'config': {'workload': '%s: robot-like synthetic scene (geometric-init SDF), %s model, num_pixels=%d per GPU'

@@ -35,6 +35,12 @@ class RayTracing(nn.Module):
         # concurrent ray chunks on separate streams (ops.trace_rays): measured on config 2, 1/2/3/4 chunks give
         # 8.16/8.34/8.37/9.17 ms per step - the dense rounds lose what the latency rounds gain - so the default is 1
         self.stream_groups = int(os.environ.get('NEFII_TRACER_GROUPS', '0'))
+        # Training mode runs minimal_sdf_points (ray_tracing.py:309-337) for the rays that miss: 67 of ~102 SDF evaluations
+        # per primary ray.  With frozen geometry its results reach only `points`/`sdf_output` of miss rays and the VALUE
+        # of mask_loss - no gradient (algorithmically dead).  True drops it (the tracer runs
+        # its eval-mode schedule): same gradients and parameter trajectory, different mask_loss value.  Default False
+        # keeps the reference's outputs.
+        self.skip_min_sdf_search = False
 
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
@@ -63,7 +69,8 @@ class RayTracing(nn.Module):
         if self._lin is None or self._lin.device != dev or self._lin.numel() != self.n_steps:
             self._lin = torch.linspace(0, 1, steps=self.n_steps).to(dev)     # ray_tracing.py:203
         steps = None
-        if self.training:
+        training = self.training and not self.skip_min_sdf_search
+        if training:
             if self.minsdf_steps_override is not None:
                 ov = self.minsdf_steps_override
                 if isinstance(ov, (list, tuple)):      # one entry per trace call (primary, secondary, ...)
@@ -76,11 +83,11 @@ class RayTracing(nn.Module):
                 steps = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
         n_rays = dirs.shape[0]
         levels = self.bisect_levels or (5 if n_rays <= 16384 else 3)
-        params = ops.make_tracer_params(self._cfg(), self.training, self.precision, levels)
+        params = ops.make_tracer_params(self._cfg(), training, self.precision, levels)
         state = None
         if self.adaptive_rounds:      # one guess per (mode, batch size): primary and secondary traces differ
             import math
-            state = self._rounds_state.setdefault((self.training, int(math.log2(n_rays + 1))), ops.TraceRounds())
+            state = self._rounds_state.setdefault((training, int(math.log2(n_rays + 1))), ops.TraceRounds())
         res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs,
                              object_mask.reshape(-1), self._lin, steps, want_counters=self.collect_counters,
                              rounds_state=state,

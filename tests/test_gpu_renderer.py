@@ -340,3 +340,34 @@ def test_batch_of_two_cameras_and_no_hits():
     ref = orr.Renderer({k: v.clone() for k, v in sd.items()}, mc, training=False).forward(away, None)
     assert (out['points'].cpu() - ref['points']).abs().max().item() < 1e-5
     assert not out['network_object_mask'].any()
+
+
+def test_skip_min_sdf_search_keeps_gradients():
+    """RayTracing.skip_min_sdf_search: dropping the training-mode min-SDF search under frozen geometry changes `points`
+    / `sdf_output` of miss rays and the value of mask_loss, and nothing that carries gradient."""
+    from nefii_amd.model.loss import IDRLoss
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=6, bumpy=0.02)
+    lc = syn.loss_conf('physg')
+    lc['idr_rgb_weight'] = 1.0
+    inp, gt = syn.make_inputs(512, (64, 64), 100.0, (0.2, 0.1, 2.0), -1, seed=2)
+    res = []
+    for skip in (False, True):
+        m = build_model(mc, sd, True)
+        m.ray_tracer.skip_min_sdf_search = skip
+        out = m(to_dev(inp))
+        lo = IDRLoss(**lc)(out, {'rgb': gt.to(DEV)})
+        lo['loss'].backward()
+        res.append((out, lo, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    (o0, l0, g0), (o1, l1, g1) = res
+    assert torch.equal(o0['network_object_mask'], o1['network_object_mask'])
+    for k in ('sg_rgb_values', 'idr_rgb_values', 'normal_values', 'sg_diffuse_albedo_values'):
+        assert torch.equal(o0[k], o1[k]), k
+    hit = o0['network_object_mask']
+    assert torch.equal(o0['points'][hit], o1['points'][hit])
+    assert not torch.equal(o0['points'][~hit], o1['points'][~hit])
+    for k in ('sg_rgb_loss', 'idr_rgb_loss'):
+        assert l0[k].item() == l1[k].item()
+    assert set(g0) == set(g1)
+    for n in g0:
+        assert rel_l2(g1[n], g0[n]) < 1e-5, n
