@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 2
+#define NEFII_ABI_VERSION 3
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -51,6 +51,8 @@ typedef struct nefii_layer {
     const float *bias;       /* [n_pad] */
     const void *w_f16x3;     /* optional: fp16 hi/lo split of w_fwd * 64 in 32x32x16 fragment order
                                 [ (k_x+k_e)/16 ][ n_pad/32 ][ hi | lo ][64 lanes][8 halves]  (nefii_pack_linear_f16x3) */
+    const void *w_bwd_f16x3; /* optional: the transposed fragments of the same split for input-gradient GEMMs
+                                [ n_pad/16 ][ (k_x+k_e)/32 ][ hi | lo ][64 lanes][8 halves]  (nefii_pack_linear_f16x3_bwd) */
 } nefii_layer;
 
 typedef struct nefii_mlp {
@@ -147,6 +149,11 @@ typedef struct nefii_tracer_params {
  * nefii_pack_sdf_stream: device-side copy from the layers' w_f16x3 (call after nefii_pack_linear_f16x3). */
 size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf);
 int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, void *stream);
+
+/* Transposed counterpart for the split-precision input-gradient GEMMs (nefii_sdf_value_grad picks its split-precision
+ * kernel when every layer carries both w_f16x3 and w_bwd_f16x3). */
+int nefii_pack_linear_f16x3_bwd(const float *W, int n_out, int k_in, int x_src0, int x_len, int e_src0, int e_len,
+                                float scale, void *w_bwd_f16x3, void *stream);
 
 /* sdf_out[i] = implicit_network(x[i])[:, 0] (implicit_differentiable_renderer.py:85-108) with the tracer's
  * split-precision tile evaluator (the arithmetic of precision 2): the bulk SDF query the reference issues from

@@ -14,7 +14,7 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
 HEAD_NONE, HEAD_TANH01, HEAD_POW2, HEAD_SIGMOID, HEAD_RELU, HEAD_ABS, HEAD_RELU_INIT = range(7)
@@ -25,7 +25,7 @@ c_float_p = ctypes.c_void_p     # device pointers travel as integers
 class Layer(ctypes.Structure):
     _fields_ = [('k_x', ctypes.c_int32), ('k_e', ctypes.c_int32), ('n_out', ctypes.c_int32),
                 ('n_pad', ctypes.c_int32), ('w_fwd', ctypes.c_void_p), ('w_bwd', ctypes.c_void_p),
-                ('bias', ctypes.c_void_p), ('w_f16x3', ctypes.c_void_p)]
+                ('bias', ctypes.c_void_p), ('w_f16x3', ctypes.c_void_p), ('w_bwd_f16x3', ctypes.c_void_p)]
 
 
 class Mlp(ctypes.Structure):
@@ -53,6 +53,7 @@ SIGNATURES = {
     'nefii_padded_width': (I, [I]),
     'nefii_pack_linear': (I, [P, P, I, I, I, I, I, I, F, P, P, P, P]),
     'nefii_pack_linear_f16x3': (I, [P, I, I, I, I, I, I, F, P, P]),
+    'nefii_pack_linear_f16x3_bwd': (I, [P, I, I, I, I, I, I, F, P, P]),
     'nefii_mlp_forward': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P]),
     'nefii_mlp_backward': (I, [ctypes.POINTER(Mlp), P, I, P, I, I64, P, I, P]),
     'nefii_mlp_wgrad': (I, [P, I, P, I, I64, I, I, F, P, P, P]),

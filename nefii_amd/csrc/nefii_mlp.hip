@@ -105,6 +105,46 @@ extern "C" int nefii_pack_linear_f16x3(const float *W, int n_out, int k_in, int 
     return 0;
 }
 
+// transposed fragments for input-gradient GEMMs (dX = dZ * W): contraction over the outputs n, output column kk of the
+// [X | E] input space.  half8 index ((s*KT + t)*2 + part)*64 + lane, element j:
+// W[n = 16s + 8(lane>>5) + j][src_col(kk = 32t + (lane&31))] * scale * 64
+__global__ void pack_linear_f16x3_bwd_kernel(const float *__restrict__ W, int n_out, int k_in, int kx, int ke, int n_pad,
+                                             int x_src0, int x_len, int e_src0, int e_len, float scale,
+                                             _Float16 *__restrict__ out) {
+    const int KT = (kx + ke) >> 5;
+    const int total = (n_pad >> 4) * KT * 64;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, blk = idx >> 6;
+        const int t = blk % KT, st = blk / KT;
+        const int kk = 32 * t + (lane & 31);
+        const int c = src_col(kk, kx, x_src0, x_len, e_src0, e_len);
+        _Float16 *hi = out + (((size_t)blk * 2) * 64 + lane) * 8;
+        _Float16 *lo = out + (((size_t)blk * 2 + 1) * 64 + lane) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int nn = 16 * st + 8 * (lane >> 5) + j;
+            const float w = (nn < n_out && c >= 0) ? W[(size_t)nn * k_in + c] * scale * W16_SCALE : 0.f;
+            split16(w, hi[j], lo[j]);
+        }
+    }
+}
+
+extern "C" int nefii_pack_linear_f16x3_bwd(const float *W, int n_out, int k_in, int x_src0, int x_len, int e_src0,
+                                           int e_len, float scale, void *w_bwd_f16x3, void *stream) {
+    if (!W || !w_bwd_f16x3 || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
+    const int kx = pad_hidden(x_len), ke = round32(e_len), n_pad = pad_hidden(n_out);
+    if (n_pad > NEFII_MAX_WIDTH || kx > NEFII_MAX_WIDTH || ke > NEFII_MAX_ENC || kx + ke == 0) return NEFII_E_SHAPE;
+    if (x_src0 + x_len > k_in || e_src0 + e_len > k_in) return NEFII_E_SHAPE;
+    // n_pad is 32 for the one-output last layer: its 16-deep k-steps still come in pairs
+    const int total = (n_pad >> 4) * ((kx + ke) >> 5) * 64;
+    int blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pack_linear_f16x3_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, n_out, k_in, kx,
+                       ke, n_pad, x_src0, x_len, e_src0, e_len, scale, (_Float16 *)w_bwd_f16x3);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // shared prologue: stage raw inputs + features of one 32-point tile, encode into E
 // ------------------------------------------------------------------------------------------------
@@ -513,6 +553,111 @@ __global__ __launch_bounds__(256, 1) void sdf_value_grad_kernel(nefii_mlp m, con
     }
 }
 
+// Split-precision variant (3 x fp16 MFMA per k-step, mlp_tile.h): the f32-input MFMA bounds the kernel above (52 % of
+// its 157 TF at one tile per CU); on fp16 hi/lo operand pairs the same tile is bound by its weight stream instead.
+__global__ __launch_bounds__(256, 1) void sdf_value_grad16_kernel(nefii_mlp m, const float *__restrict__ x, int64_t n,
+                                                                  float *__restrict__ sdf_out, int out_stride,
+                                                                  float *__restrict__ feat_out, int feat_stride,
+                                                                  float *__restrict__ grad_out, float *__restrict__ ws,
+                                                                  int ws_stride) {
+    __shared__ Lds16 lds;
+    __shared__ float GE[TILE * ES];
+    __shared__ float raw[TILE * 9];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int Lm1 = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * TILE;
+        for (int i = tid; i < TILE * 9; i += WG) {
+            const int p = i / 9, c = i - 9 * p;
+            int64_t idx = base + p;
+            if (idx >= n) idx = n - 1;
+            raw[i] = c < 3 ? x[idx * 3 + c] : 0.f;
+        }
+        for (int i = tid; i < TILE * ES; i += WG) GE[i] = 0.f;
+        __syncthreads();
+        encode_tile16(m, raw, lds, ke);
+        __syncthreads();
+        // ---- forward
+        for (int l = 0; l <= Lm1; ++l) {
+            const nefii_layer &L = m.layer[l];
+            f32x16 acc[4];
+            int ntw;
+            layer_gemm16(L, lds, L.n_pad >> 5, acc, ntw);
+            __syncthreads();
+            NEFII_FOR_ACC(acc, ntw, {
+                const float z = val * inv_scale + L.bias[col];
+                const bool live = (base + row) < n;
+                if (l < Lm1) {
+                    const float hval = act_fwd(z, m.act);
+                    split16a(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                    if (live) ws[((size_t)l * n + base + row) * ws_stride + col] = hval;
+                    if (l == Lm1 - 1 && feat_out && live && col < L.n_out)
+                        feat_out[(size_t)(base + row) * feat_stride + col] = hval;
+                } else {
+                    if (live && col < L.n_out) sdf_out[(size_t)(base + row) * out_stride + col] = z;
+                    split16a(col == 0 ? 1.f : 0.f, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);   // seed
+                }
+            })
+            __syncthreads();
+        }
+        // ---- backward to the encoded input
+        for (int l = Lm1; l >= 0; --l) {
+            const nefii_layer &L = m.layer[l];
+            const int NTs = (L.k_x + L.k_e) >> 5;
+            const half8 *wb = reinterpret_cast<const half8 *>(L.w_bwd_f16x3);
+            f32x16 acc[4];
+            if (NTs > 16) {     // input tiles past the 16 the accumulators hold are encoding columns: GE only
+                int ntb = (NTs - 16 - wave + 3) >> 2;
+                if (ntb < 0) ntb = 0;
+                zero_acc(acc);
+                gemm_block16(lds.Xh, lds.Xl, XS16, L.n_pad >> 4, wb + 16 * 2 * 64, NTs, wave, lane, ntb, acc);
+                NEFII_FOR_ACC(acc, ntb, { GE[row * ES + (col + 512 - L.k_x)] += val * inv_scale; })
+            }
+            int ntw = ((NTs < 16 ? NTs : 16) - wave + 3) >> 2;
+            if (ntw < 0) ntw = 0;
+            zero_acc(acc);
+            gemm_block16(lds.Xh, lds.Xl, XS16, L.n_pad >> 4, wb, NTs, wave, lane, ntw, acc);
+            __syncthreads();
+            NEFII_FOR_ACC(acc, ntw, {
+                const float g = val * inv_scale;
+                if (col < L.k_x) {
+                    const bool live = (base + row) < n;
+                    float v = 0.f;
+                    if (live && l > 0) {
+                        const float hprev = ws[((size_t)(l - 1) * n + base + row) * ws_stride + col];
+                        v = g * act_bwd_from_out(hprev, m.act);
+                    }
+                    split16a(v, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                } else {
+                    GE[row * ES + (col - L.k_x)] += g;
+                }
+            })
+            __syncthreads();
+        }
+        // ---- chain through the positional encoding
+        if (tid < TILE * 3) {
+            const int p = tid / 3, c = tid - 3 * p;
+            if (base + p < n) {
+                const float *v = raw + p * 9;
+                const int w0 = enc_width(m.enc_freqs[0]);
+                float g = 0.f;
+                for (int col = 0; col < w0; ++col) {
+                    int comp;
+                    const float d = enc_deriv(v, col, comp);
+                    if (comp == c) g += GE[p * ES + col] * d;
+                }
+                grad_out[(size_t)(base + p) * 3 + c] = g;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static int sdf_ws_stride(const nefii_mlp *m) {
     int s = 32;
     for (int l = 0; l < m->n_layers - 1; ++l) s = m->layer[l].n_pad > s ? m->layer[l].n_pad : s;
@@ -532,9 +677,19 @@ extern "C" int nefii_sdf_value_grad(const nefii_mlp *h_mlp, const float *x, int6
     if (!x || !sdf_out || !grad_out || !ws) return NEFII_E_ARG;
     if (h_mlp->enc_freqs[0] < 0 || h_mlp->enc_freqs[1] >= 0 || h_mlp->enc_freqs[2] >= 0 || h_mlp->feat_width != 0)
         return NEFII_E_UNSUPPORTED;
+    bool split = true;
+    for (int l = 0; l < h_mlp->n_layers; ++l)
+        split = split && h_mlp->layer[l].w_f16x3 && h_mlp->layer[l].w_bwd_f16x3;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    if (split) {        // both fp16 hi/lo fragment sets present: the split-precision kernel
+        hipLaunchKernelGGL(sdf_value_grad16_kernel, dim3(grid_for(n_tiles, 1)), dim3(WG), 0, (hipStream_t)stream,
+                           *h_mlp, x, n, sdf_out, out_stride, feat_out, feat_stride, grad_out, ws,
+                           sdf_ws_stride(h_mlp));
+        HIP_CHECK_LAUNCH();
+        return 0;
+    }
     for (int l = 0; l < h_mlp->n_layers; ++l)
         if (!h_mlp->layer[l].w_bwd) return NEFII_E_ARG;
-    const int64_t n_tiles = (n + TILE - 1) / TILE;
     hipLaunchKernelGGL(sdf_value_grad_kernel, dim3(grid_for(n_tiles, 1)), dim3(WG), 0, (hipStream_t)stream, *h_mlp, x,
                        n, sdf_out, out_stride, feat_out, feat_stride, grad_out, ws, sdf_ws_stride(h_mlp));
     HIP_CHECK_LAUNCH();

@@ -63,7 +63,7 @@ class PackedMLP:
         self.feat_width = feat_width
         self.device = device
         self.need_bwd = need_bwd
-        self.w_fwd, self.w_bwd, self.bias, self.w_f16 = [], [], [], []
+        self.w_fwd, self.w_bwd, self.bias, self.w_f16, self.w_f16b = [], [], [], [], []
         self.f16x3 = f16x3
         m = Mlp()
         m.n_layers, m.act, m.head, m.feat_width = len(specs), act, head, feat_width
@@ -75,12 +75,15 @@ class PackedMLP:
             self.w_bwd.append(torch.zeros(k * s.n_pad, device=device, dtype=torch.float32) if need_bwd else None)
             self.bias.append(torch.zeros(s.n_pad, device=device, dtype=torch.float32))
             self.w_f16.append(torch.zeros(2 * k * s.n_pad, device=device, dtype=torch.float16) if f16x3 else None)
+            self.w_f16b.append(torch.zeros(2 * k * s.n_pad, device=device, dtype=torch.float16)
+                               if f16x3 and need_bwd else None)
             L = m.layer[l]
             L.k_x, L.k_e, L.n_out, L.n_pad = s.k_x, s.k_e, s.n_out, s.n_pad
             L.w_fwd = self.w_fwd[l].data_ptr()
             L.w_bwd = self.w_bwd[l].data_ptr() if need_bwd else None
             L.bias = self.bias[l].data_ptr()
             L.w_f16x3 = self.w_f16[l].data_ptr() if f16x3 else None
+            L.w_bwd_f16x3 = self.w_f16b[l].data_ptr() if self.w_f16b[l] is not None else None
         self.struct = m
         # SDF nets of the qualifying shape also keep their hidden layers as one fragment stream per wave (the
         # pipelined tile evaluator of the tracer); other nets leave w_stream NULL and run on the generic kernel
@@ -116,6 +119,10 @@ class PackedMLP:
             if self.f16x3:
                 _lib.check(lib.nefii_pack_linear_f16x3(_ptr(w), s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0, s.e_len,
                                                        s.scale, _ptr(self.w_f16[l]), st), 'nefii_pack_linear_f16x3')
+                if self.w_f16b[l] is not None:
+                    _lib.check(lib.nefii_pack_linear_f16x3_bwd(_ptr(w), s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0,
+                                                               s.e_len, s.scale, _ptr(self.w_f16b[l]), st),
+                               'nefii_pack_linear_f16x3_bwd')
         if self.w_stream is not None:
             _lib.check(lib.nefii_pack_sdf_stream(ctypes.byref(self.struct), _ptr(self.w_stream), st),
                        'nefii_pack_sdf_stream')

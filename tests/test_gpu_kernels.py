@@ -64,8 +64,9 @@ def test_sdf_forward_and_gradient(name, hidden, n):
     assert rel_l2(feat, hid) < 1e-7
 
 
-@pytest.mark.parametrize('name,hidden,n', [('physg', 64, 200), ('conf', 512, 1000), ('physg', 512, 77)])
-def test_sdf_gradient_trained_like_skip_weights(name, hidden, n):
+@pytest.mark.parametrize('split', [False, True])
+@pytest.mark.parametrize('name,hidden,n', [('physg', 64, 200), ('conf', 512, 1000), ('physg', 512, 77), ('neus', None, 300)])
+def test_sdf_gradient_trained_like_skip_weights(name, hidden, n, split):
     """Geometric init zeroes the skip layer's sin/cos columns (implicit_differentiable_renderer.py:70-71); a trained
     checkpoint does not.  With every skip-layer input column live the 512-wide net has 17 input tiles at the skip."""
     from nefii_amd import ops
@@ -75,13 +76,16 @@ def test_sdf_gradient_trained_like_skip_weights(name, hidden, n):
     for l in mc['implicit_network']['skip_in']:
         w = sd['implicit_network.lin%d.weight_v' % l]
         w[:, -36:] = torch.randn(w.shape[0], 36, generator=g) * 0.02
-    pm = build_sdf(mc, sd)
+    pm = build_sdf(mc, sd, f16x3=split)       # split: the fp16 hi/lo kernel (sdf_value_grad16_kernel)
     x = ball_points(n, 3)
-    ref = nets.sdf_forward(sd, mc['implicit_network'], x)
-    gref = nets.sdf_gradient(sd, mc['implicit_network'], x)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref = nets.sdf_forward(sd64, mc['implicit_network'], x.double())
+    gref = nets.sdf_gradient(sd64, mc['implicit_network'], x.double())
     out, feat, grad = ops.sdf_value_grad(pm, x.to(DEV), want_feat=True)
-    assert rel_l2(out, ref[:, :1]) < 1e-5
+    assert (out[:, 0].cpu().double() - ref[:, 0]).abs().max().item() < 5e-6
     assert rel_l2(grad, gref) < 2e-5
+    if feat is not None and mc['implicit_network'].get('use_last_as_f'):
+        assert rel_l2(feat, ref[:, 1:]) < 1e-5
 
 
 @pytest.mark.parametrize('name,hidden,n', [('physg', 512, 1), ('physg', 512, 64), ('conf', 512, 1000), ('neus', None, 333),

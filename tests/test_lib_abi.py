@@ -30,7 +30,7 @@ def test_library_builds_loads_and_exports_header_symbols():
 def test_struct_layout_matches_header():
     from nefii_amd import _lib
     # nefii_layer: 4 x int32 + 4 pointers; nefii_mlp: 8 x int32 + 12 layers
-    assert ctypes.sizeof(_lib.Layer) == 16 + 4 * 8
+    assert ctypes.sizeof(_lib.Layer) == 16 + 5 * 8
     assert ctypes.sizeof(_lib.Mlp) == 40 + 12 * ctypes.sizeof(_lib.Layer)
     assert ctypes.sizeof(_lib.TracerParams) == 40
 
