@@ -706,16 +706,16 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
             pgemm<NW, (NB == 8 ? 4 : 0)>(ks, b, a, cur, ah, al, acc);
         ph = (ph + ks) % NB;
         NEFII_STAMP(1);
-        __syncthreads();
-        NEFII_STAMP(2);
-        // epilogue: activation, hi/lo split, four halves of one row per store (transposed accumulator, see mfma16w)
-        _Float16 *xh = lds.Xh + (EP16 - L.n_pad), *xl = lds.Xl + (EP16 - L.n_pad);
+        // epilogue, arithmetic first: activation and hi/lo split of the wave's 64 x 64 block, packed in registers (the
+        // accumulators' own count).  It needs nothing the other waves still read, so it runs BEFORE the barrier: the
+        // SIMD partner that lost the matrix pipe arbitration is still in its k-loop then (MFMA beside VALU), see
+        // tools/stamps.py.  Only the stores into the activation image wait for everyone to be done reading it.
+        half4 phi[NC * 4 * 2], plo[NC * 4 * 2];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int bsrc = __builtin_bit_cast(int, bvec[c >> 1] * A16_SCALE);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int f0 = 32 * (NC * wave + c) + 8 * g + 4 * h;
                 float4v bs;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -723,7 +723,6 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
                         float, __builtin_amdgcn_ds_bpermute(4 * (32 * (c & 1) + 8 * g + 4 * h + k), bsrc));
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    const int query = 32 * rt + r;
                     const f32x16 &av = acc[rt * NC + c];
                     float4v hs;
 #pragma unroll
@@ -733,12 +732,27 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
                                                                : act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
                     }
                     const half4 hi = __builtin_convertvector(hs, half4);
-                    const half4 lo = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
-                    *reinterpret_cast<half4 *>(xh + query * XP16 + f0) = hi;
-                    *reinterpret_cast<half4 *>(xl + query * XP16 + f0) = lo;
+                    phi[(c * 4 + g) * 2 + rt] = hi;
+                    plo[(c * 4 + g) * 2 + rt] =
+                        __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
                 }
             }
         }
+        __syncthreads();
+        NEFII_STAMP(2);
+        _Float16 *xh = lds.Xh + (EP16 - L.n_pad), *xl = lds.Xl + (EP16 - L.n_pad);
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int f0 = 32 * (NC * wave + c) + 8 * g + 4 * h;
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    const int query = 32 * rt + r;
+                    *reinterpret_cast<half4 *>(xh + query * XP16 + f0) = phi[(c * 4 + g) * 2 + rt];
+                    *reinterpret_cast<half4 *>(xl + query * XP16 + f0) = plo[(c * 4 + g) * 2 + rt];
+                }
+            }
         NEFII_STAMP(3);
         __syncthreads();
         NEFII_STAMP(4);
