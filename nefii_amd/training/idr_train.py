@@ -1,0 +1,219 @@
+"""IDRTrainRunner: the Step-2 training loop around the hot path, with the reference runner's constructor keywords,
+experiment-directory layout and checkpoint format (code/training/idr_train.py:22-372, 612-802), so that a reference
+checkpoint continues here and vice versa:
+
+    <exps_folder>/<expname>/<timestamp>/checkpoints/{ModelParameters, IDROptimizerParameters, IDRSchedulerParameters,
+        SGOptimizerParameters, SGSchedulerParameters}/{<epoch>, latest}.pth
+    with {"epoch", "model_state_dict"} / {"epoch", "optimizer_state_dict"} / {"epoch", "scheduler_state_dict"}.
+
+One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the launcher; the reference's --local_rank also works); the
+per-iteration work is training/step.py:TrainStep (forward, IDRLoss, backward, gradient all-reduce, 2x Adam, 2x
+MultiStepLR, alpha milestones, roughness/specular warm-up, secondary-consistency step).  Not built: tensorboard
+logging, plots (vis_train/vis_test/plot_to_disk), camera optimisation, the view-diff pixel pairing - the reference's
+image stack is not installed and none of it is on the hot path."""
+import os
+import sys
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import conf as hocon
+from ..utils import general as utils
+from .step import TrainStep
+
+SUBDIRS = {'model': 'ModelParameters', 'idr_opt': 'IDROptimizerParameters', 'idr_sched': 'IDRSchedulerParameters',
+           'sg_opt': 'SGOptimizerParameters', 'sg_sched': 'SGSchedulerParameters'}
+
+
+class IDRTrainRunner:
+    def __init__(self, **kwargs):
+        torch.set_default_dtype(torch.float32)
+        self.local_rank = kwargs.get('local_rank', int(os.environ.get('LOCAL_RANK', -1)) if 'RANK' in os.environ else -1)
+        self.multiprocessing = self.local_rank > -1
+        if self.multiprocessing:
+            torch.cuda.set_device(self.local_rank)
+            if not dist.is_initialized():
+                dist.init_process_group(backend=kwargs.get('dist_backend', 'nccl'))      # RCCL on ROCm
+            self.device = torch.device('cuda', self.local_rank)
+            self.world_size = dist.get_world_size()
+        else:
+            self.device = torch.device('cuda')
+            self.world_size = 1
+        self.rank = dist.get_rank() if self.multiprocessing else 0
+        c = kwargs['conf']
+        self.conf = c if isinstance(c, hocon.ConfigTree) else hocon.parse_file(c)
+        self.batch_size = kwargs.get('batch_size', 1)
+        self.nepochs = kwargs.get('nepochs', 2000)
+        self.max_niters = kwargs.get('max_niters', 200001)
+        self.exps_folder_name = kwargs.get('exps_folder_name', 'exps')
+        self.expname = kwargs.get('expname', 'default')
+        self.freeze_geometry = kwargs.get('freeze_geometry', False)
+        self.freeze_idr = kwargs.get('freeze_idr', False)
+        self.freeze_decompose_render = kwargs.get('freeze_decompose_render', False)
+        self.freeze_light = kwargs.get('freeze_light', False)
+        self.freeze_diffuse = kwargs.get('freeze_diffuse', False)
+        self.ckpt_freq = kwargs.get('ckpt_freq', self.conf.get_int('train.ckpt_freq', default=5000))
+        self.log_freq = kwargs.get('log_freq', 50)
+        if kwargs.get('train_cameras', False):
+            raise NotImplementedError('camera optimisation is outside the Step-2 hot path')
+
+        is_continue, timestamp = kwargs.get('is_continue', False), kwargs.get('timestamp', 'latest')
+        self.expdir = os.path.join(self.exps_folder_name, self.expname)
+        if is_continue and timestamp == 'latest':                                  # idr_train.py:76-92
+            old = str(kwargs.get('old_expdir') or '') or self.expdir
+            stamps = sorted(s for s in os.listdir(old) if '.' not in s) if os.path.exists(old) else []
+            is_continue, timestamp = (True, stamps[-1]) if stamps else (False, None)
+        if self.rank == 0:
+            self.timestamp = kwargs.get('new_timestamp') or '{:%Y_%m_%d_%H_%M_%S}'.format(datetime.now())
+            self.checkpoints_path = os.path.join(self.expdir, self.timestamp, 'checkpoints')
+            for sub in SUBDIRS.values():
+                os.makedirs(os.path.join(self.checkpoints_path, sub), exist_ok=True)
+            if not isinstance(c, hocon.ConfigTree):
+                with open(c) as f, open(os.path.join(self.expdir, self.timestamp, 'runconf.conf'), 'w') as g:
+                    g.write(f.read())
+            with open(os.path.join(self.expdir, self.timestamp, 'runcmd.txt'), 'w') as f:
+                f.write('shell command : {0}'.format(' '.join(sys.argv)))
+
+        ds_cls = kwargs.get('dataset_class') or self.conf.get_string('train.dataset_class')
+        self.train_dataset = utils.get_class(ds_cls)(kwargs.get('gamma', 1.0), kwargs.get('data_split_dir', ''), False,
+                                                     kwargs.get('subsample', 1), wo_mask=kwargs.get('wo_mask', False),
+                                                     **kwargs.get('dataset_kwargs', {}))
+        self.train_sampler_generator = torch.Generator()
+        sampler = torch.utils.data.RandomSampler(self.train_dataset, generator=self.train_sampler_generator)
+        self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size,
+                                                            collate_fn=self.train_dataset.collate_fn, sampler=sampler)
+        self.n_batches = len(self.train_dataloader)
+
+        model_cls = kwargs.get('model_class') or self.conf.get_string('train.model_class')
+        self.model = utils.get_class(model_cls)(conf=self.conf.get_config('model')).to(self.device)
+        for key, part in (('pretrain_geometry_path', ('implicit_network',)),         # idr_train.py:205-244
+                          ('pretrain_idr_rendering_path', ('rendering_network',)),
+                          ('pretrain_diffuse_path', ('envmap_material_network', 'diffuse_albedo_layers'))):
+            path = kwargs.get(key)
+            if path and os.path.exists(path):
+                sd = torch.load(path, map_location=self.device)['model_state_dict']
+                sd = {k: v for k, v in sd.items() if tuple(k.split('.')[:len(part)]) == part}
+                full = self.model.state_dict()
+                full.update(sd)
+                self.model.load_state_dict(full)
+        if kwargs.get('light_sg_path') and os.path.exists(kwargs['light_sg_path']):
+            self.model.envmap_material_network.load_light(kwargs['light_sg_path'])
+        if str(kwargs.get('geometry_neus', '')).endswith('.pth'):                   # idr_train.py:303-306
+            self.model.implicit_network.load_state_dict(
+                torch.load(kwargs['geometry_neus'], map_location=self.device)['sdf_network_fine'])
+
+        self.start_epoch = 0
+        saved = {}
+        if is_continue:
+            old = os.path.join(str(kwargs.get('old_expdir') or '') or self.expdir, timestamp, 'checkpoints')
+            ck = str(kwargs.get('checkpoint', 'latest')) + '.pth'
+            saved = {k: torch.load(os.path.join(old, sub, ck), map_location=self.device) for k, sub in SUBDIRS.items()}
+            self.model.load_state_dict(saved['model']['model_state_dict'])
+            self.start_epoch = saved['model']['epoch']
+
+        self.num_pixels = self.conf.get_int('train.num_pixels')
+        self.num_rays = self.conf.get_int('train.num_rays', default=-1)
+        if self.freeze_idr:                                                         # idr_train.py:620-638
+            self.model.freeze_idr()
+        elif self.freeze_geometry:
+            self.model.freeze_geometry()
+        if self.freeze_decompose_render:
+            self.model.freeze_decompose_render()
+        if self.freeze_light:
+            self.model.envmap_material_network.freeze_light()
+        if self.freeze_diffuse:
+            self.model.envmap_material_network.freeze_diffuse()
+        self.model.train()
+
+        t = self.conf.get_config('train')
+        self.step = TrainStep(
+            self.model, dict(self.conf.get_config('loss')), idr_lr=t.get_float('idr_learning_rate'),
+            sg_lr=t.get_float('sg_learning_rate'), world_size=self.world_size,
+            secondary_train_interval=kwargs.get('secondary_train_interval', 0),
+            secondary_batch_size=kwargs.get('secondary_batch_size', 1024), num_rays=self.num_rays,
+            graph=kwargs.get('graph', True),
+            idr_sched_milestones=t.get_list('idr_sched_milestones', default=[]),
+            idr_sched_factor=t.get_float('idr_sched_factor', default=0.0),
+            sg_sched_milestones=t.get_list('sg_sched_milestones', default=[]),
+            sg_sched_factor=t.get_float('sg_sched_factor', default=0.0),
+            alpha_milestones=t.get_list('alpha_milestones', default=[]), alpha_factor=t.get_float('alpha_factor', default=0.0),
+            roughness_warmup=kwargs.get('roughness_warmup', -1), specular_warmup=kwargs.get('specular_warmup', -1),
+            start_iter=self.start_epoch * self.n_batches)
+        self.loss = self.step.loss
+        if saved:
+            self.step.idr_optimizer.load_state_dict(saved['idr_opt']['optimizer_state_dict'])
+            self.step.idr_scheduler.load_state_dict(saved['idr_sched']['scheduler_state_dict'])
+            self.step.sg_optimizer.load_state_dict(saved['sg_opt']['optimizer_state_dict'])
+            self.step.sg_scheduler.load_state_dict(saved['sg_sched']['scheduler_state_dict'])
+            self.step.retensor_lr()
+        self.history = []
+
+    # ---- idr_train.py:329-372
+    def save_checkpoints(self, epoch):
+        if self.rank != 0:
+            return
+        st = self.step
+        payload = {'model': {'epoch': epoch, 'model_state_dict': self.model.state_dict()},
+                   'idr_opt': {'epoch': epoch, 'optimizer_state_dict': st.portable_state_dict(st.idr_optimizer)},
+                   'idr_sched': {'epoch': epoch, 'scheduler_state_dict': st.idr_scheduler.state_dict()},
+                   'sg_opt': {'epoch': epoch, 'optimizer_state_dict': st.portable_state_dict(st.sg_optimizer)},
+                   'sg_sched': {'epoch': epoch, 'scheduler_state_dict': st.sg_scheduler.state_dict()}}
+        for key, sub in SUBDIRS.items():
+            for name in (str(epoch), 'latest'):
+                torch.save(payload[key], os.path.join(self.checkpoints_path, sub, name + '.pth'))
+
+    def _resample(self):
+        r = self.loss.r_patch
+        ds = self.train_dataset
+        if r < 1:                                                                   # idr_train.py:641-645
+            ds.change_sampling_idx(self.num_pixels)
+            if self.multiprocessing:
+                sub = ds.sampling_idx.shape[0] // self.world_size
+                last = self.rank == self.world_size - 1
+                ds.sampling_idx = ds.sampling_idx[self.rank * sub:] if last else \
+                    ds.sampling_idx[self.rank * sub: (self.rank + 1) * sub]
+        else:                                                                       # :646-656
+            n_patch = self.num_pixels // (4 * r * r)
+            ds.change_sampling_idx_patch(n_patch, r)
+            if self.multiprocessing:
+                ds.scatter_sampling_idx_patch(self.rank, self.world_size, n_patch, r)
+
+    # ---- idr_train.py:612-802
+    def run(self):
+        mse2psnr = lambda x: -10. * np.log(x + 1e-8) / np.log(10.)
+        for epoch in range(self.start_epoch, self.nepochs + 1):
+            np.random.seed(epoch)           # every rank draws the same patch list before cutting its slice
+            self._resample()
+            self.train_dataset.change_sampling_rays(self.num_rays)
+            if self.step.cur_iter > self.max_niters:
+                self.save_checkpoints(epoch)
+                return self.history
+            self.train_sampler_generator.manual_seed(epoch)
+            for data_index, (indices, model_input, ground_truth) in enumerate(self.train_dataloader):
+                if getattr(self.loss, 'sample_each_iter', False):
+                    self._resample()
+                model_input = {k: v.to(self.device) for k, v in model_input.items()}
+                ground_truth = {'rgb': ground_truth['rgb'].to(self.device)}
+                it = self.step.cur_iter
+                if self.rank == 0 and it % self.ckpt_freq == 0:                      # :695-696 (before the step)
+                    self.save_checkpoints(epoch)
+                _, lo = self.step(model_input, ground_truth)
+                if it % self.log_freq == 0:
+                    loss = lo['loss'].item()
+                    if not np.isfinite(loss):                                       # :752-755
+                        self.save_checkpoints(epoch)
+                        raise FloatingPointError('nan/inf in loss at iteration %d' % it)
+                    rec = {'iter': it, 'epoch': epoch, 'loss': loss, 'sg_rgb_loss': lo['sg_rgb_loss'].item(),
+                           'sg_psnr': float(mse2psnr(lo['sg_rgb_loss'].item())),
+                           'idr_lr': float(self.step.idr_optimizer.param_groups[0]['lr']),
+                           'sg_lr': float(self.step.sg_optimizer.param_groups[0]['lr'])}
+                    self.history.append(rec)
+                    if self.rank == 0:
+                        print('{0} [{1}] ({2}/{3}): loss = {4:.6f}, sg_rgb_loss = {5:.6f}, sg_psnr = {6:.3f}, idr_lr = {7}, '
+                              'sg_lr = {8}'.format(self.expname, epoch, data_index, self.n_batches, loss,
+                                                   rec['sg_rgb_loss'], rec['sg_psnr'], rec['idr_lr'], rec['sg_lr']))
+                if self.step.cur_iter > self.max_niters:
+                    break
+        return self.history

@@ -129,6 +129,27 @@ class TrainStep:
                                                                  gamma=sg_sched_factor)
         self.trainable = [p for p in model.parameters() if p.requires_grad]
 
+    def retensor_lr(self):
+        """After optimizer.load_state_dict (which installs the checkpoint's python-float learning rates): graph mode keeps
+        them in device tensors that the captured Adam reads and the schedulers fill in place."""
+        if not self.graph:
+            return
+        for opt in (self.idr_optimizer, self.sg_optimizer):
+            dev = opt.param_groups[0]['params'][0].device
+            for g in opt.param_groups:
+                if not torch.is_tensor(g['lr']):
+                    g['lr'] = torch.tensor(float(g['lr']), device=dev)
+        self._graphs.clear()          # captured graphs hold the old tensors
+
+    @staticmethod
+    def portable_state_dict(opt):
+        """optimizer.state_dict() with python-float learning rates (what the reference's runner saves and loads)."""
+        sd = opt.state_dict()
+        for g in sd['param_groups']:
+            if torch.is_tensor(g.get('lr')):
+                g['lr'] = float(g['lr'])
+        return sd
+
     def _pre_iteration(self):
         """idr_train.py:692-713, in the reference's order."""
         if self.cur_iter in self.alpha_milestones:

@@ -137,3 +137,35 @@ def test_split_and_merge_roundtrip():
     merged = utils.merge_output(res, 37, 2)
     assert torch.equal(merged['a'], uv.reshape(-1, 2))
     assert merged['m'].shape == (74,)
+
+
+def test_synthetic_dataset_follows_scene_dataset_contract():
+    """scene_dataset.py:149-279: item layout, 2x2 patch sampling, contiguous per-rank split of the patch list (the last
+    rank takes the remainder), sub-pixel ray jitter shared by all pixels, collate."""
+    import numpy as np
+    import torch
+    from nefii_amd.datasets.synthetic_dataset import SyntheticSceneDataset
+    ds = SyntheticSceneDataset(n_views=3, img_res=(20, 24))
+    idx, sample, gt = ds[1]
+    assert sample['uv'].shape == (480, 2) and gt['rgb'].shape == (480, 3) and sample['pose'].shape == (4, 4)
+    assert sample['uv'][25].tolist() == [1.0, 1.0]                      # (u = x, v = y), row-major pixels
+    np.random.seed(3)
+    ds.change_sampling_idx_patch(10, 1)
+    full = ds.sampling_idx.clone()
+    assert full.shape == (40,)
+    p = full.reshape(10, 4)
+    assert ((p[:, 1] - p[:, 0]) == 1).all() and ((p[:, 2] - p[:, 0]) == 24).all() and ((p[:, 3] - p[:, 2]) == 1).all()
+    parts = []
+    for rank in range(3):
+        ds.sampling_idx = full.clone()
+        ds.scatter_sampling_idx_patch(rank, 3, 10, 1)
+        parts.append(ds.sampling_idx)
+    assert [t.shape[0] for t in parts] == [12, 12, 16]
+    assert torch.equal(torch.cat(parts), full)
+    ds.change_sampling_rays(5)
+    idx, sample, gt = ds[0]
+    assert sample['uv'].shape == (16, 5, 2) and gt['rgb'].shape == (16, 3) and sample['object_mask'].shape == (16,)
+    jit = sample['uv'] - sample['uv'].round()
+    assert (jit[0] - jit[7]).abs().max() < 1e-6                          # one jitter set for every pixel
+    batch = ds.collate_fn([ds[0], ds[2]])
+    assert batch[0].tolist() == [0, 2] and batch[1]['uv'].shape == (2, 16, 5, 2) and batch[2]['rgb'].shape == (2, 16, 3)
