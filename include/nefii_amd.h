@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 3
+#define NEFII_ABI_VERSION 4
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -251,6 +251,23 @@ int nefii_mc_shade_backward(const float *specular, const float *roughness, const
                             const float *light, const float *visibility, const float *indirect, int64_t n,
                             const float *d_rgb, const float *d_spec, const float *d_diff, float *g_light,
                             float *g_indirect, float *g_albedo, float *g_roughness, float *g_specular, void *stream);
+
+/* IDRLoss.forward (code/model/loss.py:278-320) for the terms the shipped confs weight: masked L1/L2/SmoothL1 of idr_rgb
+ * and sg_rgb against the ground truth over rays with network_object_mask & object_mask (:163-184), the mask BCE over
+ * the others (:186-196), the normal-smoothness variance over 2r x 2r patches (:198-207) and the background colour term
+ * over rays missing both masks; eikonal is zero under frozen geometry, SSIM / view-diff / roughness-smooth have weight 0
+ * in every conf.  losses[0..5] = loss, idr_rgb_loss, sg_rgb_loss, mask_loss, normalsmooth_loss, background_rgb_loss;
+ * d_idr_rgb / d_sg_rgb [n,3] (either may be NULL) receive d loss / d input in the same launch. */
+typedef struct nefii_loss_params {
+    float idr_rgb_weight, sg_rgb_weight, mask_weight, alpha, normalsmooth_weight, background_rgb_weight;
+    int32_t loss_type;       /* 0 L1, 1 L2, 2 SmoothL1(beta 1) */
+    int32_t env_loss_type;   /* 0 L1, 1 L2 */
+    int32_t r_patch;         /* patches of (2 r)^2 consecutive rays for the normal-smoothness term; < 1: off */
+    int32_t reserved;
+} nefii_loss_params;
+int nefii_idr_loss(const nefii_loss_params *h_params, const float *idr_rgb, const float *sg_rgb, const float *rgb_gt,
+                   const uint8_t *network_object_mask, const uint8_t *object_mask, const float *sdf_output,
+                   const float *normals, int64_t n, float *losses, float *d_idr_rgb, float *d_sg_rgb, void *stream);
 
 #ifdef __cplusplus
 }

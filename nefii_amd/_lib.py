@@ -14,7 +14,7 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
 HEAD_NONE, HEAD_TANH01, HEAD_POW2, HEAD_SIGMOID, HEAD_RELU, HEAD_ABS, HEAD_RELU_INIT = range(7)
@@ -40,6 +40,13 @@ class TracerParams(ctypes.Structure):
                 ('sphere_tracing_iters', ctypes.c_int32), ('n_steps', ctypes.c_int32),
                 ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32), ('bisect_levels', ctypes.c_int32),
                 ('precision', ctypes.c_int32)]
+
+
+class LossParams(ctypes.Structure):
+    _fields_ = [('idr_rgb_weight', ctypes.c_float), ('sg_rgb_weight', ctypes.c_float), ('mask_weight', ctypes.c_float),
+                ('alpha', ctypes.c_float), ('normalsmooth_weight', ctypes.c_float),
+                ('background_rgb_weight', ctypes.c_float), ('loss_type', ctypes.c_int32),
+                ('env_loss_type', ctypes.c_int32), ('r_patch', ctypes.c_int32), ('reserved', ctypes.c_int32)]
 
 
 P = ctypes.c_void_p
@@ -74,6 +81,7 @@ SIGNATURES = {
     'nefii_trace_profile_enable': (I, [I]),
     'nefii_trace_profile_read': (I, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(I), ctypes.POINTER(ctypes.c_double)]),
     'nefii_trace_profile_launches': (I, [ctypes.POINTER(ctypes.c_float), I]),
+    'nefii_idr_loss': (I, [ctypes.POINTER(LossParams), P, P, P, P, P, P, P, I64, P, P, P, P]),
     'nefii_camera_rays': (I, [P, P, P, I, I64, P, P, P]),
     'nefii_sg_render_forward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P]),
     'nefii_sg_render_backward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P, P, P, P, P]),

@@ -811,3 +811,139 @@ extern "C" int nefii_mc_shade_backward(const float *specular, const float *rough
     HIP_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// IDRLoss (code/model/loss.py:278-320), value and gradient in one launch.  The loss runs on num_pixels x 3 floats:
+// as torch ops it is ~45 launches of a few microseconds each, behind one another on the step's critical path.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float img_err(float d, int kind) {       // loss.py:144-161: L1 / L2 / SmoothL1(beta=1)
+    const float ad = fabsf(d);
+    if (kind == 0) return ad;
+    if (kind == 1) return d * d;
+    return ad < 1.f ? 0.5f * d * d : ad - 0.5f;
+}
+__device__ __forceinline__ float img_err_grad(float d, int kind) {
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (kind == 0) return sg;
+    if (kind == 1) return 2.f * d;
+    return fabsf(d) < 1.f ? d : sg;
+}
+
+constexpr int LOSS_T = 1024, LOSS_Q = 8;       // threads of the single block; quantities reduced
+
+// quantities: 0 idr err sum, 1 sg err sum, 2 hit count, 3 mask bce sum, 4 background err sum, 5 background count,
+// 6 normal-variance sum, 7 patch count
+__global__ __launch_bounds__(LOSS_T) void idr_loss_kernel(nefii_loss_params p, const float *__restrict__ idr_rgb,
+                                                          const float *__restrict__ sg_rgb,
+                                                          const float *__restrict__ gt, const uint8_t *__restrict__ net,
+                                                          const uint8_t *__restrict__ obj,
+                                                          const float *__restrict__ sdf,
+                                                          const float *__restrict__ normals, int64_t n,
+                                                          float *__restrict__ losses, float *__restrict__ d_idr,
+                                                          float *__restrict__ d_sg) {
+    __shared__ double red[LOSS_T];
+    __shared__ double tot[LOSS_Q];
+    const int tid = threadIdx.x;
+    double acc[LOSS_Q];
+#pragma unroll
+    for (int q = 0; q < LOSS_Q; ++q) acc[q] = 0.0;
+    for (int64_t i = tid; i < n; i += LOSS_T) {
+        const bool nm = net[i] != 0, om = obj[i] != 0;
+        if (nm && om) {
+            for (int c = 0; c < 3; ++c) {
+                const float g = gt[i * 3 + c];
+                acc[0] += img_err(idr_rgb[i * 3 + c] - g, p.loss_type);
+                acc[1] += img_err(sg_rgb[i * 3 + c] - g, p.loss_type);
+            }
+            acc[2] += 1.0;
+        } else {        // get_mask_loss :186-196: BCE-with-logits of -alpha*sdf against the object mask, on the other rays
+            const float x = -p.alpha * sdf[i], t = om ? 1.f : 0.f;
+            acc[3] += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+        }
+        if (!nm && !om && p.background_rgb_weight > 0.f) {
+            for (int c = 0; c < 3; ++c) acc[4] += img_err(sg_rgb[i * 3 + c] - gt[i * 3 + c], p.env_loss_type);
+            acc[5] += 1.0;
+        }
+    }
+    if (p.r_patch >= 1 && p.normalsmooth_weight != 0.f) {      // get_normalsmooth_loss :198-207
+        const int k = 4 * p.r_patch * p.r_patch;
+        for (int64_t pi = tid; pi < n / k; pi += LOSS_T) {
+            bool all = true;
+            for (int j = 0; j < k; ++j) all = all && net[pi * k + j] && obj[pi * k + j];
+            if (!all) continue;
+            for (int c = 0; c < 3; ++c) {
+                float mean = 0.f;
+                for (int j = 0; j < k; ++j) mean += normals[(pi * k + j) * 3 + c];
+                mean /= k;
+                float var = 0.f;
+                for (int j = 0; j < k; ++j) {
+                    const float d = normals[(pi * k + j) * 3 + c] - mean;
+                    var += d * d;
+                }
+                acc[6] += var / (k - 1);
+            }
+            acc[7] += 1.0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < LOSS_Q; ++q) {          // plain shared-memory tree per quantity (8 x 10 steps on 8 KB)
+        red[tid] = acc[q];
+        __syncthreads();
+        for (int half = LOSS_T / 2; half > 0; half >>= 1) {
+            if (tid < half) red[tid] += red[tid + half];
+            __syncthreads();
+        }
+        if (tid == 0) tot[q] = red[0];
+        __syncthreads();
+    }
+    const float den = fmaxf((float)tot[2] * 3.f, 1.f), bden = fmaxf((float)tot[5] * 3.f, 1.f);
+    if (tid == 0) {
+        const float idr_l = (float)tot[0] / den, sg_l = (float)tot[1] / den;
+        const float mask_l = (1.f / p.alpha) * (float)tot[3] / (float)n;
+        const float ns_l = (p.r_patch >= 1 && p.normalsmooth_weight != 0.f) ? (float)tot[6] / fmaxf((float)tot[7] * 3.f, 1.f) : 0.f;
+        const float bg_l = p.background_rgb_weight > 0.f ? (float)tot[4] / bden : 0.f;
+        losses[0] = p.idr_rgb_weight * idr_l + p.sg_rgb_weight * sg_l + p.mask_weight * mask_l +
+                    p.normalsmooth_weight * ns_l + p.background_rgb_weight * bg_l;
+        losses[1] = idr_l;
+        losses[2] = sg_l;
+        losses[3] = mask_l;
+        losses[4] = ns_l;
+        losses[5] = bg_l;
+    }
+    if (!d_idr && !d_sg) return;
+    for (int64_t i = tid; i < n; i += LOSS_T) {
+        const bool nm = net[i] != 0, om = obj[i] != 0;
+        for (int c = 0; c < 3; ++c) {
+            const float g = gt[i * 3 + c];
+            float gi = 0.f, gs = 0.f;
+            if (nm && om) {
+                gi = p.idr_rgb_weight * img_err_grad(idr_rgb[i * 3 + c] - g, p.loss_type) / den;
+                gs = p.sg_rgb_weight * img_err_grad(sg_rgb[i * 3 + c] - g, p.loss_type) / den;
+            } else if (!nm && !om && p.background_rgb_weight > 0.f) {
+                gs = p.background_rgb_weight * img_err_grad(sg_rgb[i * 3 + c] - g, p.env_loss_type) / bden;
+            }
+            if (d_idr) d_idr[i * 3 + c] = gi;
+            if (d_sg) d_sg[i * 3 + c] = gs;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int nefii_idr_loss(const nefii_loss_params *h_params, const float *idr_rgb, const float *sg_rgb,
+                              const float *rgb_gt, const uint8_t *network_object_mask, const uint8_t *object_mask,
+                              const float *sdf_output, const float *normals, int64_t n, float *losses, float *d_idr_rgb,
+                              float *d_sg_rgb, void *stream) {
+    if (!h_params || !idr_rgb || !sg_rgb || !rgb_gt || !network_object_mask || !object_mask || !sdf_output || !losses)
+        return NEFII_E_ARG;
+    if (n <= 0) return NEFII_E_SHAPE;
+    if (h_params->loss_type < 0 || h_params->loss_type > 2 || h_params->env_loss_type < 0 || h_params->env_loss_type > 1)
+        return NEFII_E_ARG;
+    if (h_params->r_patch >= 1 && h_params->normalsmooth_weight != 0.f && !normals) return NEFII_E_ARG;
+    hipLaunchKernelGGL(idr_loss_kernel, dim3(1), dim3(LOSS_T), 0, (hipStream_t)stream, *h_params, idr_rgb, sg_rgb, rgb_gt,
+                       network_object_mask, object_mask, sdf_output, normals, n, losses, d_idr_rgb, d_sg_rgb);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}

@@ -30,6 +30,7 @@ class IDRLoss(nn.Module):
         self.env_loss_type = env_loss_type
         self.r_patch = int(r_patch)
         self.normalsmooth_weight = normalsmooth_weight
+        self.fused = True       # one-launch HIP kernel for value + gradient when the inputs live on the GPU
 
     @staticmethod
     def _zero(ref):
@@ -82,7 +83,31 @@ class IDRLoss(nn.Module):
         var = torch.var(normal.view((-1, k, 3)), dim=1)
         return self._masked_mean(var, mask, 3)
 
+    def _fused(self, model_outputs, ground_truth):
+        """All terms and d loss / d (idr_rgb, sg_rgb) in one kernel launch (ops.IdrLossFn); the torch formulation below
+        is ~45 launches of a few microseconds each on the step's critical path."""
+        from .. import ops
+        from .._lib import LossParams
+        kinds = {'L1': 0, 'L2': 1, 'L1_smooth': 2}
+        p = LossParams(self.idr_rgb_weight, self.sg_rgb_weight, self.mask_weight, self.alpha, self.normalsmooth_weight,
+                       self.background_rgb_weight, kinds[self.loss_type], kinds[self.env_loss_type], self.r_patch, 0)
+        idr_rgb = model_outputs['idr_rgb_values']
+        if self.idr_rgb_weight == 0:
+            idr_rgb = idr_rgb.detach()      # see forward()
+        lo = ops.IdrLossFn.apply(idr_rgb, model_outputs['sg_rgb_values'], ground_truth['rgb'],
+                                 model_outputs['network_object_mask'], model_outputs['object_mask'],
+                                 model_outputs['sdf_output'].detach(), model_outputs['normal_values'].detach(), p)
+        zero = self._zero(lo)
+        d = lo.detach()
+        return {'loss': lo[0], 'idr_rgb_loss': d[1], 'sg_rgb_loss': d[2], 'eikonal_loss': zero, 'mask_loss': d[3],
+                'normalsmooth_loss': d[4], 'idr_ssim_loss': zero, 'sg_ssim_loss': zero, 'view_diff_loss': zero,
+                'background_rgb_loss': d[5]}
+
     def forward(self, model_outputs, ground_truth):
+        sg = model_outputs['sg_rgb_values']
+        if self.fused and sg.is_cuda and model_outputs['grad_theta'] is None and \
+                not model_outputs['sdf_output'].requires_grad and not model_outputs['normal_values'].requires_grad:
+            return self._fused(model_outputs, ground_truth)
         rgb_gt = ground_truth['rgb']
         net = model_outputs['network_object_mask']
         obj = model_outputs['object_mask']

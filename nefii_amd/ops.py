@@ -378,8 +378,9 @@ def camera_rays(uv, pose, intrinsics):
     B, S, _ = uv.shape
     dirs = torch.empty(B, S, 3, device=uv.device, dtype=torch.float32)
     orig = torch.empty(B, S, 3, device=uv.device, dtype=torch.float32)
-    _lib.check(lib.nefii_camera_rays(_ptr(_f32(uv)), _ptr(_f32(pose)), _ptr(_f32(intrinsics)), B, S, _ptr(dirs),
-                                     _ptr(orig), _stream()), 'nefii_camera_rays')
+    uv_c, pose_c, k_c = _f32(uv), _f32(pose), _f32(intrinsics)      # converted copies must outlive the launch call
+    _lib.check(lib.nefii_camera_rays(_ptr(uv_c), _ptr(pose_c), _ptr(k_c), B, S, _ptr(dirs), _ptr(orig), _stream()),
+               'nefii_camera_rays')
     return dirs, orig
 
 
@@ -410,9 +411,10 @@ class SGRenderFn(torch.autograd.Function):
         g_rough = torch.zeros(1, 1, device=albedo.device, dtype=torch.float32)
         g_spec = torch.zeros(1, 3, device=albedo.device, dtype=torch.float32)
         g_lgt = torch.zeros_like(lgt)
+        d_rgb, d_s, d_d = _f32(d_rgb), _f32(d_s), _f32(d_d)     # keep converted copies alive across the launch call
         _lib.check(lib.nefii_sg_render_backward(_ptr(lgt), lgt.shape[0], _ptr(spec), _ptr(rough), _ptr(albedo),
-                                                _ptr(normal), _ptr(view), n, _ptr(_f32(d_rgb)), _ptr(_f32(d_s)),
-                                                _ptr(_f32(d_d)), _ptr(g_alb), _ptr(g_rough), _ptr(g_spec), _ptr(g_lgt),
+                                                _ptr(normal), _ptr(view), n, _ptr(d_rgb), _ptr(d_s),
+                                                _ptr(d_d), _ptr(g_alb), _ptr(g_rough), _ptr(g_spec), _ptr(g_lgt),
                                                 _stream()), 'nefii_sg_render_backward')
         if ctx.spec_shape[-1] == 1:
             g_spec = g_spec.sum(-1, keepdim=True)
@@ -437,8 +439,9 @@ class EnvRadianceFn(torch.autograd.Function):
         lib = _lib.lib()
         lgt, dirs = ctx.saved_tensors
         g = torch.zeros_like(lgt)
+        d_rgb = _f32(d_rgb)
         _lib.check(lib.nefii_env_radiance_backward(_ptr(lgt), lgt.shape[0], _ptr(dirs), dirs.shape[0], ctx.eps,
-                                                   _ptr(_f32(d_rgb)), _ptr(g), _stream()), 'nefii_env_radiance_backward')
+                                                   _ptr(d_rgb), _ptr(g), _stream()), 'nefii_env_radiance_backward')
         return g, None, None
 
 
@@ -516,9 +519,9 @@ def mis_sample(lgt, rough, normal, view, uniforms):
     own = torch.empty(3, n, device=dev, dtype=torch.float32)
     tab = torch.empty(3, n, 3, device=dev, dtype=torch.float32)
     lgt_c = _f32(lgt)
-    _lib.check(lib.nefii_mis_sample(_ptr(lgt_c), lgt_c.shape[0], _ptr(_f32(rough).reshape(-1)), _ptr(_f32(normal)),
-                                    _ptr(_f32(view)), _ptr(_f32(uniforms)), n, _ptr(wi), _ptr(own), _ptr(tab),
-                                    _stream()), 'nefii_mis_sample')
+    rough_c, normal_c, view_c, uni_c = _f32(rough).reshape(-1), _f32(normal), _f32(view), _f32(uniforms)
+    _lib.check(lib.nefii_mis_sample(_ptr(lgt_c), lgt_c.shape[0], _ptr(rough_c), _ptr(normal_c), _ptr(view_c),
+                                    _ptr(uni_c), n, _ptr(wi), _ptr(own), _ptr(tab), _stream()), 'nefii_mis_sample')
     return wi, own, tab
 
 
@@ -553,9 +556,43 @@ class McShadeFn(torch.autograd.Function):
         g_alb = torch.empty(n, 3, device=dev, dtype=torch.float32)
         g_rough = torch.empty(n, device=dev, dtype=torch.float32)
         g_spec = torch.zeros(1, 3, device=dev, dtype=torch.float32) if ctx.spec_grad else None
-        _lib.check(lib.nefii_mc_shade_backward(*[_ptr(x) for x in t], n, _ptr(_f32(d_rgb)), _ptr(_f32(d_s)),
-                                               _ptr(_f32(d_d)), _ptr(g_light), _ptr(g_ind), _ptr(g_alb), _ptr(g_rough),
+        d_rgb, d_s, d_d = _f32(d_rgb), _f32(d_s), _f32(d_d)
+        _lib.check(lib.nefii_mc_shade_backward(*[_ptr(x) for x in t], n, _ptr(d_rgb), _ptr(d_s),
+                                               _ptr(d_d), _ptr(g_light), _ptr(g_ind), _ptr(g_alb), _ptr(g_rough),
                                                _ptr(g_spec), _stream()), 'nefii_mc_shade_backward')
         if g_spec is not None and ctx.spec_shape[-1] == 1:
             g_spec = g_spec.sum(-1, keepdim=True)
         return (g_spec, g_rough.reshape(ctx.rough_shape), g_alb, None, None, None, None, None, g_light, None, g_ind)
+
+
+class IdrLossFn(torch.autograd.Function):
+    """IDRLoss value + gradient in one launch (nefii_idr_loss).  Returns losses [6] = (loss, idr_rgb_loss, sg_rgb_loss,
+    mask_loss, normalsmooth_loss, background_rgb_loss); only losses[0] is differentiable, wrt idr_rgb and sg_rgb."""
+
+    @staticmethod
+    def forward(ctx, idr_rgb, sg_rgb, rgb_gt, net_mask, obj_mask, sdf_output, normals, params):
+        lib = _lib.lib()
+        n = sg_rgb.shape[0]
+        dev = sg_rgb.device
+        losses = torch.empty(6, device=dev, dtype=torch.float32)
+        need_i, need_s = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d_idr = torch.empty(n, 3, device=dev, dtype=torch.float32) if need_i else None
+        d_sg = torch.empty(n, 3, device=dev, dtype=torch.float32) if need_s else None
+        # converted copies are bound to names: a temporary handed to _ptr() dies before the launch call is made and the
+        # next temporary of the same size is given its memory
+        idr_c, sg_c, gt_c = _f32(idr_rgb), _f32(sg_rgb), _f32(rgb_gt).reshape(-1, 3)
+        net_c, obj_c = net_mask.to(torch.uint8).contiguous(), obj_mask.to(torch.uint8).contiguous()
+        sdf_c = _f32(sdf_output).reshape(-1)
+        nrm_c = _f32(normals) if normals is not None else None
+        _lib.check(lib.nefii_idr_loss(ctypes.byref(params), _ptr(idr_c), _ptr(sg_c), _ptr(gt_c), _ptr(net_c), _ptr(obj_c),
+                                      _ptr(sdf_c), _ptr(nrm_c), n, _ptr(losses), _ptr(d_idr), _ptr(d_sg), _stream()),
+                   'nefii_idr_loss')
+        ctx.save_for_backward(d_idr, d_sg)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        d_idr, d_sg = ctx.saved_tensors
+        s = g[0]
+        return (d_idr * s if d_idr is not None else None, d_sg * s if d_sg is not None else None,
+                None, None, None, None, None, None)

@@ -521,3 +521,44 @@ def test_tracer_large_batch_properties_and_subset_vs_oracle():
     ref = tracer.trace(sdf, o[idx], d[idx], om[idx], mc['ray_tracer'], True, steps)
     compare_trace(sdf, o[idx], d[idx], (pts[idx], hit[idx], dist[idx], None), ref['hit'], ref['dists'], 'subset',
                   argmin_set(ref['hit'], om[idx], True))
+
+
+@pytest.mark.parametrize('loss_type,env_type,r_patch,bg_w,ns_w,idr_w', [
+    ('L1', 'L1', 1, 0.0, 0.0, 1.0), ('L1', 'L2', 1, 0.5, 0.1, 0.0), ('L2', 'L1', 1, 1.0, 0.2, 1.0),
+    ('L1_smooth', 'L2', 2, 0.3, 0.05, 0.7), ('L1', 'L1', -1, 0.0, 0.0, 1.0)])
+@pytest.mark.parametrize('n', [64, 4096, 5000 * 16])
+def test_fused_idr_loss_matches_torch_formulation(loss_type, env_type, r_patch, bg_w, ns_w, idr_w, n):
+    """nefii_idr_loss (one launch) against IDRLoss's torch formulation (itself checked against the reference's loss in
+    tests/test_loss_cpu.py): every reported term and the gradients wrt idr_rgb and sg_rgb."""
+    from nefii_amd.model.loss import IDRLoss
+    g = torch.Generator().manual_seed(n + r_patch)
+    kw = dict(idr_rgb_weight=idr_w, sg_rgb_weight=1.0, eikonal_weight=0.1, mask_weight=100.0, alpha=50.0, r_patch=r_patch,
+              normalsmooth_weight=ns_w, loss_type=loss_type, env_loss_type=env_type, background_rgb_weight=bg_w)
+    base = {'idr_rgb_values': torch.rand(n, 3, generator=g) * 1.6, 'sg_rgb_values': torch.rand(n, 3, generator=g) * 2.5,
+            'network_object_mask': torch.rand(n, generator=g) < 0.4, 'object_mask': torch.rand(n, generator=g) < 0.7,
+            'sdf_output': torch.randn(n, 1, generator=g) * 0.05, 'normal_values': torch.randn(n, 3, generator=g),
+            'grad_theta': None}
+    if r_patch >= 1:        # some whole patches inside both masks
+        k = 4 * r_patch * r_patch
+        base['network_object_mask'].view(-1, k)[::3] = True
+        base['object_mask'].view(-1, k)[::3] = True
+    gt = {'rgb': torch.rand(1, n, 3, generator=g).to(DEV)}
+    res = []
+    for fused in (False, True):
+        out = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in base.items()}
+        out['idr_rgb_values'].requires_grad_(True)
+        out['sg_rgb_values'].requires_grad_(True)
+        L = IDRLoss(**kw)
+        L.fused = fused
+        lo = L(out, gt)
+        lo['loss'].backward()
+        res.append((lo, out['idr_rgb_values'].grad, out['sg_rgb_values'].grad))
+    (l0, gi0, gs0), (l1, gi1, gs1) = res
+    for k in l0:
+        a, b = l0[k].item(), l1[k].item()
+        assert abs(a - b) <= 2e-5 * max(abs(a), 1e-6), (k, a, b)
+    assert rel_l2(gs1, gs0) < 1e-5
+    if idr_w > 0:
+        assert rel_l2(gi1, gi0) < 1e-5
+    else:
+        assert gi0 is None and gi1 is None
