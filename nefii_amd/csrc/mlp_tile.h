@@ -372,9 +372,9 @@ struct AStage16w {
 };
 
 template <bool TWO_COLS>
-__device__ __forceinline__ void load_b16w(BStage16w &st, const half8 *__restrict__ wp, int NT, int wave, int lane,
+__device__ __forceinline__ void load_b16w(BStage16w &st, const half8 *__restrict__ wp, int NT, int tile0, int lane,
                                           int s) {
-    const size_t t = (size_t)s * NT + 2 * wave;
+    const size_t t = (size_t)s * NT + tile0;
     st.bh[0] = wp[(t * 2) * 64 + lane];
     st.bl[0] = wp[(t * 2 + 1) * 64 + lane];
     if (TWO_COLS) {
@@ -437,25 +437,31 @@ __device__ __forceinline__ void gemm_block16w_t(const _Float16 *Ah, const _Float
 }
 
 __device__ __forceinline__ void gemm_block16w(const _Float16 *Ah, const _Float16 *Al, int a_stride, int ksteps,
-                                              const half8 *__restrict__ wp, int NT, int wave, int lane, int nct,
+                                              const half8 *__restrict__ wp, int NT, int tile0, int lane, int nct,
                                               f32x16 (&acc)[4]) {
     if (ksteps <= 0 || nct <= 0) return;
     if (nct == 2)
-        gemm_block16w_t<true>(Ah, Al, a_stride, ksteps, wp, NT, wave, lane, acc);
+        gemm_block16w_t<true>(Ah, Al, a_stride, ksteps, wp, NT, tile0, lane, acc);
     else
-        gemm_block16w_t<false>(Ah, Al, a_stride, ksteps, wp, NT, wave, lane, acc);
+        gemm_block16w_t<false>(Ah, Al, a_stride, ksteps, wp, NT, tile0, lane, acc);
 }
+
+__device__ __forceinline__ int wide16w_tiles_per_wave(int n_tiles) { return n_tiles > 8 ? 2 : 1; }
+__device__ __forceinline__ int wide16w_tile0(int n_tiles, int wave) { return n_tiles > 8 ? 2 * wave : wave; }
 
 __device__ __forceinline__ void layer_gemm16w(const nefii_layer &L, const Lds16w &lds, int n_tiles, f32x16 (&acc)[4],
                                               int &nct) {
     // readfirstlane: tell the compiler the wave index is wave-uniform (scalar branches, no exec masking of MFMAs)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    nct = n_tiles - 2 * wave;
-    nct = nct < 0 ? 0 : (nct > 2 ? 2 : nct);
+    // column tiles of this wave: a pair (tiles 2w, 2w+1) for layers wider than 8 tiles, ONE tile (w) for narrower ones -
+    // a 256-wide net (conf_neus.conf) then keeps all 8 waves on the matrix cores instead of 4
+    const int tile0 = wide16w_tile0(n_tiles, wave);
+    nct = n_tiles - tile0;
+    nct = nct < 0 ? 0 : (nct > wide16w_tiles_per_wave(n_tiles) ? wide16w_tiles_per_wave(n_tiles) : nct);
     zero_acc(acc);
     const half8 *wp = reinterpret_cast<const half8 *>(L.w_f16x3);
-    gemm_block16w(lds.Xh, lds.Xl, XS16, L.k_x >> 4, wp, n_tiles, wave, lane, nct, acc);
-    gemm_block16w(lds.Eh, lds.El, ES16, L.k_e >> 4, wp + (size_t)(L.k_x >> 4) * n_tiles * 2 * 64, n_tiles, wave, lane,
+    gemm_block16w(lds.Xh, lds.Xl, XS16, L.k_x >> 4, wp, n_tiles, tile0, lane, nct, acc);
+    gemm_block16w(lds.Eh, lds.El, ES16, L.k_e >> 4, wp + (size_t)(L.k_x >> 4) * n_tiles * 2 * 64, n_tiles, tile0, lane,
                   nct, acc);
 }
 
@@ -476,12 +482,12 @@ __device__ __forceinline__ float softplus100_s16(float zs) {
 
 // transposed accumulator walk of the wide kernel: BODY sees `query` (row of the tile), `f0` (first of 4 consecutive
 // features) and `v` (float4v: the 4 accumulator values)
-#define NEFII_FOR_ACC_WT(acc, nct, BODY)                                                  \
+#define NEFII_FOR_ACC_WT(acc, nct, n_tiles, BODY)                                         \
     {                                                                                     \
         const int _wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), _lane = threadIdx.x & 63; \
         _Pragma("unroll") for (int _c = 0; _c < 2; ++_c) if (_c < (nct)) {                \
             _Pragma("unroll") for (int _g = 0; _g < 4; ++_g) {                            \
-                const int f0 = 32 * (2 * _wave + _c) + 8 * _g + 4 * (_lane >> 5);         \
+                const int f0 = 32 * (wide16w_tile0((n_tiles), _wave) + _c) + 8 * _g + 4 * (_lane >> 5); \
                 _Pragma("unroll") for (int _rt = 0; _rt < 2; ++_rt) {                     \
                     const int query = 32 * _rt + (_lane & 31);                            \
                     const f32x16 &_a = (acc)[_rt * 2 + _c];                               \

@@ -538,7 +538,7 @@ __device__ __forceinline__ void sdf_tile16w(const nefii_mlp &m, Lds16w &lds, con
         __syncthreads();
         if (l < Lm1) {
             const float k16 = inv_scale * A16_SCALE;
-            NEFII_FOR_ACC_WT(acc, nct, {
+            NEFII_FOR_ACC_WT(acc, nct, L.n_pad >> 5, {
                 const float4v b = *reinterpret_cast<const float4v *>(L.bias + f0);
                 float4v hs;       // A16_SCALE * activation
                 _Pragma("unroll") for (int k = 0; k < 4; ++k) {
@@ -552,7 +552,7 @@ __device__ __forceinline__ void sdf_tile16w(const nefii_mlp &m, Lds16w &lds, con
                 *reinterpret_cast<half4 *>(&lds.Xl[query * XS16 + f0]) = lo;
             })
         } else {
-            NEFII_FOR_ACC_WT(acc, nct, {
+            NEFII_FOR_ACC_WT(acc, nct, L.n_pad >> 5, {
                 if (f0 == 0 && dest[query]) *dest[query] = v[0] * inv_scale + L.bias[0];
             })
         }
