@@ -175,10 +175,9 @@ def main():
         step(inp, gt)
     # the graph of the step's tail is captured once per padded hit count, after 3 eager steps: with fewer warm-up steps
     # than that, run the missing ones (still untimed) so that no capture lands in the timed region
-    priming = 0
-    while use_graph and not step._graphs and priming < 6:
+    priming = max(0, step.graph_after + 1 - args.warmup) if use_graph else 0     # the same count on every rank
+    for _ in range(priming):
         step(inp, gt)
-        priming += 1
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -210,18 +209,24 @@ def main():
     model.ray_tracer.skip_min_sdf_search = False
     step(inp, gt)
 
+    # ---- roofline of the dominant kernel: one extra, un-timed step with per-launch HIP events.  Every rank runs the step
+    # (it contains the gradient all-reduce); only rank 0 instruments and reports it.
+    model.ray_tracer.collect_counters = True
+    model.ray_tracer.counter_sum = None
+    model.ray_tracer.stream_groups = 1      # the profiled step runs the rounds back to back on one stream
+    if rank == 0:
+        lib.nefii_trace_profile_enable(1)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out, lo = step(inp, gt)
+    torch.cuda.synchronize()
+    prof_step_ms = (time.perf_counter() - t1) * 1e3
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()        # nothing below communicates (rank 0 alone runs the CPU baseline)
+
     result = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: one extra, un-timed step with per-launch HIP events
-        model.ray_tracer.collect_counters = True
-        model.ray_tracer.counter_sum = None
-        model.ray_tracer.stream_groups = 1      # the profiled step runs the rounds back to back on one stream
-        lib.nefii_trace_profile_enable(1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        out, lo = step(inp, gt)
-        torch.cuda.synchronize()
-        prof_step_ms = (time.perf_counter() - t1) * 1e3
         eval_ms, n_eval, span_ms = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
         lib.nefii_trace_profile_read(ctypes.byref(eval_ms), ctypes.byref(n_eval), ctypes.byref(span_ms))
         lib.nefii_trace_profile_enable(0)
@@ -284,9 +289,6 @@ def main():
             result['cpu_baseline'], result['parity_vs_cpu_oracle'] = cpu_baseline(
                 args.workload, args.cpu_sample_pixels, steps=3, warmup=1, device=dev)
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -479,3 +479,23 @@ model { %s }
     ck = os.path.join(str(tmp_path), 'cli', runs[0], 'checkpoints', 'ModelParameters')
     assert 'latest.pth' in os.listdir(ck)
     assert os.path.exists(os.path.join(str(tmp_path), 'cli', runs[0], 'runconf.conf'))
+
+
+def test_bench_two_processes_share_one_gpu():
+    """bench.py's multi-process path end to end (sharded inputs, gradient all-reduce, graph step with eager Adam, the
+    profiled step on every rank, clean exit) with two ranks on this box's one GPU over gloo - RCCL needs two devices."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NEFII_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', '29517', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup',
+           '4', '--no-cpu-baseline']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['value'] > 0
+    assert d['config']['primary_rays_per_step_per_gpu'] == 4096
