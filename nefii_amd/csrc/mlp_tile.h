@@ -53,6 +53,21 @@ __device__ __forceinline__ float softplus100(float v) {
     return z > 20.f ? v : r * 0.01f;
 }
 
+// Runs BODY with ACT a compile-time copy of the (wave-uniform) activation id.  Epilogues apply the activation to 64
+// values per lane; with the id tested per value every value took its own scalar branch and the compiler could not
+// interleave the values' dependent exp/log chains.
+#define NEFII_ACT_SWITCH(act, BODY)                                  \
+    if ((act) == NEFII_ACT_SOFTPLUS100) {                            \
+        constexpr int ACT = NEFII_ACT_SOFTPLUS100;                   \
+        BODY                                                         \
+    } else if ((act) == NEFII_ACT_ELU) {                             \
+        constexpr int ACT = NEFII_ACT_ELU;                           \
+        BODY                                                         \
+    } else {                                                         \
+        constexpr int ACT = NEFII_ACT_RELU;                          \
+        BODY                                                         \
+    }
+
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == NEFII_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == NEFII_ACT_ELU) return v > 0.f ? v : expm1f(v);
@@ -663,6 +678,40 @@ __device__ __forceinline__ void prime16p(const nefii_mlp &m, typename P16<NW>::S
 // One 64-query tile through the whole SDF network.  Stage/cursor state runs on from tile to tile (ph = stage of the
 // next k-step).  raw[64][9]: the points (overwritten with the last layer's partial sums); dest[64]: where each SDF
 // value goes (nullptr = padding row).
+// epilogue arithmetic of one wave's 64 x 32*NC block: bias, activation, (16 x) hi/lo split, packed four features at a
+// time (transposed accumulator: lane = query, registers = 4 consecutive features x 4 groups).  FAST = Softplus(beta 100).
+template <int NW, bool FAST>
+__device__ __forceinline__ void pepilogue(const f32x16 (&acc)[2 * P16<NW>::NC], const float (&bvec)[P16<NW>::NC / 2 + 1],
+                                          float k16, int h, int act, half4 (&phi)[P16<NW>::NC * 8],
+                                          half4 (&plo)[P16<NW>::NC * 8]) {
+    constexpr int NC = P16<NW>::NC;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int bsrc = __builtin_bit_cast(int, bvec[c >> 1] * A16_SCALE);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4v bs;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                bs[k] = __builtin_bit_cast(float,
+                                           __builtin_amdgcn_ds_bpermute(4 * (32 * (c & 1) + 8 * g + 4 * h + k), bsrc));
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const f32x16 &av = acc[rt * NC + c];
+                float4v hs;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float zs = __builtin_fmaf(av[4 * g + k], k16, bs[k]);
+                    hs[k] = FAST ? softplus100_s16(zs) : act_fwd(zs * (1.f / A16_SCALE), act) * A16_SCALE;
+                }
+                const half4 hi = __builtin_convertvector(hs, half4);
+                phi[(c * 4 + g) * 2 + rt] = hi;
+                plo[(c * 4 + g) * 2 + rt] = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+            }
+        }
+    }
+}
+
 #ifdef NEFII_STAMPS     /* timing instrumentation: s_memtime at 5 points per layer, workgroup 0, into g_stamps */
 __device__ unsigned long long g_stamps[2 * 8 * 12 * 5];
 __device__ int g_stamp_tile;
@@ -696,7 +745,7 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
         __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
         __builtin_amdgcn_sched_barrier(0);
         NEFII_STAMP(0);
-        float bvec[NC / 2];
+        float bvec[NC / 2 + 1];
 #pragma unroll
         for (int i = 0; i < NC / 2; ++i) bvec[i] = bp[64 * i];
         f32x16 acc[2 * NC];
@@ -717,33 +766,13 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
         // SIMD partner that lost the matrix pipe arbitration is still in its k-loop then (MFMA beside VALU), see
         // tools/stamps.py.  Only the stores into the activation image wait for everyone to be done reading it.
         half4 phi[NC * 4 * 2], plo[NC * 4 * 2];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int bsrc = __builtin_bit_cast(int, bvec[c >> 1] * A16_SCALE);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4v bs;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    bs[k] = __builtin_bit_cast(
-                        float, __builtin_amdgcn_ds_bpermute(4 * (32 * (c & 1) + 8 * g + 4 * h + k), bsrc));
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
-                    const f32x16 &av = acc[rt * NC + c];
-                    float4v hs;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float zs = __builtin_fmaf(av[4 * g + k], k16, bs[k]);
-                        hs[k] = m.act == NEFII_ACT_SOFTPLUS100 ? softplus100_s16(zs)
-                                                               : act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
-                    }
-                    const half4 hi = __builtin_convertvector(hs, half4);
-                    phi[(c * 4 + g) * 2 + rt] = hi;
-                    plo[(c * 4 + g) * 2 + rt] =
-                        __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
-                }
-            }
-        }
+        // the activation switch sits OUTSIDE the 64-value loop: with the test inside it every value went through its own
+        // scalar branch, the compiler could not interleave the values' exp -> add -> log -> fma chains, and the epilogue
+        // ran at the latency of one chain per value (~120 cycles) instead of the VALU's throughput
+        if (m.act == NEFII_ACT_SOFTPLUS100)
+            pepilogue<NW, true>(acc, bvec, k16, h, m.act, phi, plo);
+        else
+            pepilogue<NW, false>(acc, bvec, k16, h, m.act, phi, plo);
         __syncthreads();
         NEFII_STAMP(2);
         _Float16 *xh = lds.Xh + (EP16 - L.n_pad), *xl = lds.Xl + (EP16 - L.n_pad);

@@ -201,19 +201,21 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(nefii_mlp m, const 
             __syncthreads();
             const bool last = (l == m.n_layers - 1);
             const bool pre_last = (l == m.n_layers - 2);
-            NEFII_FOR_ACC(acc, ntw, {
-                const float z = val + L.bias[col];
-                const bool live = (base + row) < n;
-                if (!last) {
-                    const float hval = act_fwd(z, m.act);
-                    lds.X[row * XS + col] = hval;
-                    if (stash && live) stash[((size_t)l * n + base + row) * stash_stride + col] = hval;
-                    if (pre_last && hidden_out && live && col < L.n_out)
-                        hidden_out[(size_t)(base + row) * hid_stride + col] = hval;
-                } else {
-                    if (stash && live) stash[((size_t)l * n + base + row) * stash_stride + col] = z;
-                    if (live && col < L.n_out) out[(size_t)(base + row) * out_stride + col] = head_fwd(z, m.head);
-                }
+            NEFII_ACT_SWITCH(m.act, {
+                NEFII_FOR_ACC(acc, ntw, {
+                    const float z = val + L.bias[col];
+                    const bool live = (base + row) < n;
+                    if (!last) {
+                        const float hval = act_fwd(z, ACT);
+                        lds.X[row * XS + col] = hval;
+                        if (stash && live) stash[((size_t)l * n + base + row) * stash_stride + col] = hval;
+                        if (pre_last && hidden_out && live && col < L.n_out)
+                            hidden_out[(size_t)(base + row) * hid_stride + col] = hval;
+                    } else {
+                        if (stash && live) stash[((size_t)l * n + base + row) * stash_stride + col] = z;
+                        if (live && col < L.n_out) out[(size_t)(base + row) * out_stride + col] = head_fwd(z, m.head);
+                    }
+                })
             })
             __syncthreads();
         }
@@ -336,15 +338,17 @@ __global__ __launch_bounds__(256, 2) void mlp_backward_kernel(nefii_mlp m, const
             zero_acc(acc);
             gemm_block(lds.X, XS, L.n_pad >> 3, reinterpret_cast<const float4 *>(L.w_bwd), NTs, wave, lane, ntw, acc);
             __syncthreads();
-            NEFII_FOR_ACC(acc, ntw, {
-                const bool live = (base + row) < n;
-                float v = 0.f;
-                if (live) {
-                    const float hprev = stash[((size_t)(l - 1) * n + base + row) * stash_stride + col];
-                    v = val * act_bwd_from_out(hprev, m.act);
-                    dz[((size_t)(l - 1) * n + base + row) * dz_stride + col] = v;
-                }
-                lds.X[row * XS + col] = v;
+            NEFII_ACT_SWITCH(m.act, {
+                NEFII_FOR_ACC(acc, ntw, {
+                    const bool live = (base + row) < n;
+                    float v = 0.f;
+                    if (live) {
+                        const float hprev = stash[((size_t)(l - 1) * n + base + row) * stash_stride + col];
+                        v = val * act_bwd_from_out(hprev, ACT);
+                        dz[((size_t)(l - 1) * n + base + row) * dz_stride + col] = v;
+                    }
+                    lds.X[row * XS + col] = v;
+                })
             })
             __syncthreads();
         }
@@ -482,19 +486,21 @@ __global__ __launch_bounds__(256, 1) void sdf_value_grad_kernel(nefii_mlp m, con
             int ntw;
             layer_gemm(L, lds.X, lds.E, L.w_fwd, L.n_pad >> 5, acc, ntw);
             __syncthreads();
-            NEFII_FOR_ACC(acc, ntw, {
-                const float z = val + L.bias[col];
-                const bool live = (base + row) < n;
-                if (l < Lm1) {
-                    const float hval = act_fwd(z, m.act);
-                    lds.X[row * XS + col] = hval;
-                    if (live) ws[((size_t)l * n + base + row) * ws_stride + col] = hval;
-                    if (l == Lm1 - 1 && feat_out && live && col < L.n_out)
-                        feat_out[(size_t)(base + row) * feat_stride + col] = hval;
-                } else {
-                    if (live && col < L.n_out) sdf_out[(size_t)(base + row) * out_stride + col] = z;
-                    lds.X[row * XS + col] = (col == 0) ? 1.f : 0.f;   // seed d sdf / d z_{L-1}
-                }
+            NEFII_ACT_SWITCH(m.act, {
+                NEFII_FOR_ACC(acc, ntw, {
+                    const float z = val + L.bias[col];
+                    const bool live = (base + row) < n;
+                    if (l < Lm1) {
+                        const float hval = act_fwd(z, ACT);
+                        lds.X[row * XS + col] = hval;
+                        if (live) ws[((size_t)l * n + base + row) * ws_stride + col] = hval;
+                        if (l == Lm1 - 1 && feat_out && live && col < L.n_out)
+                            feat_out[(size_t)(base + row) * feat_stride + col] = hval;
+                    } else {
+                        if (live && col < L.n_out) sdf_out[(size_t)(base + row) * out_stride + col] = z;
+                        lds.X[row * XS + col] = (col == 0) ? 1.f : 0.f;   // seed d sdf / d z_{L-1}
+                    }
+                })
             })
             __syncthreads();
         }
@@ -519,18 +525,20 @@ __global__ __launch_bounds__(256, 1) void sdf_value_grad_kernel(nefii_mlp m, con
             zero_acc(acc);
             gemm_block(lds.X, XS, L.n_pad >> 3, wb, NTs, wave, lane, ntw, acc);
             __syncthreads();
-            NEFII_FOR_ACC(acc, ntw, {
-                if (col < L.k_x) {
-                    const bool live = (base + row) < n;
-                    float v = 0.f;
-                    if (live && l > 0) {
-                        const float hprev = ws[((size_t)(l - 1) * n + base + row) * ws_stride + col];
-                        v = val * act_bwd_from_out(hprev, m.act);
+            NEFII_ACT_SWITCH(m.act, {
+                NEFII_FOR_ACC(acc, ntw, {
+                    if (col < L.k_x) {
+                        const bool live = (base + row) < n;
+                        float v = 0.f;
+                        if (live && l > 0) {
+                            const float hprev = ws[((size_t)(l - 1) * n + base + row) * ws_stride + col];
+                            v = val * act_bwd_from_out(hprev, ACT);
+                        }
+                        lds.X[row * XS + col] = v;
+                    } else {
+                        GE[row * ES + (col - L.k_x)] += val;
                     }
-                    lds.X[row * XS + col] = v;
-                } else {
-                    GE[row * ES + (col - L.k_x)] += val;
-                }
+                })
             })
             __syncthreads();
         }
@@ -589,19 +597,21 @@ __global__ __launch_bounds__(256, 1) void sdf_value_grad16_kernel(nefii_mlp m, c
             int ntw;
             layer_gemm16(L, lds, L.n_pad >> 5, acc, ntw);
             __syncthreads();
-            NEFII_FOR_ACC(acc, ntw, {
-                const float z = val * inv_scale + L.bias[col];
-                const bool live = (base + row) < n;
-                if (l < Lm1) {
-                    const float hval = act_fwd(z, m.act);
-                    split16a(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
-                    if (live) ws[((size_t)l * n + base + row) * ws_stride + col] = hval;
-                    if (l == Lm1 - 1 && feat_out && live && col < L.n_out)
-                        feat_out[(size_t)(base + row) * feat_stride + col] = hval;
-                } else {
-                    if (live && col < L.n_out) sdf_out[(size_t)(base + row) * out_stride + col] = z;
-                    split16a(col == 0 ? 1.f : 0.f, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);   // seed
-                }
+            NEFII_ACT_SWITCH(m.act, {
+                NEFII_FOR_ACC(acc, ntw, {
+                    const float z = val * inv_scale + L.bias[col];
+                    const bool live = (base + row) < n;
+                    if (l < Lm1) {
+                        const float hval = act_fwd(z, ACT);
+                        split16a(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                        if (live) ws[((size_t)l * n + base + row) * ws_stride + col] = hval;
+                        if (l == Lm1 - 1 && feat_out && live && col < L.n_out)
+                            feat_out[(size_t)(base + row) * feat_stride + col] = hval;
+                    } else {
+                        if (live && col < L.n_out) sdf_out[(size_t)(base + row) * out_stride + col] = z;
+                        split16a(col == 0 ? 1.f : 0.f, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);   // seed
+                    }
+                })
             })
             __syncthreads();
         }
@@ -623,19 +633,21 @@ __global__ __launch_bounds__(256, 1) void sdf_value_grad16_kernel(nefii_mlp m, c
             zero_acc(acc);
             gemm_block16(lds.Xh, lds.Xl, XS16, L.n_pad >> 4, wb, NTs, wave, lane, ntw, acc);
             __syncthreads();
-            NEFII_FOR_ACC(acc, ntw, {
-                const float g = val * inv_scale;
-                if (col < L.k_x) {
-                    const bool live = (base + row) < n;
-                    float v = 0.f;
-                    if (live && l > 0) {
-                        const float hprev = ws[((size_t)(l - 1) * n + base + row) * ws_stride + col];
-                        v = g * act_bwd_from_out(hprev, m.act);
+            NEFII_ACT_SWITCH(m.act, {
+                NEFII_FOR_ACC(acc, ntw, {
+                    const float g = val * inv_scale;
+                    if (col < L.k_x) {
+                        const bool live = (base + row) < n;
+                        float v = 0.f;
+                        if (live && l > 0) {
+                            const float hprev = ws[((size_t)(l - 1) * n + base + row) * ws_stride + col];
+                            v = g * act_bwd_from_out(hprev, ACT);
+                        }
+                        split16a(v, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                    } else {
+                        GE[row * ES + (col - L.k_x)] += g;
                     }
-                    split16a(v, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
-                } else {
-                    GE[row * ES + (col - L.k_x)] += g;
-                }
+                })
             })
             __syncthreads();
         }

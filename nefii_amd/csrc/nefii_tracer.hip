@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int
             layer_gemm(L, lds.X, lds.E, L.w_fwd, L.n_pad >> 5, acc, ntw);
             __syncthreads();
             if (l < Lm1) {
-                NEFII_FOR_ACC(acc, ntw, { lds.X[row * XS + col] = act_fwd(val + L.bias[col], m.act); })
+                NEFII_ACT_SWITCH(m.act, { NEFII_FOR_ACC(acc, ntw, { lds.X[row * XS + col] = act_fwd(val + L.bias[col], ACT); }) })
             } else {
                 NEFII_FOR_ACC(acc, ntw, {
                     if (col == 0 && dest[row]) *dest[row] = val + L.bias[0];
@@ -508,9 +508,11 @@ __global__ __launch_bounds__(256, 2) void eval_kernel16(Params P, nefii_mlp m, i
             layer_gemm16(L, lds, L.n_pad >> 5, acc, ntw);
             __syncthreads();
             if (l < Lm1) {
-                NEFII_FOR_ACC(acc, ntw, {
-                    const float hval = act_fwd(val * inv_scale + L.bias[col], m.act);
-                    split16a(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                NEFII_ACT_SWITCH(m.act, {
+                    NEFII_FOR_ACC(acc, ntw, {
+                        const float hval = act_fwd(val * inv_scale + L.bias[col], ACT);
+                        split16a(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
+                    })
                 })
             } else {
                 NEFII_FOR_ACC(acc, ntw, {
@@ -538,18 +540,20 @@ __device__ __forceinline__ void sdf_tile16w(const nefii_mlp &m, Lds16w &lds, con
         __syncthreads();
         if (l < Lm1) {
             const float k16 = inv_scale * A16_SCALE;
-            NEFII_FOR_ACC_WT(acc, nct, L.n_pad >> 5, {
-                const float4v b = *reinterpret_cast<const float4v *>(L.bias + f0);
-                float4v hs;       // A16_SCALE * activation
-                _Pragma("unroll") for (int k = 0; k < 4; ++k) {
-                    const float zs = __builtin_fmaf(v[k], k16, b[k] * A16_SCALE);
-                    hs[k] = m.act == NEFII_ACT_SOFTPLUS100 ? softplus100_s16(zs)
-                                                           : act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
-                }
-                const half4 hi = __builtin_convertvector(hs, half4);
-                const half4 lo = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
-                *reinterpret_cast<half4 *>(&lds.Xh[query * XS16 + f0]) = hi;
-                *reinterpret_cast<half4 *>(&lds.Xl[query * XS16 + f0]) = lo;
+            NEFII_ACT_SWITCH(m.act, {
+                NEFII_FOR_ACC_WT(acc, nct, L.n_pad >> 5, {
+                    const float4v b = *reinterpret_cast<const float4v *>(L.bias + f0);
+                    float4v hs;       // A16_SCALE * activation
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k) {
+                        const float zs = __builtin_fmaf(v[k], k16, b[k] * A16_SCALE);
+                        hs[k] = ACT == NEFII_ACT_SOFTPLUS100 ? softplus100_s16(zs)
+                                                             : act_fwd(zs * (1.f / A16_SCALE), ACT) * A16_SCALE;
+                    }
+                    const half4 hi = __builtin_convertvector(hs, half4);
+                    const half4 lo = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+                    *reinterpret_cast<half4 *>(&lds.Xh[query * XS16 + f0]) = hi;
+                    *reinterpret_cast<half4 *>(&lds.Xl[query * XS16 + f0]) = lo;
+                })
             })
         } else {
             NEFII_FOR_ACC_WT(acc, nct, L.n_pad >> 5, {
