@@ -171,19 +171,21 @@ def main():
     step = TrainStep(model, lc, world_size=world, secondary_train_interval=10 if indirect else 0,
                      secondary_batch_size=1024, num_rays=w['num_rays'], graph=use_graph)
 
+    # NEFII_BENCH_PREFETCH=1 (default): every step also enqueues the trace of the next batch (TrainStep.prefetch_trace)
+    nxt = inp if os.environ.get('NEFII_BENCH_PREFETCH', '1') != '0' else None
     for _ in range(args.warmup):
-        step(inp, gt)
+        step(inp, gt, nxt)
     # the graph of the step's tail is captured once per padded hit count, after 3 eager steps: with fewer warm-up steps
     # than that, run the missing ones (still untimed) so that no capture lands in the timed region
     priming = max(0, step.graph_after + 1 - args.warmup) if use_graph else 0     # the same count on every rank
     for _ in range(priming):
-        step(inp, gt)
+        step(inp, gt, nxt)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out, lo = step(inp, gt)
+        out, lo = step(inp, gt, nxt)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,11 +201,11 @@ def main():
     # geometry (RayTracing.skip_min_sdf_search; same gradients, different mask_loss value)
     model.ray_tracer.skip_min_sdf_search = True
     for _ in range(3):
-        step(inp, gt)
+        step(inp, gt, nxt)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     for _ in range(max(args.steps // 2, 1)):
-        step(inp, gt)
+        step(inp, gt, nxt)
     torch.cuda.synchronize()
     ms_skip = (time.perf_counter() - t2) / max(args.steps // 2, 1) * 1e3
     model.ray_tracer.skip_min_sdf_search = False
@@ -282,6 +284,9 @@ def main():
                                       'indirect OFF (closed-form SG)' if mc.get('render_type', 'sg') == 'sg'
                                       else 'MC direct + near-field indirect ON'),
                        'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
+                       'step_graph': bool(use_graph),
+                       'trace_prefetch': nxt is not None,     # batch i+1 is traced beside the tail of batch i
+
                        'loss': float(lo['loss'].item())},
             'roofline': roofline,
         }

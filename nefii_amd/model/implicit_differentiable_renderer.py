@@ -285,6 +285,15 @@ class IDRNetwork(nn.Module):
         with torch.no_grad():
             points, network_object_mask, dists = self.ray_tracer(sdf=self.implicit_network, cam_loc=cam_loc,
                                                                  object_mask=object_mask, ray_directions=ray_dirs)
+        ctx = {'points': points, 'network_object_mask': network_object_mask, 'object_mask': object_mask,
+               'ray_dirs': ray_dirs.reshape(-1, 3), 'multi': shape}
+        return self.attach_surface(ctx)
+
+    def attach_surface(self, ctx):
+        """SDF value (and, for small batches, features and gradient) at the traced points - the part of trace_head that
+        has to be redone when a trace enqueued ahead of time turns out to need more rounds (training/step.py)."""
+        points = ctx['points']
+        with torch.no_grad():
             # the tracer already returns cam + dist * dir (reference recomputes it, :352).
             # Small batches (<= one 32-point tile per CU) are latency-bound: one value+feature+gradient pass over ALL
             # rays costs the same as the pass over the hits alone and replaces the separate SDF forward.
@@ -294,8 +303,8 @@ class IDRNetwork(nn.Module):
                 sdf_output = pre[0]
             else:
                 sdf_output = self.implicit_network(points)[:, 0:1]
-        return {'points': points, 'network_object_mask': network_object_mask, 'object_mask': object_mask,
-                'sdf_output': sdf_output, 'pre': pre, 'ray_dirs': ray_dirs.reshape(-1, 3), 'multi': shape}
+        ctx['sdf_output'], ctx['pre'] = sdf_output, pre
+        return ctx
 
     def shade_tail(self, ctx, idx, dst=None):
         """Shading of the compacted hit rays `idx` and assembly of the output dict (:358-501).

@@ -41,6 +41,8 @@ class RayTracing(nn.Module):
         # its eval-mode schedule): same gradients and parameter trajectory, different mask_loss value.  Default False
         # keeps the reference's outputs.
         self.skip_min_sdf_search = False
+        # a list: traces append their deferred round-prefix checks instead of syncing (ops.trace_rays `deferred`)
+        self.deferred_checks = None
 
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
@@ -91,7 +93,8 @@ class RayTracing(nn.Module):
         res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs,
                              object_mask.reshape(-1), self._lin, steps, want_counters=self.collect_counters,
                              rounds_state=state,
-                             groups=self.stream_groups or 1)
+                             groups=self.stream_groups or 1,
+                             deferred=self.deferred_checks if state is not None else None)
         if self.collect_counters:
             self.last_counters = res[3]
             self.counter_sum = res[3].clone() if self.counter_sum is None else self.counter_sum + res[3]

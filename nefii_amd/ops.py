@@ -285,14 +285,19 @@ def _trace_streams(dev, n):
 
 
 def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_steps=None, want_counters=False,
-               rounds_state=None, groups=1):
+               rounds_state=None, groups=1, deferred=None):
     """RayTracing.forward for per-ray origins.  Returns points [n,3], hit (bool [n]), dists [n] (+ counters).
 
     groups > 1: the rays are cut into that many contiguous chunks that run their rounds on separate HIP streams
     (nefii_trace_rays_groups).  Rays are independent, so the results are bit-identical; the latency-bound rounds of a
     small batch (fewer 64-query tiles than CUs, one tile time per round regardless) of different chunks then overlap
     on the chip.  On MI355X the dense rounds lose as much as that gains (RayTracing.stream_groups), so it is off by
-    default."""
+    default.
+
+    deferred (a list, with rounds_state): the call enqueues the guessed round prefix and returns WITHOUT reading the
+    counters back; it appends a callable that, invoked once the work has completed, tells whether that prefix was the
+    whole trace (and refreshes the guess).  For callers that trace ahead of time on a side stream
+    (training/step.py:prefetch_trace) and cannot afford a host sync there."""
     lib = _lib.lib()
     n = origins.shape[0]
     dev = origins.device
@@ -357,6 +362,24 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
             guess = rounds if rounds_state.guess is None else max(2, min(rounds, rounds_state.guess))
             run(everyone, 0, guess)
             join()
+            if deferred is not None:
+                def check():
+                    """call once the enqueued prefix has completed: None if it was the whole trace, else the remaining
+                    rounds are run (same streams, same workspaces) and the refreshed (points, hit, dists) returned"""
+                    host = counters.cpu()
+                    again = [g for g in everyone if guess < rounds and int(host[g, guess - 1, :3].sum()) > 0]
+                    if again:
+                        run(again, guess, 0)
+                        for st in streams:
+                            st.synchronize()
+                        host = counters.cpu()
+                    busy = torch.nonzero(host[:, :, :3].sum(dim=(0, 2))).flatten()
+                    rounds_state.guess = (int(busy[-1]) if busy.numel() else 0) + 3
+                    return (pts, hit.bool(), dist) if again else None
+                deferred.append(check)
+                if want_counters:
+                    return pts, hit.bool(), dist, counters.sum(dim=0)
+                return pts, hit.bool(), dist
             host = counters.cpu()                            # the one host sync (the caller syncs next anyway)
             if guess < rounds:
                 again = [g for g in everyone if int(host[g, guess - 1, :3].sum()) > 0]

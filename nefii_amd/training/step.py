@@ -116,6 +116,7 @@ class TrainStep:
         self.graph_bucket, self.graph_after = int(graph_bucket), int(graph_after)
         self._graphs = {}
         self._eager_steps = 0     # captures need an initialised optimiser state: the first steps run eagerly
+        self._prefetch, self._trace_stream = None, None
         kw = dict(fused=fused, capturable=True) if self.graph else dict(fused=fused)
         if self.graph:      # a captured Adam reads its learning rate from device memory: the schedulers fill it in place
             dev = next(model.parameters()).device
@@ -170,8 +171,51 @@ class TrainStep:
         self.idr_scheduler.step()
         self.sg_scheduler.step()
 
-    def _graph_step(self, model_input, ground_truth):
-        ctx = self.model.trace_head(model_input)
+    # ---- trace of the NEXT batch beside the tail of this one -------------------------------------------------------
+    # With frozen geometry the tracer's result does not depend on any trainable parameter, so the next batch can be
+    # traced while this batch's shading / backward / Adam runs: the tail's small kernels (24-128 workgroups) fill the
+    # CUs that the tracer's latency-bound rounds (fewer tiles than CUs) leave idle.  Same arithmetic, same order of the
+    # tracer's random draws; only the schedule changes.
+    def prefetch_trace(self, model_input, after=None):
+        """after: event on the caller's stream behind which the inputs are ready (default: now).  Must not be an event
+        behind this step's tail - the trace would wait for exactly what it is meant to run beside."""
+        m = self.model
+        if not (m.training and getattr(m, 'state_freeze_geo', False) and next(m.parameters()).is_cuda):
+            return
+        if self._trace_stream is None:
+            self._trace_stream = torch.cuda.Stream()
+        self._trace_stream.wait_event(after if after is not None else torch.cuda.current_stream().record_event())
+        checks = []
+        with torch.cuda.stream(self._trace_stream):
+            m.ray_tracer.deferred_checks = checks       # no host sync inside the trace: its round-prefix check waits
+            try:
+                ctx = m.trace_head(model_input)
+            finally:
+                m.ray_tracer.deferred_checks = None
+            ev = self._trace_stream.record_event()
+        self._prefetch = (model_input, ctx, ev, checks)
+
+    def _take_prefetched(self, model_input):
+        pf, self._prefetch = self._prefetch, None
+        if pf is None or pf[0] is not model_input:
+            return None
+        _, ctx, ev, checks = pf
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        ev.synchronize()
+        for chk in checks:
+            more = chk()
+            if more is not None:        # the guessed round prefix was too short: the check ran the remaining rounds
+                ctx['points'], ctx['network_object_mask'] = more[0], more[1]
+                ctx = self.model.attach_surface(ctx)
+        for v in list(ctx.values()) + list(ctx['pre'] or ()):
+            if torch.is_tensor(v):
+                v.record_stream(cur)          # allocated on the trace stream, consumed here
+        return ctx
+
+    def _graph_step(self, model_input, ground_truth, ctx=None):
+        if ctx is None:
+            ctx = self.model.trace_head(model_input)
         idx = torch.nonzero(ctx['network_object_mask']).flatten()      # the step's one host sync
         n_hit, n_all = idx.numel(), ctx['points'].shape[0]
         if n_hit == 0:
@@ -198,17 +242,28 @@ class TrainStep:
             self.sg_optimizer.step()
         return g.out, g.lo
 
-    def __call__(self, model_input, ground_truth):
+    def __call__(self, model_input, ground_truth, next_input=None):
+        """next_input (optional): the model_input of the following call (the same dict object must then be passed to
+        it) - its rays are traced concurrently with this step's tail, see prefetch_trace."""
         self._pre_iteration()
+        ctx = self._take_prefetched(model_input)
+        if next_input is not None:
+            m = self.model
+            if ctx is None and m.training and getattr(m, 'state_freeze_geo', False):
+                ctx = m.trace_head(model_input)         # own trace first: the tracer's random draws keep their order
+            self.prefetch_trace(next_input)             # enqueued now: it runs beside everything this call does next
         if self.graph and self._eager_steps >= self.graph_after and self.model.training:
-            res = self._graph_step(model_input, ground_truth)
+            res = self._graph_step(model_input, ground_truth, ctx)
             if res is not None:
                 if self.secondary_train_interval > 0 and self.cur_iter % self.secondary_train_interval == 0:
                     self.train_with_secondary(res[0])
                 self._post_iteration()
                 return res
         self._eager_steps += 1
-        out = self.model(model_input)
+        if ctx is not None:
+            out = self.model.shade_tail(ctx, torch.nonzero(ctx['network_object_mask']).flatten())
+        else:
+            out = self.model(model_input)
         lo = self.loss(out, ground_truth)
         self.idr_optimizer.zero_grad()
         self.sg_optimizer.zero_grad()

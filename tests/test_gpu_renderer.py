@@ -499,3 +499,36 @@ def test_bench_two_processes_share_one_gpu():
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['value'] > 0
     assert d['config']['primary_rays_per_step_per_gpu'] == 4096
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_prefetched_trace_gives_the_same_steps(graph):
+    """TrainStep(next_input=...): tracing the next batch beside this batch's tail changes the schedule, not the result -
+    same losses and parameter trajectory as the plain sequence of steps, also when a prefetch is not consumed."""
+    from nefii_amd.training.step import TrainStep
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=4, bumpy=0.02)
+    lc = syn.loss_conf('physg')
+    lc['idr_rgb_weight'] = 1.0
+    batches = []
+    for it in range(6):
+        inp, gt = syn.make_inputs(256, (64, 64), 100.0 + 5 * it, (0.2, 0.1, 2.0 + 0.04 * it), -1, seed=30 + it)
+        batches.append((to_dev(inp), {'rgb': gt.to(DEV)}))
+    runs = []
+    for prefetch in (False, True):
+        m = build_model(mc, sd, True)
+        m.ray_tracer.minsdf_steps_override = [torch.rand(100, generator=torch.Generator().manual_seed(3 + i)) for i in range(6)]
+        st = TrainStep(m, lc, graph=graph, graph_bucket=64, graph_after=2)
+        losses = []
+        for i, (inp, gt) in enumerate(batches):
+            nxt = batches[i + 1][0] if prefetch and i + 1 < len(batches) and i != 3 else None     # one step without
+            out, lo = st(inp, gt, nxt)
+            losses.append({k: v.item() for k, v in lo.items()})
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+    (l0, p0), (l1, p1) = runs
+    for a, b in zip(l0, l1):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-4 * max(abs(a[k]), 1e-3), (k, a[k], b[k])
+    for k in p0:
+        if p0[k].dtype.is_floating_point:
+            assert rel_l2(p1[k], p0[k]) < 1e-4, (k, rel_l2(p1[k], p0[k]))
