@@ -56,6 +56,7 @@ class IDRTrainRunner:
         self.freeze_diffuse = kwargs.get('freeze_diffuse', False)
         self.ckpt_freq = kwargs.get('ckpt_freq', self.conf.get_int('train.ckpt_freq', default=5000))
         self.log_freq = kwargs.get('log_freq', 50)
+        self.prefetch = kwargs.get('prefetch', True)       # TrainStep.prefetch_trace (frozen geometry only)
         if kwargs.get('train_cameras', False):
             raise NotImplementedError('camera optimisation is outside the Step-2 hot path')
 
@@ -191,15 +192,26 @@ class IDRTrainRunner:
                 self.save_checkpoints(epoch)
                 return self.history
             self.train_sampler_generator.manual_seed(epoch)
-            for data_index, (indices, model_input, ground_truth) in enumerate(self.train_dataloader):
-                if getattr(self.loss, 'sample_each_iter', False):
-                    self._resample()
-                model_input = {k: v.to(self.device) for k, v in model_input.items()}
-                ground_truth = {'rgb': ground_truth['rgb'].to(self.device)}
+            resample = getattr(self.loss, 'sample_each_iter', False)
+
+            def batches():       # one batch of lookahead: TrainStep traces batch i+1 beside the tail of batch i
+                prev = None
+                for item in self.train_dataloader:
+                    if resample:
+                        self._resample()
+                    item = (item[0], {k: v.to(self.device) for k, v in item[1].items()},
+                            {'rgb': item[2]['rgb'].to(self.device)})
+                    if prev is not None:
+                        yield prev, (None if resample else item[1])
+                    prev = item
+                if prev is not None:
+                    yield prev, None
+
+            for data_index, ((indices, model_input, ground_truth), next_input) in enumerate(batches()):
                 it = self.step.cur_iter
                 if self.rank == 0 and it % self.ckpt_freq == 0:                      # :695-696 (before the step)
                     self.save_checkpoints(epoch)
-                _, lo = self.step(model_input, ground_truth)
+                _, lo = self.step(model_input, ground_truth, next_input if self.prefetch else None)
                 if it % self.log_freq == 0:
                     loss = lo['loss'].item()
                     if not np.isfinite(loss):                                       # :752-755
