@@ -566,20 +566,21 @@ __device__ __forceinline__ void pload(typename P16<NW>::Stage &st, PCursor &c) {
     c.off = c.off == c.bytes ? 0u : c.off;
 }
 
+template <int RT>
 __device__ __forceinline__ void pload_a(AStage16w &st, const _Float16 *ah, const _Float16 *al, int s) {
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         st.ah[rt] = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP16 + 16 * s);
         st.al[rt] = *reinterpret_cast<const half8 *>(al + rt * 32 * XP16 + 16 * s);
     }
 }
 
-template <int NW>
+template <int NW, int RT>
 __device__ __forceinline__ void pmfma(const AStage16w &sa, const typename P16<NW>::Stage &sb,
-                                      f32x16 (&acc)[2 * P16<NW>::NC]) {
+                                      f32x16 (&acc)[RT * P16<NW>::NC]) {
     constexpr int NC = P16<NW>::NC;
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             f32x16 &a = acc[rt * NC + c];
@@ -591,10 +592,10 @@ __device__ __forceinline__ void pmfma(const AStage16w &sa, const typename P16<NW
 
 // one k-step: prefetch the fragments NB-1 steps ahead into the stage consumed last step, read the next step's
 // activation fragments, multiply this step's.  J = stage of this step, U = its parity (activation double buffer).
-template <int NW, int J, int U>
+template <int NW, int RT, int J, int U>
 __device__ __forceinline__ void pstep(typename P16<NW>::Stage (&b)[P16<NW>::NB], AStage16w (&a)[2], PCursor &cur,
                                       const _Float16 *ah, const _Float16 *al, int s,
-                                      f32x16 (&acc)[2 * P16<NW>::NC]) {
+                                      f32x16 (&acc)[RT * P16<NW>::NC]) {
     constexpr int NB = P16<NW>::NB;
     // Issue order inside the step: the MFMAs lead and the step's memory instructions (prefetch of the stage consumed last
     // step, next step's activation fragments) are spread between them, two MFMAs per instruction.  Issuing the eight
@@ -602,8 +603,8 @@ __device__ __forceinline__ void pstep(typename P16<NW>::Stage (&b)[P16<NW>::NB],
     // the tile time (s_memtime stamps, tools/stamps.py); the closing sched_barrier keeps the compiler from sinking
     // a prefetch past the step (it otherwise moves every load down to its use and drains the pipeline).
     pload<NW>(b[(J + NB - 1) % NB], cur);
-    pload_a(a[(U + 1) & 1], ah, al, s + 1);
-    pmfma<NW>(a[U & 1], b[J], acc);
+    pload_a<RT>(a[(U + 1) & 1], ah, al, s + 1);
+    pmfma<NW, RT>(a[U & 1], b[J], acc);
 #pragma unroll
     for (int i = 0; i < 2 * P16<NW>::NC; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);    // 2 MFMA
@@ -617,36 +618,36 @@ __device__ __forceinline__ void pstep(typename P16<NW>::Stage (&b)[P16<NW>::NB],
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NW, int J0>
+template <int NW, int RT, int J0>
 __device__ __forceinline__ void pstep4(typename P16<NW>::Stage (&b)[P16<NW>::NB], AStage16w (&a)[2], PCursor &cur,
                                        const _Float16 *ah, const _Float16 *al, int s,
-                                       f32x16 (&acc)[2 * P16<NW>::NC]) {
-    pstep<NW, J0, 0>(b, a, cur, ah, al, s, acc);
-    pstep<NW, J0 + 1, 1>(b, a, cur, ah, al, s + 1, acc);
-    pstep<NW, J0 + 2, 0>(b, a, cur, ah, al, s + 2, acc);
-    pstep<NW, J0 + 3, 1>(b, a, cur, ah, al, s + 3, acc);
+                                       f32x16 (&acc)[RT * P16<NW>::NC]) {
+    pstep<NW, RT, J0, 0>(b, a, cur, ah, al, s, acc);
+    pstep<NW, RT, J0 + 1, 1>(b, a, cur, ah, al, s + 1, acc);
+    pstep<NW, RT, J0 + 2, 0>(b, a, cur, ah, al, s + 2, acc);
+    pstep<NW, RT, J0 + 3, 1>(b, a, cur, ah, al, s + 3, acc);
 }
 
 // k-loop of one layer whose first k-step sits in stage PH; ks is a multiple of 4 (PH is 0, or 4 with 8 stages)
-template <int NW, int PH>
+template <int NW, int RT, int PH>
 __device__ __forceinline__ void pgemm(int ks, typename P16<NW>::Stage (&b)[P16<NW>::NB], AStage16w (&a)[2],
                                       PCursor &cur, const _Float16 *ah, const _Float16 *al,
-                                      f32x16 (&acc)[2 * P16<NW>::NC]) {
+                                      f32x16 (&acc)[RT * P16<NW>::NC]) {
     constexpr int NB = P16<NW>::NB;
     static_assert((NB == 4 && PH == 0) || (NB == 8 && (PH == 0 || PH == 4)), "stage bookkeeping");
     int s = 0;
     if constexpr (NB == 4) {
-        for (; s < ks; s += 4) pstep4<NW, 0>(b, a, cur, ah, al, s, acc);
+        for (; s < ks; s += 4) pstep4<NW, RT, 0>(b, a, cur, ah, al, s, acc);
     } else {
         if (PH == 4) {
-            pstep4<NW, 4>(b, a, cur, ah, al, 0, acc);
+            pstep4<NW, RT, 4>(b, a, cur, ah, al, 0, acc);
             s = 4;
         }
         for (; s + 8 <= ks; s += 8) {
-            pstep4<NW, 0>(b, a, cur, ah, al, s, acc);
-            pstep4<NW, 4>(b, a, cur, ah, al, s + 4, acc);
+            pstep4<NW, RT, 0>(b, a, cur, ah, al, s, acc);
+            pstep4<NW, RT, 4>(b, a, cur, ah, al, s + 4, acc);
         }
-        if (s < ks) pstep4<NW, 0>(b, a, cur, ah, al, s, acc);
+        if (s < ks) pstep4<NW, RT, 0>(b, a, cur, ah, al, s, acc);
     }
 }
 
@@ -675,15 +676,17 @@ __device__ __forceinline__ void prime16p(const nefii_mlp &m, typename P16<NW>::S
     for (int u = 0; u < P16<NW>::NB - 1; ++u) pload<NW>(b[u], cur);
 }
 
+// One tile of 32 * RT queries through the whole SDF network (RT = 2: the 64-query tile; RT = 1: 32 queries, half the
+// matrix work and epilogue on the same fragment stream - for rounds with fewer 64-query tiles than half the CUs).
 // One 64-query tile through the whole SDF network.  Stage/cursor state runs on from tile to tile (ph = stage of the
 // next k-step).  raw[64][9]: the points (overwritten with the last layer's partial sums); dest[64]: where each SDF
 // value goes (nullptr = padding row).
 // epilogue arithmetic of one wave's 64 x 32*NC block: bias, activation, (16 x) hi/lo split, packed four features at a
 // time (transposed accumulator: lane = query, registers = 4 consecutive features x 4 groups).  FAST = Softplus(beta 100).
-template <int NW, bool FAST>
-__device__ __forceinline__ void pepilogue(const f32x16 (&acc)[2 * P16<NW>::NC], const float (&bvec)[P16<NW>::NC / 2 + 1],
-                                          float k16, int h, int act, half4 (&phi)[P16<NW>::NC * 8],
-                                          half4 (&plo)[P16<NW>::NC * 8]) {
+template <int NW, int RT, bool FAST>
+__device__ __forceinline__ void pepilogue(const f32x16 (&acc)[RT * P16<NW>::NC], const float (&bvec)[P16<NW>::NC / 2 + 1],
+                                          float k16, int h, int act, half4 (&phi)[P16<NW>::NC * 4 * RT],
+                                          half4 (&plo)[P16<NW>::NC * 4 * RT]) {
     constexpr int NC = P16<NW>::NC;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -696,7 +699,7 @@ __device__ __forceinline__ void pepilogue(const f32x16 (&acc)[2 * P16<NW>::NC], 
                 bs[k] = __builtin_bit_cast(float,
                                            __builtin_amdgcn_ds_bpermute(4 * (32 * (c & 1) + 8 * g + 4 * h + k), bsrc));
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const f32x16 &av = acc[rt * NC + c];
                 float4v hs;
 #pragma unroll
@@ -705,8 +708,8 @@ __device__ __forceinline__ void pepilogue(const f32x16 (&acc)[2 * P16<NW>::NC], 
                     hs[k] = FAST ? softplus100_s16(zs) : act_fwd(zs * (1.f / A16_SCALE), act) * A16_SCALE;
                 }
                 const half4 hi = __builtin_convertvector(hs, half4);
-                phi[(c * 4 + g) * 2 + rt] = hi;
-                plo[(c * 4 + g) * 2 + rt] = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+                phi[(c * 4 + g) * RT + rt] = hi;
+                plo[(c * 4 + g) * RT + rt] = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
             }
         }
     }
@@ -722,7 +725,7 @@ __device__ int g_stamp_tile;
 #define NEFII_STAMP(i)
 #endif
 
-template <int NW>
+template <int NW, int RT>
 __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, float *raw, float *const *dest,
                                             typename P16<NW>::Stage (&b)[P16<NW>::NB], PCursor &cur, int &ph, int ke) {
     constexpr int NC = P16<NW>::NC, NB = P16<NW>::NB;
@@ -748,31 +751,31 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
         float bvec[NC / 2 + 1];
 #pragma unroll
         for (int i = 0; i < NC / 2; ++i) bvec[i] = bp[64 * i];
-        f32x16 acc[2 * NC];
+        f32x16 acc[RT * NC];
 #pragma unroll
-        for (int j = 0; j < 2 * NC; ++j)
+        for (int j = 0; j < RT * NC; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
         AStage16w a[2];
-        pload_a(a[0], ah, al, 0);
+        pload_a<RT>(a[0], ah, al, 0);
         if (NB == 4 || ph == 0)
-            pgemm<NW, 0>(ks, b, a, cur, ah, al, acc);
+            pgemm<NW, RT, 0>(ks, b, a, cur, ah, al, acc);
         else
-            pgemm<NW, (NB == 8 ? 4 : 0)>(ks, b, a, cur, ah, al, acc);
+            pgemm<NW, RT, (NB == 8 ? 4 : 0)>(ks, b, a, cur, ah, al, acc);
         ph = (ph + ks) % NB;
         NEFII_STAMP(1);
         // epilogue, arithmetic first: activation and hi/lo split of the wave's 64 x 64 block, packed in registers (the
         // accumulators' own count).  It needs nothing the other waves still read, so it runs BEFORE the barrier: the
         // SIMD partner that lost the matrix pipe arbitration is still in its k-loop then (MFMA beside VALU), see
         // tools/stamps.py.  Only the stores into the activation image wait for everyone to be done reading it.
-        half4 phi[NC * 4 * 2], plo[NC * 4 * 2];
+        half4 phi[NC * 4 * RT], plo[NC * 4 * RT];
         // the activation switch sits OUTSIDE the 64-value loop: with the test inside it every value went through its own
         // scalar branch, the compiler could not interleave the values' exp -> add -> log -> fma chains, and the epilogue
         // ran at the latency of one chain per value (~120 cycles) instead of the VALU's throughput
         if (m.act == NEFII_ACT_SOFTPLUS100)
-            pepilogue<NW, true>(acc, bvec, k16, h, m.act, phi, plo);
+            pepilogue<NW, RT, true>(acc, bvec, k16, h, m.act, phi, plo);
         else
-            pepilogue<NW, false>(acc, bvec, k16, h, m.act, phi, plo);
+            pepilogue<NW, RT, false>(acc, bvec, k16, h, m.act, phi, plo);
         __syncthreads();
         NEFII_STAMP(2);
         _Float16 *xh = lds.Xh + (EP16 - L.n_pad), *xl = lds.Xl + (EP16 - L.n_pad);
@@ -782,10 +785,10 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
             for (int g = 0; g < 4; ++g) {
                 const int f0 = 32 * (NC * wave + c) + 8 * g + 4 * h;
 #pragma unroll
-                for (int rt = 0; rt < 2; ++rt) {
+                for (int rt = 0; rt < RT; ++rt) {
                     const int query = 32 * rt + r;
-                    *reinterpret_cast<half4 *>(xh + query * XP16 + f0) = phi[(c * 4 + g) * 2 + rt];
-                    *reinterpret_cast<half4 *>(xl + query * XP16 + f0) = plo[(c * 4 + g) * 2 + rt];
+                    *reinterpret_cast<half4 *>(xh + query * XP16 + f0) = phi[(c * 4 + g) * RT + rt];
+                    *reinterpret_cast<half4 *>(xl + query * XP16 + f0) = plo[(c * 4 + g) * RT + rt];
                 }
             }
         NEFII_STAMP(3);
@@ -800,27 +803,29 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
         const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
         const _Float16 *ah = ah0 + (EP16 - L.k_x), *al = al0 + (EP16 - L.k_x);
         const int ksw = (L.k_x >> 4) / NW;          // k-steps per wave
-        f32x16 acc2[2];
+        f32x16 acc2[RT];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc2[0][i] = acc2[1][i] = 0.f;
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
         for (int u = 0; u < ksw; ++u) {
             const int s = wave * ksw + u;
             const half8 wh = wl[(size_t)s * NT * 128], wlo = wl[(size_t)s * NT * 128 + 64];
             AStage16w a;
-            pload_a(a, ah, al, s);
+            pload_a<RT>(a, ah, al, s);
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a.ah[rt], acc2[rt], 0, 0, 0);
                 acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, a.ah[rt], acc2[rt], 0, 0, 0);
                 acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a.al[rt], acc2[rt], 0, 0, 0);
             }
         }
         if (h == 0) {       // feature 0 = register 0 of lanes 0..31
-            raw[wave * TILE_W + r] = acc2[0][0];
-            raw[wave * TILE_W + 32 + r] = acc2[1][0];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) raw[wave * TILE_W + 32 * rt + r] = acc2[rt][0];
         }
         __syncthreads();
-        if (threadIdx.x < TILE_W) {
+        if (threadIdx.x < 32 * RT) {
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) sum += raw[w * TILE_W + threadIdx.x];

@@ -583,8 +583,14 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, 
     }
 }
 
-// pipelined variant (mlp_tile.h "16p"): 512-wide hidden layers, fragment stream never drains
-template <int NW>
+// pipelined variant (mlp_tile.h "16p"): 512-wide hidden layers, fragment stream never drains.
+// Two instantiations are launched per round and the round's query count (known on the device only) picks the one that
+// works: RT = 2 (64-query tiles) for rounds of more than SMALL_ROUND queries, RT = 1 (32-query tiles) for the others - a
+// round with fewer 64-query tiles than half the CUs puts twice as many CUs to work on tiles with half the matrix work
+// and epilogue (the fragment stream per tile is the same: ~110 instead of ~150 us per round).  Kept as two kernels:
+// fused into one, the register allocation of the 64-query path degraded (60 spills, dense rounds +25 %).
+constexpr int64_t SMALL_ROUND = 64 * 128;
+template <int NW, int RT>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Params P, nefii_mlp m, int round) {
     __shared__ Lds16p lds;
     __shared__ float raw[TILE_W * 9];
@@ -594,7 +600,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Param
     const int n_tri = P.counters[round * 4 + 2];
     const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
     const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
-    const int64_t n_tiles = (total + TILE_W - 1) / TILE_W;
+    if ((total <= SMALL_ROUND) != (RT == 1)) return;
+    constexpr int ROWS = 32 * RT;
+    const int64_t n_tiles = (total + ROWS - 1) / ROWS;
     if (blockIdx.x >= n_tiles) return;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
@@ -603,9 +611,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Param
     int ph = 0;
     prime16p<NW>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile<TILE_W>(P, tile, total, n_single, n_sd, raw, dest);
+        decode_tile<ROWS>(P, tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
-        sdf_tile16p<NW>(m, lds, raw, dest, b, cur, ph, ke);
+        sdf_tile16p<NW, RT>(m, lds, raw, dest, b, cur, ph, ke);
     }
 }
 
@@ -634,7 +642,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void sdf_points_kernel16p
             dest[tid] = live ? out + q : nullptr;
         }
         __syncthreads();
-        sdf_tile16p<NW>(m, lds, raw, dest, b, cur, ph, ke);
+        sdf_tile16p<NW, 2>(m, lds, raw, dest, b, cur, ph, ke);
 #ifdef NEFII_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_stamp_tile = g_stamp_tile + 1;
         __syncthreads();
@@ -926,8 +934,13 @@ int launch_round(const TraceJob &J, int r, bool profile) {
             e1 = prof_event();
             (void)hipEventRecord(e0, st);
         }
-        if (J.precision == 2 && J.pipelined)
-            hipLaunchKernelGGL(eval_kernel16p<P16W>, dim3(J.eval_blocks_w), dim3(64 * P16W), 0, st, J.P, *J.sdf, r);
+        if (J.precision == 2 && J.pipelined) {
+            hipLaunchKernelGGL((eval_kernel16p<P16W, 2>), dim3(J.eval_blocks_w), dim3(64 * P16W), 0, st, J.P, *J.sdf, r);
+            HIP_CHECK_LAUNCH();
+            const int64_t small_tiles = (J.P.n * 2 + 31) / 32 < 256 ? (J.P.n * 2 + 31) / 32 : 256;   // >= SMALL_ROUND / 32
+            hipLaunchKernelGGL((eval_kernel16p<P16W, 1>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(64 * P16W),
+                               0, st, J.P, *J.sdf, r);
+        }
         else if (J.precision == 2)
             hipLaunchKernelGGL(eval_kernel16w, dim3(J.eval_blocks_w), dim3(WG_W), 0, st, J.P, *J.sdf, r);
         else if (J.precision == 1)
