@@ -82,6 +82,12 @@ __device__ __forceinline__ float act_bwd_from_out(float h, int act) {
     return -expm1f(-100.f * h);
 }
 
+// d Softplus(beta 100) / dz from the activation's OUTPUT h: sigmoid(100 z) = 1 - e^{-100 h}, on v_exp_f32 (the libm
+// expm1f of act_bwd_from_out costs ~40 instructions; absolute error here ~1e-7, the result multiplies a gradient)
+__device__ __forceinline__ float softplus100_bwd_fast(float h) {
+    return 1.f - __builtin_amdgcn_exp2f(h * (-100.f * 1.44269504088896340736f));
+}
+
 __device__ __forceinline__ float head_fwd(float v, int head) {
     switch (head) {
         case NEFII_HEAD_TANH01: return (tanhf(v) + 1.f) / 2.f;
@@ -271,7 +277,56 @@ __device__ __forceinline__ void encode_tile16(const nefii_mlp &m, const float *r
     }
 }
 
-// acc[j] += A[32 x 16*ksteps] * W for this wave's tiles.  wp: half8 index ((s*NT + t)*2 + part)*64 + lane
+// acc[j] += A[32 x 16*ksteps] * W for this wave's tiles t = wave + 4 j (j < NTW).
+// wp: half8 index ((s*NT + t)*2 + part)*64 + lane.  NB statically named register stages of weight fragments (NB-1
+// k-steps in flight: these kernels run one 32-row tile per CU and are bound by how fast one workgroup pulls its
+// 1 MiB per layer from L2), two stages of the activation fragments; the k-loop is unrolled NB times so that no stage is
+// ever copied.  Kernels using it run one workgroup of 4 waves per CU (512 registers per wave).
+#ifndef NEFII_HD
+#define NEFII_HD 4       /* measured on sdf_value_grad16: 4 / 6 / 8 stages -> 0.551 / 0.550 / 0.663 ms (8 spills) */
+#endif
+template <int NTW>
+__device__ __forceinline__ void gemm_block16_t(const _Float16 *ah, const _Float16 *al, int ksteps,
+                                               const half8 *__restrict__ wp, int NT, int wave, int lane,
+                                               f32x16 (&acc)[4]) {
+    constexpr int NB = NEFII_HD;
+    static_assert(NB >= 2 && NB % 2 == 0, "NB must be even");
+    half8 bh[NB][NTW], bl[NB][NTW];
+    half8 a_hi[2], a_lo[2];
+    auto load_b = [&](int u, int s) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) {
+            const size_t t = (size_t)s * NT + wave + 4 * j;
+            bh[u][j] = wp[(t * 2) * 64 + lane];
+            bl[u][j] = wp[(t * 2 + 1) * 64 + lane];
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < NB - 1; ++u)
+        if (u < ksteps) load_b(u, u);
+    a_hi[0] = *reinterpret_cast<const half8 *>(ah);
+    a_lo[0] = *reinterpret_cast<const half8 *>(al);
+    for (int s0 = 0; s0 < ksteps; s0 += NB) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int s = s0 + u;
+            if (s < ksteps) {
+                if (s + NB - 1 < ksteps) load_b((u + NB - 1) % NB, s + NB - 1);
+                if (s + 1 < ksteps) {
+                    a_hi[(u + 1) % 2] = *reinterpret_cast<const half8 *>(ah + 16 * (s + 1));
+                    a_lo[(u + 1) % 2] = *reinterpret_cast<const half8 *>(al + 16 * (s + 1));
+                }
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[u % 2], bh[u][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[u % 2], bl[u][j], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[u % 2], bh[u][j], acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void gemm_block16(const _Float16 *Ah, const _Float16 *Al, int a_stride, int ksteps,
                                              const half8 *__restrict__ wp, int NT, int wave, int lane, int ntw,
                                              f32x16 (&acc)[4]) {
@@ -279,52 +334,11 @@ __device__ __forceinline__ void gemm_block16(const _Float16 *Ah, const _Float16 
     const int r = lane & 31, h = lane >> 5;
     const _Float16 *ah = Ah + r * a_stride + 8 * h;
     const _Float16 *al = Al + r * a_stride + 8 * h;
-    half8 bh0[4], bl0[4], bh1[4], bl1[4], bh2[4], bl2[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        bh0[j] = bl0[j] = bh1[j] = bl1[j] = bh2[j] = bl2[j] = (half8)(_Float16)0;
-        if (j < ntw) {
-            const size_t t = wave + 4 * j;
-            bh0[j] = wp[(t * 2) * 64 + lane];
-            bl0[j] = wp[(t * 2 + 1) * 64 + lane];
-            if (ksteps > 1) {
-                bh1[j] = wp[(((size_t)NT + t) * 2) * 64 + lane];
-                bl1[j] = wp[(((size_t)NT + t) * 2 + 1) * 64 + lane];
-            }
-        }
-    }
-    half8 a_hi = *reinterpret_cast<const half8 *>(ah), a_lo = *reinterpret_cast<const half8 *>(al);
-    for (int s = 0; s < ksteps; ++s) {
-        if (s + 2 < ksteps) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (j < ntw) {
-                    const size_t t = (size_t)(s + 2) * NT + wave + 4 * j;
-                    bh2[j] = wp[(t * 2) * 64 + lane];
-                    bl2[j] = wp[(t * 2 + 1) * 64 + lane];
-                }
-        }
-        half8 n_hi = a_hi, n_lo = a_lo;
-        if (s + 1 < ksteps) {
-            n_hi = *reinterpret_cast<const half8 *>(ah + 16 * (s + 1));
-            n_lo = *reinterpret_cast<const half8 *>(al + 16 * (s + 1));
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < ntw) {
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bh0[j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, bl0[j], acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, bh0[j], acc[j], 0, 0, 0);
-            }
-        a_hi = n_hi;
-        a_lo = n_lo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bh0[j] = bh1[j];
-            bl0[j] = bl1[j];
-            bh1[j] = bh2[j];
-            bl1[j] = bl2[j];
-        }
+    switch (ntw) {          // ntw is wave-uniform; each case has fully static register indexing
+        case 1: gemm_block16_t<1>(ah, al, ksteps, wp, NT, wave, lane, acc); break;
+        case 2: gemm_block16_t<2>(ah, al, ksteps, wp, NT, wave, lane, acc); break;
+        case 3: gemm_block16_t<3>(ah, al, ksteps, wp, NT, wave, lane, acc); break;
+        default: gemm_block16_t<4>(ah, al, ksteps, wp, NT, wave, lane, acc); break;   // callers pass ntw <= 4
     }
 }
 

@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256, 1) void sdf_value_grad16_kernel(nefii_mlp m, c
                     const float z = val * inv_scale + L.bias[col];
                     const bool live = (base + row) < n;
                     if (l < Lm1) {
-                        const float hval = act_fwd(z, ACT);
+                        const float hval = ACT == NEFII_ACT_SOFTPLUS100 ? softplus100_s16(z * A16_SCALE) * (1.f / A16_SCALE) : act_fwd(z, ACT);
                         split16a(hval, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
                         if (live) ws[((size_t)l * n + base + row) * ws_stride + col] = hval;
                         if (l == Lm1 - 1 && feat_out && live && col < L.n_out)
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, 1) void sdf_value_grad16_kernel(nefii_mlp m, c
                         float v = 0.f;
                         if (live && l > 0) {
                             const float hprev = ws[((size_t)(l - 1) * n + base + row) * ws_stride + col];
-                            v = g * act_bwd_from_out(hprev, ACT);
+                            v = g * (ACT == NEFII_ACT_SOFTPLUS100 ? softplus100_bwd_fast(hprev) : act_bwd_from_out(hprev, ACT));
                         }
                         split16a(v, lds.Xh[row * XS16 + col], lds.Xl[row * XS16 + col]);
                     } else {

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int
 }
 
 // split-precision variant (3 x fp16 MFMA per k-step, mlp_tile.h)
-__global__ __launch_bounds__(256, 2) void eval_kernel16(Params P, nefii_mlp m, int round) {
+__global__ __launch_bounds__(256, 1) void eval_kernel16(Params P, nefii_mlp m, int round) {    // 81 KB of LDS: one workgroup per CU anyway
     __shared__ Lds16 lds;
     __shared__ float raw[TILE * 9];
     __shared__ float *dest[TILE];
