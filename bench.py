@@ -252,7 +252,8 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic_%s.json' % args.workload)
         kname = {'f32': 'eval_kernel', 'f16x3': 'eval_kernel16', 'f16x3w': 'eval_kernel16w'}[model.ray_tracer.precision]
         if prec == 'f16x3w' and model.implicit_network.packed(f16x3=True).w_stream is not None:
-            kname = 'eval_kernel16p'        # 512-wide nets: the pipelined stream kernel (mlp_tile.h "16p")
+            kname = 'eval_kernel16q' if model.implicit_network.packed(f16x3=True).struct.reserved == 1 else 'eval_kernel16p'
+            # 512-wide nets: the pipelined stream kernel (mlp_tile.h "16q": 16x16x32 MFMA; "16p": 32x32x16)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if tj.get('kernel') == kname:
@@ -262,7 +263,7 @@ def main():
                     'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
                     'traffic_unit': 'HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, averaged over all launches '
                                     'of the kernel incl. empty rounds; profiles/r01/pmc_traffic_*.json)',
-                    'arithmetic': ('3x v_mfma_f32_32x32x16_f16 per k-step on fp16 hi/lo operand pairs, fp32 accumulate: '
+                    'arithmetic': ('3x v_mfma_f32_{16x16x32,32x32x16}_f16 per k-step on fp16 hi/lo operand pairs, fp32 accumulate: '
                                    'achieved counts ALGORITHMIC flops (the matrix cores issue 3x that)') if split
                                   else 'v_mfma_f32_32x32x2_f32 (exact fp32)',
                     'flops_per_sdf_eval': f_eval, 'sdf_evals_per_step': queries, 'sdf_evals_executed': executed,

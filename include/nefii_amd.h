@@ -62,7 +62,8 @@ typedef struct nefii_mlp {
     int32_t enc_freqs[3];    /* positional-encoding octaves of raw inputs a,b,c; -1 = input absent
                                 (embedder.py:38-50: x, sin(2^k x), cos(2^k x), k < L) */
     int32_t feat_width;      /* per-point feature vector loaded into X before layer 0 (0 = none) */
-    int32_t reserved;
+    int32_t reserved;        /* layout of w_stream / matrix instruction of the pipelined evaluator: 0 = 32x32x16 fragments,
+                                1 = 16x16x32 fragments (8 % faster per tile on MI355X; what nefii_amd.ops packs) */
     const void *w_stream;    /* optional (SDF nets, split precision): the hidden layers' w_f16x3 fragments re-packed as one
                                 stream per wave for the pipelined tile evaluator (nefii_pack_sdf_stream), or NULL */
     nefii_layer layer[NEFII_MAX_LAYERS];
@@ -143,7 +144,9 @@ typedef struct nefii_tracer_params {
 } nefii_tracer_params;
 
 /* The pipelined evaluator behind nefii_trace_rays (precision 2) and nefii_sdf_eval reads the hidden layers' fragments as
- * ONE stream per wave: [8 waves][k-steps of layer 0, 1, ... back to back][hi/lo of the wave's two column tiles][64][8].
+ * ONE stream per wave, 4 KiB per 16-deep unit of the layer sequence: [8 waves][units][4 fragments][64 lanes][8 halves];
+ * the fragments are 32x32x16 ones (hi/lo of the wave's two column tiles) or, with nefii_mlp.reserved == 1, 16x16x32 ones
+ * (hi/lo of two of the wave's four 16-feature tiles, alternating between the halves of a 32-deep k-step).
  * nefii_sdf_stream_bytes: size of that buffer, 0 if the net's shape does not qualify (every hidden layer 512 wide,
  * k_x in {0,512}, k_e in {0,64}, 512-deep last layer) - such nets run on the generic kernel and leave w_stream NULL.
  * nefii_pack_sdf_stream: device-side copy from the layers' w_f16x3 (call after nefii_pack_linear_f16x3). */

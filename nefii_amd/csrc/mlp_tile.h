@@ -850,6 +850,189 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
     }
 }
 
+// ================================================================================================
+// "16q": the pipelined evaluator on v_mfma_f32_16x16x32_f16 (nefii_mlp.reserved == 1 selects it and the matching stream
+// layout).  Same tile, stream cursor, stages, LDS image and epilogue idea as "16p"; what changes is the matrix
+// instruction: 16 x 16 output tiles, 32-deep k-steps.  A wave still owns 64 features (4 feature tiles) x all queries.
+// The stream's unit is a HALF step: the hi/lo fragments of two feature tiles for one 32-deep k-step (4 KiB, as
+// before), consumed by 2 x QT x 3 MFMAs; the activation fragments (QT query tiles, hi and lo) are read once per full
+// step.  Weights are the A operand (rows = features), activations the B operand (columns = queries): the accumulator
+// holds features 4 (lane>>4) + 0..3 of query lane&15.
+// ================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int QT>
+struct QAct {
+    half8 h[QT], l[QT];
+};
+
+template <int QT>
+__device__ __forceinline__ void qload_a(QAct<QT> &st, const _Float16 *ah, const _Float16 *al, int s32) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        st.h[qt] = *reinterpret_cast<const half8 *>(ah + qt * 16 * XP16 + 32 * s32);
+        st.l[qt] = *reinterpret_cast<const half8 *>(al + qt * 16 * XP16 + 32 * s32);
+    }
+}
+
+// one half step: HALF selects the feature-tile pair (ft = 2 HALF, 2 HALF + 1) whose fragments stage J holds
+template <int QT, int J, int HALF, int ABUF, bool LOADA>
+__device__ __forceinline__ void qstep(P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], PCursor &cur, const _Float16 *ah,
+                                      const _Float16 *al, int s32, f32x4 (&acc)[4 * QT]) {
+    pload<8>(b[(J + 3) % 4], cur);
+    if (LOADA) qload_a<QT>(a[ABUF ^ 1], ah, al, s32 + 1);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 &c = acc[(2 * HALF + f) * QT + qt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 * f], a[ABUF].h[qt], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 * f + 1], a[ABUF].h[qt], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 * f], a[ABUF].l[qt], c, 0, 0, 0);
+        }
+    // MFMAs lead, the memory instructions are spread between them (see pstep)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    if (LOADA) {
+#pragma unroll
+        for (int i = 0; i < 2 * QT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// k-loop of one layer: hsteps half steps (a multiple of 4), stage 0 first
+template <int QT>
+__device__ __forceinline__ void qgemm(int hsteps, P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], PCursor &cur,
+                                      const _Float16 *ah, const _Float16 *al, f32x4 (&acc)[4 * QT]) {
+    for (int hs = 0; hs < hsteps; hs += 4) {
+        const int s32 = hs >> 1;
+        qstep<QT, 0, 0, 0, true>(b, a, cur, ah, al, s32, acc);
+        qstep<QT, 1, 1, 0, false>(b, a, cur, ah, al, s32, acc);
+        qstep<QT, 2, 0, 1, true>(b, a, cur, ah, al, s32 + 1, acc);
+        qstep<QT, 3, 1, 1, false>(b, a, cur, ah, al, s32 + 1, acc);
+    }
+}
+
+template <int QT, bool FAST>
+__device__ __forceinline__ void qepilogue(const f32x4 (&acc)[4 * QT], float bvec, float k16, int lane, int act,
+                                          half4 (&phi)[4 * QT], half4 (&plo)[4 * QT]) {
+    const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        float4v bs;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            bs[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const f32x4 &av = acc[ft * QT + qt];
+            float4v hs;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float zs = __builtin_fmaf(av[k], k16, bs[k]);
+                hs[k] = FAST ? softplus100_s16(zs) : act_fwd(zs * (1.f / A16_SCALE), act) * A16_SCALE;
+            }
+            const half4 hi = __builtin_convertvector(hs, half4);
+            phi[ft * QT + qt] = hi;
+            plo[ft * QT + qt] = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+        }
+    }
+}
+
+// One tile of 16 * QT queries through the whole SDF network (QT = 4: 64 queries, QT = 2: 32).
+template <int QT>
+__device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, Lds16p &lds, float *raw, float *const *dest,
+                                            P16<8>::Stage (&b)[4], PCursor &cur, int ke) {
+    constexpr int NW = 8, RT = QT / 2;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NH = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    const float k16 = inv_scale * A16_SCALE;
+    encode_tile16p<NW>(m, raw, lds, ke);
+    __syncthreads();
+    const _Float16 *qh0 = lds.Xh + (lane & 15) * XP16 + 8 * (lane >> 4), *ql0 = lds.Xl + (lane & 15) * XP16 + 8 * (lane >> 4);
+    for (int l = 0; l < NH; ++l) {
+        const nefii_layer &L = m.layer[l];
+        const int hsteps = (L.k_x + L.k_e) >> 4;          // half steps = 16-deep units
+        const _Float16 *ah = qh0 + (EP16 - L.k_x), *al = ql0 + (EP16 - L.k_x);
+        const float *bp = L.bias + 64 * wave + lane;
+        asm volatile("" ::"s"(hsteps), "v"(ah), "v"(al), "v"(bp));
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see 16p)
+        __builtin_amdgcn_sched_barrier(0);
+        const float bvec = *bp;
+        f32x4 acc[4 * QT];
+#pragma unroll
+        for (int j = 0; j < 4 * QT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+        QAct<QT> a[2];
+        qload_a<QT>(a[0], ah, al, 0);
+        qgemm<QT>(hsteps, b, a, cur, ah, al, acc);
+        half4 phi[4 * QT], plo[4 * QT];
+        if (m.act == NEFII_ACT_SOFTPLUS100)
+            qepilogue<QT, true>(acc, bvec, k16, lane, m.act, phi, plo);
+        else
+            qepilogue<QT, false>(acc, bvec, k16, lane, m.act, phi, plo);
+        __syncthreads();
+        _Float16 *xh = lds.Xh + (EP16 - L.n_pad), *xl = lds.Xl + (EP16 - L.n_pad);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int query = 16 * qt + (lane & 15);
+                *reinterpret_cast<half4 *>(xh + query * XP16 + f0) = phi[ft * QT + qt];
+                *reinterpret_cast<half4 *>(xl + query * XP16 + f0) = plo[ft * QT + qt];
+            }
+        }
+        __syncthreads();
+    }
+    // last layer: as in 16p (32x32x16 fragments of the layer's own w_f16x3, K split over the waves)
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const nefii_layer &L = m.layer[NH];
+        const int NT = L.n_pad >> 5;
+        const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
+        const _Float16 *ah = lds.Xh + r * XP16 + 8 * h + (EP16 - L.k_x), *al = lds.Xl + r * XP16 + 8 * h + (EP16 - L.k_x);
+        const int ksw = (L.k_x >> 4) / NW;
+        f32x16 acc2[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
+        for (int u = 0; u < ksw; ++u) {
+            const int s = wave * ksw + u;
+            const half8 wh = wl[(size_t)s * NT * 128], wlo = wl[(size_t)s * NT * 128 + 64];
+            AStage16w a;
+            pload_a<RT>(a, ah, al, s);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a.ah[rt], acc2[rt], 0, 0, 0);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, a.ah[rt], acc2[rt], 0, 0, 0);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a.al[rt], acc2[rt], 0, 0, 0);
+            }
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) raw[wave * TILE_W + 32 * rt + r] = acc2[rt][0];
+        }
+        __syncthreads();
+        if (threadIdx.x < 32 * RT) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += raw[w * TILE_W + threadIdx.x];
+            float *d = dest[threadIdx.x];
+            if (d) *d = sum * inv_scale + L.bias[0];
+        }
+        __syncthreads();
+    }
+}
+
 // accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
 #define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \

@@ -617,6 +617,59 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Param
     }
 }
 
+// the same on v_mfma_f32_16x16x32_f16 (mlp_tile.h "16q"; nefii_mlp.reserved == 1)
+template <int QT>
+__global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, int round) {
+    __shared__ Lds16p lds;
+    __shared__ float raw[TILE_W * 9];
+    __shared__ float *dest[TILE_W];
+    const int n_single = P.counters[round * 4 + 0];
+    const int n_dense = P.counters[round * 4 + 1];
+    const int n_tri = P.counters[round * 4 + 2];
+    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
+    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
+    if ((total <= SMALL_ROUND) != (QT == 2)) return;
+    constexpr int ROWS = 16 * QT;
+    const int64_t n_tiles = (total + ROWS - 1) / ROWS;
+    if (blockIdx.x >= n_tiles) return;
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    P16<8>::Stage b[4];
+    PCursor cur;
+    prime16p<8>(m, b, cur);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        decode_tile<ROWS>(P, tile, total, n_single, n_sd, raw, dest);
+        __syncthreads();
+        sdf_tile16q<QT>(m, lds, raw, dest, b, cur, ke);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void sdf_points_kernel16q(nefii_mlp m, const float *__restrict__ x, int64_t n,
+                                                              float *__restrict__ out) {
+    __shared__ Lds16p lds;
+    __shared__ float raw[TILE_W * 9];
+    __shared__ float *dest[TILE_W];
+    const int64_t n_tiles = (n + TILE_W - 1) / TILE_W;
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    P16<8>::Stage b[4];
+    PCursor cur;
+    prime16p<8>(m, b, cur);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tid = threadIdx.x;
+        if (tid < TILE_W) {
+            const int64_t q = tile * TILE_W + tid;
+            float *rw = raw + tid * 9;
+            const bool live = q < n;
+            rw[0] = live ? x[q * 3] : 0.f, rw[1] = live ? x[q * 3 + 1] : 0.f, rw[2] = live ? x[q * 3 + 2] : 0.f;
+            rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
+            dest[tid] = live ? out + q : nullptr;
+        }
+        __syncthreads();
+        sdf_tile16q<4>(m, lds, raw, dest, b, cur, ke);
+    }
+}
+
 template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void sdf_points_kernel16p(nefii_mlp m,
                                                                                 const float *__restrict__ x,
@@ -681,13 +734,26 @@ int stream_steps(const nefii_mlp *m) {
     return G;
 }
 
-// dst[(wave*G + g)*256 + i] <- the 4 KiB fragment block of (k-step s, column tiles 2 wave, 2 wave + 1)
+// layout 0 (32x32x16 fragments): dst[(wave*G + g)*256 + i] <- the 4 KiB fragment block of (k-step g of the layer
+// sequence, column tiles 2 wave, 2 wave + 1), a straight copy.
+// layout 1 (16x16x32 fragments, nefii_mlp.reserved == 1): unit g is a HALF step (32-deep k-step g/2 of the layer sequence,
+// feature-tile pair g&1): dst[((wave*G + g)*4 + 2 f + part)*64 + lane][j] = W[n = 64 wave + 16 (2 (g&1) + f) + (lane&15)]
+// [k = 32 s32 + 8 (lane>>4) + j], gathered from the layer's 32x32x16 fragments (one source half8 per destination half8).
 __global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int G) {
     const int g = blockIdx.x, wave = blockIdx.y;
     int l = 0, s = g;
     while (s >= ((m.layer[l].k_x + m.layer[l].k_e) >> 4)) s -= (m.layer[l].k_x + m.layer[l].k_e) >> 4, ++l;
-    const half8 *src = reinterpret_cast<const half8 *>(m.layer[l].w_f16x3) + ((size_t)s * 16 + 2 * wave) * 2 * 64;
-    dst[((size_t)wave * G + g) * 256 + threadIdx.x] = src[threadIdx.x];
+    const half8 *w = reinterpret_cast<const half8 *>(m.layer[l].w_f16x3);
+    if (m.reserved != 1) {
+        const half8 *src = w + ((size_t)s * 16 + 2 * wave) * 2 * 64;
+        dst[((size_t)wave * G + g) * 256 + threadIdx.x] = src[threadIdx.x];
+        return;
+    }
+    const int frag = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = frag >> 1, part = frag & 1, half = s & 1, s32 = s >> 1, kg = lane >> 4;
+    const int n = 64 * wave + 16 * (2 * half + f) + (lane & 15);
+    const int s16 = 2 * s32 + (kg >> 1), t = n >> 5, lane_src = (n & 31) + 32 * (kg & 1);
+    dst[((size_t)wave * G + g) * 256 + threadIdx.x] = w[(((size_t)s16 * 16 + t) * 2 + part) * 64 + lane_src];
 }
 
 // the same tile evaluator over an explicit point list (nefii_sdf_eval)
@@ -828,7 +894,10 @@ extern "C" int nefii_sdf_eval(const nefii_mlp *h_sdf, const float *x, int64_t n,
     for (int l = 0; l < h_sdf->n_layers; ++l)
         if (!h_sdf->layer[l].w_f16x3 || !h_sdf->layer[l].bias) return NEFII_E_ARG;
     const int64_t n_tiles = (n + TILE_W - 1) / TILE_W;
-    if (fits16p(h_sdf))
+    if (fits16p(h_sdf) && h_sdf->reserved == 1)
+        hipLaunchKernelGGL(sdf_points_kernel16q, dim3((int)(n_tiles < 512 ? n_tiles : 512)), dim3(512), 0,
+                           (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    else if (fits16p(h_sdf))
         hipLaunchKernelGGL(sdf_points_kernel16p<P16W>, dim3((int)(n_tiles < 512 ? n_tiles : 512)), dim3(64 * P16W), 0,
                            (hipStream_t)stream, *h_sdf, x, n, sdf_out);
     else
@@ -934,7 +1003,13 @@ int launch_round(const TraceJob &J, int r, bool profile) {
             e1 = prof_event();
             (void)hipEventRecord(e0, st);
         }
-        if (J.precision == 2 && J.pipelined) {
+        if (J.precision == 2 && J.pipelined && J.sdf->reserved == 1) {
+            hipLaunchKernelGGL((eval_kernel16q<4>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
+            HIP_CHECK_LAUNCH();
+            const int64_t small_tiles = (J.P.n * 2 + 31) / 32 < 256 ? (J.P.n * 2 + 31) / 32 : 256;
+            hipLaunchKernelGGL((eval_kernel16q<2>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(512), 0, st, J.P,
+                               *J.sdf, r);
+        } else if (J.precision == 2 && J.pipelined) {
             hipLaunchKernelGGL((eval_kernel16p<P16W, 2>), dim3(J.eval_blocks_w), dim3(64 * P16W), 0, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();
             const int64_t small_tiles = (J.P.n * 2 + 31) / 32 < 256 ? (J.P.n * 2 + 31) / 32 : 256;   // >= SMALL_ROUND / 32

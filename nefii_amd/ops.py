@@ -5,6 +5,7 @@ HIP kernels; every hot op below runs in libnefii_hip.so.  There is no eager fall
 library (or without a GPU tensor) these functions raise.
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -93,6 +94,8 @@ class PackedMLP:
             if nbytes and feat_width == 0 and self.enc_freqs[1] < 0 and self.enc_freqs[2] < 0:
                 self.w_stream = torch.zeros(nbytes // 2, device=device, dtype=torch.float16)
                 m.w_stream = self.w_stream.data_ptr()
+                # stream layout / matrix instruction of the pipelined evaluator: 0 = 32x32x16, 1 = 16x16x32
+                m.reserved = int(os.environ.get('NEFII_STREAM_LAYOUT', '1'))
         self.hidden_stride = max(s.n_pad for s in specs)
         self.packed_version = None
 

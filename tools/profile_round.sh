@@ -3,7 +3,7 @@
 # (FETCH_SIZE, WRITE_SIZE; separate runs) -> gpurun_out/<tag>/ ; copy what should be judged into profiles/.
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-TAG=${1:-r01b}; WL=${2:-cfg2}; KERN=${3:-eval_kernel16p}
+TAG=${1:-r01b}; WL=${2:-cfg2}; KERN=${3:-eval_kernel16q}
 O=gpurun_out/$TAG; S=/tmp/prof_$TAG
 mkdir -p $O $S
 python3 bench.py --workload $WL --steps 20 --warmup 5 > $O/bench_$WL.json 2> $O/bench_err.log
