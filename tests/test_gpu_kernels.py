@@ -562,3 +562,37 @@ def test_fused_idr_loss_matches_torch_formulation(loss_type, env_type, r_patch, 
         assert rel_l2(gi1, gi0) < 1e-5
     else:
         assert gi0 is None and gi1 is None
+
+
+def test_pipelined_evaluator_both_matrix_instructions(monkeypatch):
+    """The pipelined tile evaluator exists on 32x32x16 and on 16x16x32 fp16 MFMAs (stream layouts 0 / 1, nefii_mlp.reserved):
+    both against the fp64 oracle, for a multi-tile launch and through the tracer (small and large rounds)."""
+    from nefii_amd import ops
+    mc = syn.model_conf('physg', hidden=512)
+    sd = syn.make_state_dict(mc, seed=3, bumpy=0.004)
+    x = ball_points(3000, 5)
+    ref = nets.sdf_forward({k: v.double() for k, v in sd.items()}, mc['implicit_network'], x.double())[:, 0]
+    g = torch.Generator().manual_seed(5)
+    n = 6000
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * (1.2 + 1.5 * torch.rand(n, 1, generator=g))
+    d = torch.randn(n, 3, generator=g) * 0.5 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    om = torch.rand(n, generator=g) < 0.9
+    st = torch.rand(100, generator=g)
+    res = []
+    for layout in ('0', '1'):
+        monkeypatch.setenv('NEFII_STREAM_LAYOUT', layout)
+        pm = build_sdf(mc, sd, f16x3=True)
+        assert pm.struct.reserved == int(layout)
+        out = ops.sdf_eval(pm, x.to(DEV)).cpu()
+        assert (out.double() - ref).abs().max().item() < 5e-6
+        tp = ops.make_tracer_params(mc['ray_tracer'], True, 'f16x3w', 5)
+        lin = torch.linspace(0, 1, steps=tp.n_steps).to(DEV)
+        res.append(ops.trace_rays(pm, tp, o.to(DEV).contiguous(), d.to(DEV).contiguous(), om.to(DEV), lin, st.to(DEV),
+                                  want_counters=True))
+    (p0, h0, d0, c0), (p1, h1, d1, c1) = res
+    assert (h0 != h1).sum().item() <= 3                     # knife-edge rays may flip between summation orders
+    same = (h0 == h1) & h0
+    assert (d0[same] - d1[same]).abs().median().item() < 2e-6
+    assert abs(int(c0.sum()) - int(c1.sum())) <= 0.01 * int(c0.sum())
