@@ -116,7 +116,7 @@ class TrainStep:
         self.graph_bucket, self.graph_after = int(graph_bucket), int(graph_after)
         self._graphs = {}
         self._eager_steps = 0     # captures need an initialised optimiser state: the first steps run eagerly
-        self._prefetch, self._trace_stream = None, None
+        self._prefetch, self._trace_stream = [], None      # traces enqueued ahead: (input, ctx, event, checks)
         kw = dict(fused=fused, capturable=True) if self.graph else dict(fused=fused)
         if self.graph:      # a captured Adam reads its learning rate from device memory: the schedulers fill it in place
             dev = next(model.parameters()).device
@@ -193,12 +193,17 @@ class TrainStep:
             finally:
                 m.ray_tracer.deferred_checks = None
             ev = self._trace_stream.record_event()
-        self._prefetch = (model_input, ctx, ev, checks)
+        self._prefetch.append((model_input, ctx, ev, checks))
+
+    def _n_prefetched(self, model_input):
+        return sum(1 for pf in self._prefetch if pf[0] is model_input)
 
     def _take_prefetched(self, model_input):
-        pf, self._prefetch = self._prefetch, None
-        if pf is None or pf[0] is not model_input:
+        pf = next((e for e in self._prefetch if e[0] is model_input), None)     # oldest first: enqueue order
+        if pf is None:
+            self._prefetch = []         # the caller changed its mind about the next batch
             return None
+        self._prefetch = [e for e in self._prefetch if e is not pf][-1:]
         _, ctx, ev, checks = pf
         cur = torch.cuda.current_stream()
         cur.wait_event(ev)
@@ -246,12 +251,18 @@ class TrainStep:
         """next_input (optional): the model_input of the following call (the same dict object must then be passed to
         it) - its rays are traced concurrently with this step's tail, see prefetch_trace."""
         self._pre_iteration()
-        ctx = self._take_prefetched(model_input)
+        ctx = None
         if next_input is not None:
             m = self.model
-            if ctx is None and m.training and getattr(m, 'state_freeze_geo', False):
+            mine = self._n_prefetched(model_input)
+            if not mine and m.training and getattr(m, 'state_freeze_geo', False):
                 ctx = m.trace_head(model_input)         # own trace first: the tracer's random draws keep their order
-            self.prefetch_trace(next_input)             # enqueued now: it runs beside everything this call does next
+            # enqueued BEFORE this batch's own (earlier enqueued) trace is waited for: the trace stream then always has
+            # the next trace queued behind the running one and never idles while the host checks and launches
+            if self._n_prefetched(next_input) < (2 if next_input is model_input and mine else 1):
+                self.prefetch_trace(next_input)
+        if ctx is None:
+            ctx = self._take_prefetched(model_input)
         if self.graph and self._eager_steps >= self.graph_after and self.model.training:
             res = self._graph_step(model_input, ground_truth, ctx)
             if res is not None:
