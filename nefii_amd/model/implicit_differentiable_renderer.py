@@ -267,6 +267,10 @@ class IDRNetwork(nn.Module):
     def trace_head(self, input):
         """Camera rays -> surface points (no autograd): everything of forward_with_uv (:312-356) ahead of the
         compaction of the hit rays.  Returns the tensors shade_tail needs, all of the static shape [B*S*R, .]."""
+        return self.attach_surface(self.trace_points(input))
+
+    def trace_points(self, input):
+        """trace_head without the SDF value / feature / gradient pass at the traced points (attach_surface)."""
         if self.training and not self.state_freeze_geo:
             raise NotImplementedError('training with trainable geometry is outside the Step-2 hot path; '
                                       'call freeze_geometry()')
@@ -285,9 +289,8 @@ class IDRNetwork(nn.Module):
         with torch.no_grad():
             points, network_object_mask, dists = self.ray_tracer(sdf=self.implicit_network, cam_loc=cam_loc,
                                                                  object_mask=object_mask, ray_directions=ray_dirs)
-        ctx = {'points': points, 'network_object_mask': network_object_mask, 'object_mask': object_mask,
-               'ray_dirs': ray_dirs.reshape(-1, 3), 'multi': shape}
-        return self.attach_surface(ctx)
+        return {'points': points, 'network_object_mask': network_object_mask, 'object_mask': object_mask,
+                'ray_dirs': ray_dirs.reshape(-1, 3), 'multi': shape}
 
     def attach_surface(self, ctx):
         """SDF value (and, for small batches, features and gradient) at the traced points - the part of trace_head that

@@ -5,6 +5,8 @@ Optimiser construction follows idr_train.py:188-196: one Adam over implicit+rend
 envmap/material parameters, both lr 5e-4.  The multi-GPU path shards the pixel batch per rank (the dataset's
 contiguous patch split, scene_dataset.py:268-279) and averages gradients with ONE flat all-reduce over
 RCCL/xGMI (what DistributedDataParallel does for the reference, idr_train.py:308-309), 6.6-13 MB per step."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -117,6 +119,9 @@ class TrainStep:
         self._graphs = {}
         self._eager_steps = 0     # captures need an initialised optimiser state: the first steps run eagerly
         self._prefetch, self._trace_stream = [], None      # traces enqueued ahead: (input, ctx, event, checks)
+        # the SDF value/gradient pass at the traced points: on the trace stream it sits on the step's critical path; in the
+        # tail (default) it runs beside the next trace (config 2: 5.2 vs 5.45 ms per step)
+        self.surface_in_tail = os.environ.get('NEFII_SURFACE_IN_TAIL', '1') == '1'
         kw = dict(fused=fused, capturable=True) if self.graph else dict(fused=fused)
         if self.graph:      # a captured Adam reads its learning rate from device memory: the schedulers fill it in place
             dev = next(model.parameters()).device
@@ -189,7 +194,7 @@ class TrainStep:
         with torch.cuda.stream(self._trace_stream):
             m.ray_tracer.deferred_checks = checks       # no host sync inside the trace: its round-prefix check waits
             try:
-                ctx = m.trace_head(model_input)
+                ctx = m.trace_points(model_input) if self.surface_in_tail else m.trace_head(model_input)
             finally:
                 m.ray_tracer.deferred_checks = None
             ev = self._trace_stream.record_event()
@@ -212,11 +217,11 @@ class TrainStep:
             more = chk()
             if more is not None:        # the guessed round prefix was too short: the check ran the remaining rounds
                 ctx['points'], ctx['network_object_mask'] = more[0], more[1]
-                ctx = self.model.attach_surface(ctx)
-        for v in list(ctx.values()) + list(ctx['pre'] or ()):
+                ctx.pop('pre', None)
+        for v in list(ctx.values()) + list(ctx.get('pre') or ()):
             if torch.is_tensor(v):
                 v.record_stream(cur)          # allocated on the trace stream, consumed here
-        return ctx
+        return ctx if 'pre' in ctx else self.model.attach_surface(ctx)
 
     def _graph_step(self, model_input, ground_truth, ctx=None):
         if ctx is None:
