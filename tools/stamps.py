@@ -1,5 +1,7 @@
-"""Per-layer timeline of the pipelined tile evaluator from s_memtime stamps (build with -DNEFII_STAMPS)."""
+"""Per-layer timeline of the pipelined tile evaluator from s_memtime stamps (build with -DNEFII_STAMPS).
+The stamps are compiled into the 32x32x16 instance (mlp_tile.h "16p"), so the script selects stream layout 0."""
 import ctypes, os, sys
+os.environ['NEFII_STREAM_LAYOUT'] = '0'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from nefii_amd import ops, synthetic as syn, _lib
