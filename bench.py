@@ -173,6 +173,8 @@ def main():
 
     # NEFII_BENCH_PREFETCH=1 (default): every step also enqueues the trace of the next batch (TrainStep.prefetch_trace)
     nxt = inp if os.environ.get('NEFII_BENCH_PREFETCH', '1') != '0' else None
+    if nxt is not None:         # batches known ahead of time (a dataloader's prefetch queue): 2 by default
+        nxt = [inp] * max(1, int(os.environ.get('NEFII_BENCH_LOOKAHEAD', '2')))
     for _ in range(args.warmup):
         step(inp, gt, nxt)
     # the graph of the step's tail is captured once per padded hit count, after 3 eager steps: with fewer warm-up steps
@@ -213,6 +215,8 @@ def main():
 
     # ---- roofline of the dominant kernel: one extra, un-timed step with per-launch HIP events.  Every rank runs the step
     # (it contains the gradient all-reduce); only rank 0 instruments and reports it.
+    torch.cuda.synchronize()
+    step._prefetch.clear()                  # traces enqueued ahead by the loops above: done, not needed
     model.ray_tracer.collect_counters = True
     model.ray_tracer.counter_sum = None
     model.ray_tracer.stream_groups = 1      # the profiled step runs the rounds back to back on one stream
@@ -286,7 +290,7 @@ def main():
                                       else 'MC direct + near-field indirect ON'),
                        'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
                        'step_graph': bool(use_graph),
-                       'trace_prefetch': nxt is not None,     # batch i+1 is traced beside the tail of batch i
+                       'trace_prefetch': len(nxt) if nxt is not None else 0,   # batches traced ahead, beside the tail of batch i
 
                        'loss': float(lo['loss'].item())},
             'roofline': roofline,

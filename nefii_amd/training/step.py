@@ -118,7 +118,7 @@ class TrainStep:
         self.graph_bucket, self.graph_after = int(graph_bucket), int(graph_after)
         self._graphs = {}
         self._eager_steps = 0     # captures need an initialised optimiser state: the first steps run eagerly
-        self._prefetch, self._trace_stream, self._trace_stream2 = [], None, None   # traces enqueued ahead: (input, ctx, event, checks)
+        self._prefetch, self._trace_stream, self._trace_pool = [], None, []   # traces enqueued ahead: (input, ctx, event, checks)
         # the SDF value/gradient pass at the traced points: on the trace stream it sits on the step's critical path; in the
         # tail (default) it runs beside the next trace (config 2: 5.2 vs 5.45 ms per step)
         self.surface_in_tail = os.environ.get('NEFII_SURFACE_IN_TAIL', '1') == '1'
@@ -188,12 +188,12 @@ class TrainStep:
         if not (m.training and getattr(m, 'state_freeze_geo', False) and next(m.parameters()).is_cuda):
             return
         if self._trace_stream is None:
-            self._trace_stream = torch.cuda.Stream()
-            self._trace_stream2 = torch.cuda.Stream() if os.environ.get('NEFII_TRACE_STREAMS', '2') == '2' else None
-        if self._trace_stream2 is not None:
-            # consecutive traces alternate between two streams: the trace enqueued now starts beside the one still
-            # running - its dense rounds fill what the other's latency-bound rounds leave idle (config 2: 5.06 vs 5.26 ms)
-            self._trace_stream, self._trace_stream2 = self._trace_stream2, self._trace_stream
+            n = max(1, int(os.environ.get('NEFII_TRACE_STREAMS', '2')))
+            self._trace_pool = [torch.cuda.Stream() for _ in range(n)]
+        # consecutive traces rotate over the streams: the trace enqueued now starts beside the one(s) still running -
+        # its dense rounds fill what the others' latency-bound rounds leave idle (config 2, 1 / 2 streams: 5.26 / 5.06 ms)
+        self._trace_pool.append(self._trace_pool.pop(0))
+        self._trace_stream = self._trace_pool[0]
         self._trace_stream.wait_event(after if after is not None else torch.cuda.current_stream().record_event())
         checks = []
         with torch.cuda.stream(self._trace_stream):
@@ -209,11 +209,10 @@ class TrainStep:
         return sum(1 for pf in self._prefetch if pf[0] is model_input)
 
     def _take_prefetched(self, model_input):
-        pf = next((e for e in self._prefetch if e[0] is model_input), None)     # oldest first: enqueue order
-        if pf is None:
+        if not self._prefetch or self._prefetch[0][0] is not model_input:
             self._prefetch = []         # the caller changed its mind about the next batch
             return None
-        self._prefetch = [e for e in self._prefetch if e is not pf][-1:]
+        pf = self._prefetch.pop(0)      # oldest first: enqueue order
         _, ctx, ev, checks = pf
         cur = torch.cuda.current_stream()
         cur.wait_event(ev)
@@ -258,19 +257,26 @@ class TrainStep:
         return g.out, g.lo
 
     def __call__(self, model_input, ground_truth, next_input=None):
-        """next_input (optional): the model_input of the following call (the same dict object must then be passed to
-        it) - its rays are traced concurrently with this step's tail, see prefetch_trace."""
+        """next_input (optional): the model_input of the following call, or a list of the following calls' inputs in
+        order (the same dict objects must then be passed to them) - their rays are traced concurrently with this step's
+        tail, see prefetch_trace."""
         self._pre_iteration()
         ctx = None
         if next_input is not None:
             m = self.model
-            mine = self._n_prefetched(model_input)
+            upcoming = list(next_input) if isinstance(next_input, (list, tuple)) else [next_input]
+            queued = [e[0] for e in self._prefetch]
+            mine = bool(queued) and queued[0] is model_input
+            expected = ([model_input] if mine else []) + upcoming
+            if len(queued) > len(expected) or any(a is not b for a, b in zip(queued, expected)):
+                self._prefetch, queued, mine = [], [], False        # the caller changed its mind about the coming batches
+                expected = upcoming
             if not mine and m.training and getattr(m, 'state_freeze_geo', False):
                 ctx = m.trace_head(model_input)         # own trace first: the tracer's random draws keep their order
-            # enqueued BEFORE this batch's own (earlier enqueued) trace is waited for: the trace stream then always has
-            # the next trace queued behind the running one and never idles while the host checks and launches
-            if self._n_prefetched(next_input) < (2 if next_input is model_input and mine else 1):
-                self.prefetch_trace(next_input)
+            # enqueued BEFORE this batch's own (earlier enqueued) trace is waited for: the trace streams then always have
+            # the next trace(s) queued behind / beside the running one and never idle while the host checks and launches
+            for inp in expected[len(queued):]:
+                self.prefetch_trace(inp)
         if ctx is None:
             ctx = self._take_prefetched(model_input)
         if self.graph and self._eager_steps >= self.graph_after and self.model.training:

@@ -521,7 +521,11 @@ def test_prefetched_trace_gives_the_same_steps(graph):
         st = TrainStep(m, lc, graph=graph, graph_bucket=64, graph_after=2)
         losses = []
         for i, (inp, gt) in enumerate(batches):
-            nxt = batches[i + 1][0] if prefetch and i + 1 < len(batches) and i != 3 else None     # one step without
+            nxt = None
+            if prefetch and i != 3:                          # one step announces nothing
+                nxt = [b[0] for b in batches[i + 1:i + 3]] or None      # two batches of lookahead
+                if i == 1:
+                    nxt = nxt[0]                             # a single dict is accepted too
             out, lo = st(inp, gt, nxt)
             losses.append({k: v.item() for k, v in lo.items()})
         runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}))
