@@ -29,7 +29,7 @@ class RayTracing(nn.Module):
         self.collect_counters = False
         self.minsdf_steps_override = None     # parity tests replay the reference's captured uniforms
         self._calls = 0
-        self.bisect_levels = 0          # 0 = automatic: 5 for batches up to 16 k rays (latency-bound), else 3
+        self.bisect_levels = int(os.environ.get('NEFII_BISECT_LEVELS', '0'))   # 0 = automatic: 5 for batches up to 16 k rays (latency-bound), else 3
         self.adaptive_rounds = True     # skip the trailing empty rounds (ops.TraceRounds)
         self._rounds_state = {}
         # concurrent ray chunks on separate streams (ops.trace_rays): measured on config 2, 1/2/3/4 chunks give
