@@ -860,26 +860,46 @@ __device__ __forceinline__ void sdf_tile16p(const nefii_mlp &m, Lds16p &lds, flo
 // holds features 4 (lane>>4) + 0..3 of query lane&15.
 // ================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// FT = 16-feature tiles per wave: 4 for 512-wide hidden layers, 2 for 256-wide ones (conf_neus.conf).  With FT = 2 a
+// stream unit is a whole 32-deep k-step (both feature tiles), every layer's K is padded to a multiple of 128 with zero
+// weights (unit counts stay multiples of 4: one stage phase) and a tile holds up to 96 queries (QT = 6).
+template <int FT>
+struct QGeo {
+    static constexpr int HW = 128 * FT;                 // hidden width = first encoding column
+    static constexpr int EW = FT == 4 ? 64 : 128;       // encoding columns incl. zero padding
+    static constexpr int XP = HW + EW + 8;              // halves per row: 584 / 392 (16 B * odd)
+    static constexpr int ROWS = FT == 4 ? 64 : 96;      // queries per tile at most
+};
+template <int FT>
+struct LdsQ {
+    _Float16 Xh[QGeo<FT>::ROWS * QGeo<FT>::XP], Xl[QGeo<FT>::ROWS * QGeo<FT>::XP];
+    _Float16 tail[64];
+};
+// k-loop units of a layer: half steps (16 deep) for FT = 4, whole 32-deep steps of the 128-padded K for FT = 2
+template <int FT>
+__host__ __device__ __forceinline__ int q_units(const nefii_layer &L) {
+    return FT == 4 ? (L.k_x + L.k_e) >> 4 : ((L.k_x + L.k_e + 127) & ~127) >> 5;
+}
 template <int QT>
 struct QAct {
     half8 h[QT], l[QT];
 };
 
-template <int QT>
+template <int QT, int XP>
 __device__ __forceinline__ void qload_a(QAct<QT> &st, const _Float16 *ah, const _Float16 *al, int s32) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        st.h[qt] = *reinterpret_cast<const half8 *>(ah + qt * 16 * XP16 + 32 * s32);
-        st.l[qt] = *reinterpret_cast<const half8 *>(al + qt * 16 * XP16 + 32 * s32);
+        st.h[qt] = *reinterpret_cast<const half8 *>(ah + qt * 16 * XP + 32 * s32);
+        st.l[qt] = *reinterpret_cast<const half8 *>(al + qt * 16 * XP + 32 * s32);
     }
 }
 
 // one half step: HALF selects the feature-tile pair (ft = 2 HALF, 2 HALF + 1) whose fragments stage J holds
-template <int QT, int J, int HALF, int ABUF, bool LOADA>
+template <int QT, int FT, int J, int HALF, int ABUF, bool LOADA>
 __device__ __forceinline__ void qstep(P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], PCursor &cur, const _Float16 *ah,
-                                      const _Float16 *al, int s32, f32x4 (&acc)[4 * QT]) {
+                                      const _Float16 *al, int s32, f32x4 (&acc)[FT * QT]) {
     pload<8>(b[(J + 3) % 4], cur);
-    if (LOADA) qload_a<QT>(a[ABUF ^ 1], ah, al, s32 + 1);
+    if (LOADA) qload_a<QT, QGeo<FT>::XP>(a[ABUF ^ 1], ah, al, s32 + 1);
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -905,25 +925,34 @@ __device__ __forceinline__ void qstep(P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], P
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// k-loop of one layer: hsteps half steps (a multiple of 4), stage 0 first
-template <int QT>
-__device__ __forceinline__ void qgemm(int hsteps, P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], PCursor &cur,
-                                      const _Float16 *ah, const _Float16 *al, f32x4 (&acc)[4 * QT]) {
-    for (int hs = 0; hs < hsteps; hs += 4) {
-        const int s32 = hs >> 1;
-        qstep<QT, 0, 0, 0, true>(b, a, cur, ah, al, s32, acc);
-        qstep<QT, 1, 1, 0, false>(b, a, cur, ah, al, s32, acc);
-        qstep<QT, 2, 0, 1, true>(b, a, cur, ah, al, s32 + 1, acc);
-        qstep<QT, 3, 1, 1, false>(b, a, cur, ah, al, s32 + 1, acc);
+// k-loop of one layer: `units` stream units (a multiple of 4), stage 0 first
+template <int QT, int FT>
+__device__ __forceinline__ void qgemm(int units, P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], PCursor &cur,
+                                      const _Float16 *ah, const _Float16 *al, f32x4 (&acc)[FT * QT]) {
+    if constexpr (FT == 4) {
+        for (int hs = 0; hs < units; hs += 4) {
+            const int s32 = hs >> 1;
+            qstep<QT, FT, 0, 0, 0, true>(b, a, cur, ah, al, s32, acc);
+            qstep<QT, FT, 1, 1, 0, false>(b, a, cur, ah, al, s32, acc);
+            qstep<QT, FT, 2, 0, 1, true>(b, a, cur, ah, al, s32 + 1, acc);
+            qstep<QT, FT, 3, 1, 1, false>(b, a, cur, ah, al, s32 + 1, acc);
+        }
+    } else {
+        for (int s32 = 0; s32 < units; s32 += 4) {
+            qstep<QT, FT, 0, 0, 0, true>(b, a, cur, ah, al, s32, acc);
+            qstep<QT, FT, 1, 0, 1, true>(b, a, cur, ah, al, s32 + 1, acc);
+            qstep<QT, FT, 2, 0, 0, true>(b, a, cur, ah, al, s32 + 2, acc);
+            qstep<QT, FT, 3, 0, 1, true>(b, a, cur, ah, al, s32 + 3, acc);
+        }
     }
 }
 
-template <int QT, bool FAST>
-__device__ __forceinline__ void qepilogue(const f32x4 (&acc)[4 * QT], float bvec, float k16, int lane, int act,
-                                          half4 (&phi)[4 * QT], half4 (&plo)[4 * QT]) {
+template <int QT, int FT, bool FAST>
+__device__ __forceinline__ void qepilogue(const f32x4 (&acc)[FT * QT], float bvec, float k16, int lane, int act,
+                                          half4 (&phi)[FT * QT], half4 (&plo)[FT * QT]) {
     const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
 #pragma unroll
-    for (int ft = 0; ft < 4; ++ft) {
+    for (int ft = 0; ft < FT; ++ft) {
         float4v bs;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -944,61 +973,85 @@ __device__ __forceinline__ void qepilogue(const f32x4 (&acc)[4 * QT], float bvec
     }
 }
 
-// One tile of 16 * QT queries through the whole SDF network (QT = 4: 64 queries, QT = 2: 32).
-template <int QT>
-__device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, Lds16p &lds, float *raw, float *const *dest,
-                                            P16<8>::Stage (&b)[4], PCursor &cur, int ke) {
-    constexpr int NW = 8, RT = QT / 2;
+template <int FT>
+__device__ __forceinline__ void encode_tile16q(const nefii_mlp &m, const float *raw, LdsQ<FT> &lds, int rows) {
+    constexpr int XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, EW = QGeo<FT>::EW;
+    const int w0 = enc_width(m.enc_freqs[0]);
+    for (int i = threadIdx.x; i < rows * EW; i += 512) {
+        const int p = i / EW, c = i - p * EW;
+        const float val = c < w0 ? enc_value(raw + p * 9, c) : 0.f;
+        split16a(val, lds.Xh[p * XP + EP + c], lds.Xl[p * XP + EP + c]);
+    }
+}
+
+// stages 0..2 <- units 0..2 of the stream (start of a workgroup)
+template <int FT>
+__device__ __forceinline__ void prime16q(const nefii_mlp &m, P16<8>::Stage (&b)[4], PCursor &cur) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int G = 0;
+    for (int l = 0; l < m.n_layers - 1; ++l) G += q_units<FT>(m.layer[l]);
+    cur.bytes = (unsigned)G * 4096;
+    cur.base = reinterpret_cast<const half8 *>(m.w_stream) + (size_t)wave * G * 256 + lane;
+    cur.off = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) pload<8>(b[u], cur);
+}
+
+// One tile of 16 * QT queries through the whole SDF network (FT = 4: QT = 4 / 2 for 64 / 32 queries; FT = 2: QT = 6 / 2).
+template <int QT, int FT>
+__device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, float *raw, float *const *dest,
+                                            P16<8>::Stage (&b)[4], PCursor &cur) {
+    constexpr int NW = 8, RT = QT / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, RMAX = QGeo<FT>::ROWS;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int NH = m.n_layers - 1;
     const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
     const float k16 = inv_scale * A16_SCALE;
-    encode_tile16p<NW>(m, raw, lds, ke);
+    encode_tile16q<FT>(m, raw, lds, 16 * QT);
     __syncthreads();
-    const _Float16 *qh0 = lds.Xh + (lane & 15) * XP16 + 8 * (lane >> 4), *ql0 = lds.Xl + (lane & 15) * XP16 + 8 * (lane >> 4);
+    const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4), *ql0 = lds.Xl + (lane & 15) * XP + 8 * (lane >> 4);
     for (int l = 0; l < NH; ++l) {
         const nefii_layer &L = m.layer[l];
-        const int hsteps = (L.k_x + L.k_e) >> 4;          // half steps = 16-deep units
-        const _Float16 *ah = qh0 + (EP16 - L.k_x), *al = ql0 + (EP16 - L.k_x);
-        const float *bp = L.bias + 64 * wave + lane;
-        asm volatile("" ::"s"(hsteps), "v"(ah), "v"(al), "v"(bp));
+        const int units = q_units<FT>(L);
+        const _Float16 *ah = qh0 + (EP - L.k_x), *al = ql0 + (EP - L.k_x);
+        const float *bp = L.bias + 16 * FT * wave + (lane & (16 * FT - 1));
+        asm volatile("" ::"s"(units), "v"(ah), "v"(al), "v"(bp));
         __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see 16p)
         __builtin_amdgcn_sched_barrier(0);
         const float bvec = *bp;
-        f32x4 acc[4 * QT];
+        f32x4 acc[FT * QT];
 #pragma unroll
-        for (int j = 0; j < 4 * QT; ++j)
+        for (int j = 0; j < FT * QT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
         QAct<QT> a[2];
-        qload_a<QT>(a[0], ah, al, 0);
-        qgemm<QT>(hsteps, b, a, cur, ah, al, acc);
-        half4 phi[4 * QT], plo[4 * QT];
+        qload_a<QT, XP>(a[0], ah, al, 0);
+        qgemm<QT, FT>(units, b, a, cur, ah, al, acc);
+        half4 phi[FT * QT], plo[FT * QT];
         if (m.act == NEFII_ACT_SOFTPLUS100)
-            qepilogue<QT, true>(acc, bvec, k16, lane, m.act, phi, plo);
+            qepilogue<QT, FT, true>(acc, bvec, k16, lane, m.act, phi, plo);
         else
-            qepilogue<QT, false>(acc, bvec, k16, lane, m.act, phi, plo);
+            qepilogue<QT, FT, false>(acc, bvec, k16, lane, m.act, phi, plo);
         __syncthreads();
-        _Float16 *xh = lds.Xh + (EP16 - L.n_pad), *xl = lds.Xl + (EP16 - L.n_pad);
+        _Float16 *xh = lds.Xh + (EP - L.n_pad), *xl = lds.Xl + (EP - L.n_pad);
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+        for (int ft = 0; ft < FT; ++ft) {
+            const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const int query = 16 * qt + (lane & 15);
-                *reinterpret_cast<half4 *>(xh + query * XP16 + f0) = phi[ft * QT + qt];
-                *reinterpret_cast<half4 *>(xl + query * XP16 + f0) = plo[ft * QT + qt];
+                *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                *reinterpret_cast<half4 *>(xl + query * XP + f0) = plo[ft * QT + qt];
             }
         }
         __syncthreads();
     }
-    // last layer: as in 16p (32x32x16 fragments of the layer's own w_f16x3, K split over the waves)
+    // last layer, column 0 only: 32x32x16 fragments of the layer's own w_f16x3, K split over the waves (as in 16p)
     {
         const int r = lane & 31, h = lane >> 5;
         const nefii_layer &L = m.layer[NH];
         const int NT = L.n_pad >> 5;
         const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
-        const _Float16 *ah = lds.Xh + r * XP16 + 8 * h + (EP16 - L.k_x), *al = lds.Xl + r * XP16 + 8 * h + (EP16 - L.k_x);
+        const _Float16 *ah = lds.Xh + r * XP + 8 * h + (EP - L.k_x), *al = lds.Xl + r * XP + 8 * h + (EP - L.k_x);
         const int ksw = (L.k_x >> 4) / NW;
         f32x16 acc2[RT];
 #pragma unroll
@@ -1008,24 +1061,24 @@ __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, Lds16p &lds, flo
         for (int u = 0; u < ksw; ++u) {
             const int s = wave * ksw + u;
             const half8 wh = wl[(size_t)s * NT * 128], wlo = wl[(size_t)s * NT * 128 + 64];
-            AStage16w a;
-            pload_a<RT>(a, ah, al, s);
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
-                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a.ah[rt], acc2[rt], 0, 0, 0);
-                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, a.ah[rt], acc2[rt], 0, 0, 0);
-                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, a.al[rt], acc2[rt], 0, 0, 0);
+                const half8 xh8 = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP + 16 * s);
+                const half8 xl8 = *reinterpret_cast<const half8 *>(al + rt * 32 * XP + 16 * s);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh8, acc2[rt], 0, 0, 0);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh8, acc2[rt], 0, 0, 0);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl8, acc2[rt], 0, 0, 0);
             }
         }
         if (h == 0) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) raw[wave * TILE_W + 32 * rt + r] = acc2[rt][0];
+            for (int rt = 0; rt < RT; ++rt) raw[wave * RMAX + 32 * rt + r] = acc2[rt][0];
         }
         __syncthreads();
         if (threadIdx.x < 32 * RT) {
             float sum = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) sum += raw[w * TILE_W + threadIdx.x];
+            for (int w = 0; w < NW; ++w) sum += raw[w * RMAX + threadIdx.x];
             float *d = dest[threadIdx.x];
             if (d) *d = sum * inv_scale + L.bias[0];
         }

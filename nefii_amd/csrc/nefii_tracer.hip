@@ -617,12 +617,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Param
     }
 }
 
-// the same on v_mfma_f32_16x16x32_f16 (mlp_tile.h "16q"; nefii_mlp.reserved == 1)
-template <int QT>
+// the same on v_mfma_f32_16x16x32_f16 (mlp_tile.h "16q"; nefii_mlp.reserved == 1).  FT = 4: 512-wide hidden layers,
+// 64- / 32-query tiles; FT = 2: 256-wide hidden layers (conf_neus.conf), 96- / 32-query tiles.
+template <int QT, int FT>
 __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, int round) {
-    __shared__ Lds16p lds;
-    __shared__ float raw[TILE_W * 9];
-    __shared__ float *dest[TILE_W];
+    constexpr int RMAX = QGeo<FT>::ROWS;
+    __shared__ LdsQ<FT> lds;
+    __shared__ float raw[RMAX * 9];
+    __shared__ float *dest[RMAX];
     const int n_single = P.counters[round * 4 + 0];
     const int n_dense = P.counters[round * 4 + 1];
     const int n_tri = P.counters[round * 4 + 2];
@@ -632,33 +634,31 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
     constexpr int ROWS = 16 * QT;
     const int64_t n_tiles = (total + ROWS - 1) / ROWS;
     if (blockIdx.x >= n_tiles) return;
-    int ke = 0;
-    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
     P16<8>::Stage b[4];
     PCursor cur;
-    prime16p<8>(m, b, cur);
+    prime16q<FT>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         decode_tile<ROWS>(P, tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
-        sdf_tile16q<QT>(m, lds, raw, dest, b, cur, ke);
+        sdf_tile16q<QT, FT>(m, lds, raw, dest, b, cur);
     }
 }
 
+template <int FT>
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16q(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
-    __shared__ Lds16p lds;
-    __shared__ float raw[TILE_W * 9];
-    __shared__ float *dest[TILE_W];
-    const int64_t n_tiles = (n + TILE_W - 1) / TILE_W;
-    int ke = 0;
-    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    constexpr int ROWS = QGeo<FT>::ROWS, QT = ROWS / 16;
+    __shared__ LdsQ<FT> lds;
+    __shared__ float raw[ROWS * 9];
+    __shared__ float *dest[ROWS];
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
     P16<8>::Stage b[4];
     PCursor cur;
-    prime16p<8>(m, b, cur);
+    prime16q<FT>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int tid = threadIdx.x;
-        if (tid < TILE_W) {
-            const int64_t q = tile * TILE_W + tid;
+        if (tid < ROWS) {
+            const int64_t q = tile * ROWS + tid;
             float *rw = raw + tid * 9;
             const bool live = q < n;
             rw[0] = live ? x[q * 3] : 0.f, rw[1] = live ? x[q * 3 + 1] : 0.f, rw[2] = live ? x[q * 3 + 2] : 0.f;
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16q(nefii_mlp m, cons
             dest[tid] = live ? out + q : nullptr;
         }
         __syncthreads();
-        sdf_tile16q<4>(m, lds, raw, dest, b, cur, ke);
+        sdf_tile16q<QT, FT>(m, lds, raw, dest, b, cur);
     }
 }
 
@@ -713,36 +713,46 @@ extern "C" int nefii_debug_stamps(unsigned long long *host_out) {
 #endif
 
 constexpr int P16W = 8;      // waves per workgroup of the pipelined kernels
+__device__ __forceinline__ int layer_units_dev(const nefii_layer &L, int ft) {
+    return ft == 2 ? q_units<2>(L) : (L.k_x + L.k_e) >> 4;
+}
 
-// shapes the pipelined kernel takes: every hidden layer 512 wide, k-step counts multiples of 4, a 512-deep last layer
-bool shape16p(const nefii_mlp *m) {
+// shapes the pipelined kernels take: every hidden layer W wide (512; 256 with the 16x16x32 layout only), inputs of 0 or
+// W previous features plus 0 or 64 encoding columns, a W-deep last layer.  Returns the feature tiles per wave
+// (W / 128), 0 when the shape does not fit.
+int shape16p(const nefii_mlp *m) {
     const int NH = m->n_layers - 1;
-    if (NH < 1) return false;
+    if (NH < 1) return 0;
+    const int W = m->layer[0].n_pad;
+    if (W != 512 && !(W == 256 && m->reserved == 1)) return 0;
     for (int l = 0; l < NH; ++l) {
         const nefii_layer &L = m->layer[l];
-        if (L.n_pad != 512 || (L.k_x != 0 && L.k_x != 512) || (L.k_e != 0 && L.k_e != 64) || L.k_x + L.k_e == 0)
-            return false;
+        if (L.n_pad != W || (L.k_x != 0 && L.k_x != W) || (L.k_e != 0 && L.k_e != 64) || L.k_x + L.k_e == 0) return 0;
     }
     const nefii_layer &Ll = m->layer[NH];
-    return Ll.k_x == 512 && Ll.k_e == 0;
+    return Ll.k_x == W && Ll.k_e == 0 ? W / 128 : 0;
 }
-bool fits16p(const nefii_mlp *m) { return m->w_stream && shape16p(m); }
+int fits16p(const nefii_mlp *m) { return m->w_stream ? shape16p(m) : 0; }
 
+int layer_units(const nefii_layer &L, int ft) { return ft == 2 ? q_units<2>(L) : (L.k_x + L.k_e) >> 4; }
 int stream_steps(const nefii_mlp *m) {
+    const int ft = shape16p(m);
     int G = 0;
-    for (int l = 0; l < m->n_layers - 1; ++l) G += (m->layer[l].k_x + m->layer[l].k_e) >> 4;
+    for (int l = 0; l < m->n_layers - 1; ++l) G += layer_units(m->layer[l], ft);
     return G;
 }
 
 // layout 0 (32x32x16 fragments): dst[(wave*G + g)*256 + i] <- the 4 KiB fragment block of (k-step g of the layer
 // sequence, column tiles 2 wave, 2 wave + 1), a straight copy.
-// layout 1 (16x16x32 fragments, nefii_mlp.reserved == 1): unit g is a HALF step (32-deep k-step g/2 of the layer sequence,
-// feature-tile pair g&1): dst[((wave*G + g)*4 + 2 f + part)*64 + lane][j] = W[n = 64 wave + 16 (2 (g&1) + f) + (lane&15)]
-// [k = 32 s32 + 8 (lane>>4) + j], gathered from the layer's 32x32x16 fragments (one source half8 per destination half8).
-__global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int G) {
+// layout 1 (16x16x32 fragments, nefii_mlp.reserved == 1), 512-wide: unit g is a HALF step (32-deep k-step g/2 of the
+// layer sequence, feature-tile pair g&1): dst[((wave*G + g)*4 + 2 f + part)*64 + lane][j] = W[n = 64 wave + 16 (2 (g&1)
+// + f) + (lane&15)][k = 32 s32 + 8 (lane>>4) + j], gathered from the layer's 32x32x16 fragments (one source half8 per
+// destination half8).  256-wide: unit g is a whole 32-deep k-step of the layer's K padded to a multiple of 128,
+// n = 32 wave + 16 f + (lane&15); k-steps past the layer's own K hold zeros.
+__global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int G, int ft) {
     const int g = blockIdx.x, wave = blockIdx.y;
     int l = 0, s = g;
-    while (s >= ((m.layer[l].k_x + m.layer[l].k_e) >> 4)) s -= (m.layer[l].k_x + m.layer[l].k_e) >> 4, ++l;
+    while (s >= layer_units_dev(m.layer[l], ft)) s -= layer_units_dev(m.layer[l], ft), ++l;
     const half8 *w = reinterpret_cast<const half8 *>(m.layer[l].w_f16x3);
     if (m.reserved != 1) {
         const half8 *src = w + ((size_t)s * 16 + 2 * wave) * 2 * 64;
@@ -750,7 +760,17 @@ __global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int
         return;
     }
     const int frag = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int f = frag >> 1, part = frag & 1, half = s & 1, s32 = s >> 1, kg = lane >> 4;
+    const int f = frag >> 1, part = frag & 1, kg = lane >> 4;
+    if (ft == 2) {
+        const int n = 32 * wave + 16 * f + (lane & 15);
+        const int s16 = 2 * s + (kg >> 1), t = n >> 5, lane_src = (n & 31) + 32 * (kg & 1);
+        half8 v;
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+        if (s16 < ((m.layer[l].k_x + m.layer[l].k_e) >> 4)) v = w[(((size_t)s16 * 8 + t) * 2 + part) * 64 + lane_src];
+        dst[((size_t)wave * G + g) * 256 + threadIdx.x] = v;
+        return;
+    }
+    const int half = s & 1, s32 = s >> 1;
     const int n = 64 * wave + 16 * (2 * half + f) + (lane & 15);
     const int s16 = 2 * s32 + (kg >> 1), t = n >> 5, lane_src = (n & 31) + 32 * (kg & 1);
     dst[((size_t)wave * G + g) * 256 + threadIdx.x] = w[(((size_t)s16 * 16 + t) * 2 + part) * 64 + lane_src];
@@ -879,7 +899,8 @@ extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, voi
     for (int l = 0; l < h_sdf->n_layers - 1; ++l)
         if (!h_sdf->layer[l].w_f16x3) return NEFII_E_ARG;
     const int G = stream_steps(h_sdf);
-    hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, (half8 *)w_stream, G);
+    hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, (half8 *)w_stream, G,
+                       shape16p(h_sdf));
     HIP_CHECK_LAUNCH();
     return 0;
 }
@@ -894,10 +915,14 @@ extern "C" int nefii_sdf_eval(const nefii_mlp *h_sdf, const float *x, int64_t n,
     for (int l = 0; l < h_sdf->n_layers; ++l)
         if (!h_sdf->layer[l].w_f16x3 || !h_sdf->layer[l].bias) return NEFII_E_ARG;
     const int64_t n_tiles = (n + TILE_W - 1) / TILE_W;
-    if (fits16p(h_sdf) && h_sdf->reserved == 1)
-        hipLaunchKernelGGL(sdf_points_kernel16q, dim3((int)(n_tiles < 512 ? n_tiles : 512)), dim3(512), 0,
+    const int ft = fits16p(h_sdf);
+    if (ft == 2)
+        hipLaunchKernelGGL(sdf_points_kernel16q<2>, dim3((int)(n_tiles < 512 ? n_tiles : 512)), dim3(512), 0,
                            (hipStream_t)stream, *h_sdf, x, n, sdf_out);
-    else if (fits16p(h_sdf))
+    else if (ft && h_sdf->reserved == 1)
+        hipLaunchKernelGGL(sdf_points_kernel16q<4>, dim3((int)(n_tiles < 512 ? n_tiles : 512)), dim3(512), 0,
+                           (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    else if (ft)
         hipLaunchKernelGGL(sdf_points_kernel16p<P16W>, dim3((int)(n_tiles < 512 ? n_tiles : 512)), dim3(64 * P16W), 0,
                            (hipStream_t)stream, *h_sdf, x, n, sdf_out);
     else
@@ -928,7 +953,7 @@ struct TraceJob {
     Params P;
     const nefii_mlp *sdf;
     int precision, rounds, adv_blocks, eval_blocks, eval_blocks_w;
-    bool pipelined;
+    int pipelined;      // feature tiles per wave of the pipelined evaluator (4 / 2), 0: generic kernels
     hipStream_t st;
     int32_t *counters;
 };
@@ -986,7 +1011,7 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     const int64_t max_q = n_rays * (int64_t)h_params->n_steps;   // n_steps >= 2^levels > bisection tree nodes > 2 ends
     const int64_t max_tiles = (max_q + TILE - 1) / TILE;
     J.eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
-    J.pipelined = h_params->precision == 2 && fits16p(h_sdf);
+    J.pipelined = h_params->precision == 2 ? fits16p(h_sdf) : 0;
     const int64_t max_tiles_w = (max_q + TILE_W - 1) / TILE_W;
     J.eval_blocks_w = (int)(max_tiles_w < 512 ? max_tiles_w : 512);
     return 0;
@@ -1003,11 +1028,17 @@ int launch_round(const TraceJob &J, int r, bool profile) {
             e1 = prof_event();
             (void)hipEventRecord(e0, st);
         }
-        if (J.precision == 2 && J.pipelined && J.sdf->reserved == 1) {
-            hipLaunchKernelGGL((eval_kernel16q<4>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
+        if (J.precision == 2 && J.pipelined == 2) {
+            hipLaunchKernelGGL((eval_kernel16q<6, 2>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();
             const int64_t small_tiles = (J.P.n * 2 + 31) / 32 < 256 ? (J.P.n * 2 + 31) / 32 : 256;
-            hipLaunchKernelGGL((eval_kernel16q<2>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(512), 0, st, J.P,
+            hipLaunchKernelGGL((eval_kernel16q<2, 2>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(512), 0, st, J.P,
+                               *J.sdf, r);
+        } else if (J.precision == 2 && J.pipelined && J.sdf->reserved == 1) {
+            hipLaunchKernelGGL((eval_kernel16q<4, 4>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
+            HIP_CHECK_LAUNCH();
+            const int64_t small_tiles = (J.P.n * 2 + 31) / 32 < 256 ? (J.P.n * 2 + 31) / 32 : 256;
+            hipLaunchKernelGGL((eval_kernel16q<2, 4>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(512), 0, st, J.P,
                                *J.sdf, r);
         } else if (J.precision == 2 && J.pipelined) {
             hipLaunchKernelGGL((eval_kernel16p<P16W, 2>), dim3(J.eval_blocks_w), dim3(64 * P16W), 0, st, J.P, *J.sdf, r);

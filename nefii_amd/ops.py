@@ -90,12 +90,15 @@ class PackedMLP:
         # pipelined tile evaluator of the tracer); other nets leave w_stream NULL and run on the generic kernel
         self.w_stream = None
         if f16x3 and torch.device(device).type == 'cuda':
+            # stream layout / matrix instruction of the pipelined evaluator: 0 = 32x32x16 (512-wide nets only),
+            # 1 = 16x16x32 (512- and 256-wide nets)
+            m.reserved = int(os.environ.get('NEFII_STREAM_LAYOUT', '1'))
             nbytes = _lib.lib().nefii_sdf_stream_bytes(ctypes.byref(m))
             if nbytes and feat_width == 0 and self.enc_freqs[1] < 0 and self.enc_freqs[2] < 0:
                 self.w_stream = torch.zeros(nbytes // 2, device=device, dtype=torch.float16)
                 m.w_stream = self.w_stream.data_ptr()
-                # stream layout / matrix instruction of the pipelined evaluator: 0 = 32x32x16, 1 = 16x16x32
-                m.reserved = int(os.environ.get('NEFII_STREAM_LAYOUT', '1'))
+            else:
+                m.reserved = 0
         self.hidden_stride = max(s.n_pad for s in specs)
         self.packed_version = None
 

@@ -89,10 +89,11 @@ def test_sdf_gradient_trained_like_skip_weights(name, hidden, n, split):
 
 
 @pytest.mark.parametrize('name,hidden,n', [('physg', 512, 1), ('physg', 512, 64), ('conf', 512, 1000), ('neus', None, 333),
-                                           ('physg', 64, 129), ('conf', 512, 70000)])
+                                           ('physg', 64, 129), ('conf', 512, 70000), ('neus', None, 1), ('neus', None, 96),
+                                           ('neus', None, 97), ('neus', None, 70000)])
 def test_sdf_eval_split_precision(name, hidden, n):
     """nefii_sdf_eval = implicit_network(x)[:, 0] on the tracer's split-precision tile evaluators: the pipelined
-    stream kernel for 512-wide nets (PackedMLP.w_stream), the generic wide kernel for the others."""
+    stream kernel for 512- and 256-wide nets (PackedMLP.w_stream), the generic wide kernel for the others."""
     from nefii_amd import ops
     mc = syn.model_conf(name, hidden=hidden)
     sd = syn.make_state_dict(mc, seed=3, bumpy=0.02 if hidden == 64 else 0.004)
@@ -101,7 +102,7 @@ def test_sdf_eval_split_precision(name, hidden, n):
         w = sd['implicit_network.lin%d.weight_v' % l]
         w[:, -36:] = torch.randn(w.shape[0], 36, generator=g) * 0.02
     pm = build_sdf(mc, sd, f16x3=True)
-    assert (pm.w_stream is not None) == (hidden == 512)
+    assert (pm.w_stream is not None) == (hidden != 64)
     x = ball_points(n, 3)
     out = ops.sdf_eval(pm, x.to(DEV)).cpu()
     m = min(n, 4000)
@@ -283,6 +284,38 @@ def test_tracer_vs_oracle_and_counts(hidden, bumpy, n, precision):
         c = ref['counters']
         cpu_evals = sum(c.get(k, 0) for k in ('sphere_trace', 'sampler', 'bisect', 'min_sdf'))
         assert abs(gpu_evals - cpu_evals) <= 0.01 * cpu_evals, (gpu_evals, cpu_evals)
+
+
+@pytest.mark.parametrize('n', [300, 6000])
+def test_tracer_256_wide_net_vs_oracle(monkeypatch, n):
+    """conf_neus.conf's SDF net (8 x 256) runs on the pipelined evaluator's 256-wide shape (96- and 32-query tiles:
+    n = 6000 has rounds on both sides of the switch); NEFII_STREAM_LAYOUT=0 keeps it on the generic wide kernel,
+    and the two agree."""
+    from nefii_amd import ops
+    mc = syn.model_conf('neus')
+    sd = syn.make_state_dict(mc, seed=4, bumpy=0.01)
+    sdf = lambda x: nets.sdf_forward(sd, mc['implicit_network'], x)[:, 0]
+    g = torch.Generator().manual_seed(23)
+    o = torch.randn(n, 3, generator=g)
+    o = o / o.norm(dim=-1, keepdim=True) * (1.5 + torch.rand(n, 1, generator=g))
+    d = torch.randn(n, 3, generator=g) * 0.45 - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    om = torch.rand(n, generator=g) < 0.8
+    steps = torch.rand(100, generator=g)
+    assert build_sdf(mc, sd, f16x3=True).w_stream is not None
+    for training in (False, True):
+        ref = tracer.trace(sdf, o, d, om, mc['ray_tracer'], training, steps)
+        got = run_gpu_trace(mc, sd, o, d, om, training, steps, 'f16x3w')
+        compare_trace(sdf, o, d, got, ref['hit'], ref['dists'], ('neus256', training),
+                      argmin_set(ref['hit'], om, training))
+        monkeypatch.setenv('NEFII_STREAM_LAYOUT', '0')
+        assert build_sdf(mc, sd, f16x3=True).w_stream is None
+        gen = run_gpu_trace(mc, sd, o, d, om, training, steps, 'f16x3w')
+        monkeypatch.delenv('NEFII_STREAM_LAYOUT')
+        assert (got[1] != gen[1]).sum().item() <= 3
+        same = (got[1] == gen[1]) & got[1]
+        assert (got[2][same] - gen[2][same]).abs().median().item() < 2e-6
+        assert abs(int(got[3].sum()) - int(gen[3].sum())) <= 0.01 * int(gen[3].sum())
 
 
 def test_tracer_empty_and_tiny():

@@ -68,10 +68,14 @@ def test_padded_width_rule_matches_host():
 def test_sdf_stream_size():
     from nefii_amd import _lib, ops, synthetic as syn
     lib = _lib.lib()
-    for name, hidden, want in [('physg', 512, 8 * (4 + 32 * 3 + 36 + 32 * 3) * 4096), ('physg', 64, 0), ('neus', None, 0)]:
+    # 512-wide: 16-deep k-steps (either layout); 256-wide: 32-deep k-steps of K padded to 128, 16x16x32 layout only
+    for name, hidden, layout, want in [('physg', 512, 0, 8 * (4 + 32 * 3 + 36 + 32 * 3) * 4096),
+                                       ('physg', 512, 1, 8 * (4 + 32 * 3 + 36 + 32 * 3) * 4096), ('physg', 64, 1, 0),
+                                       ('neus', None, 0, 0), ('neus', None, 1, 8 * (4 + 8 * 3 + 12 + 8 * 3) * 4096)]:
         mc = syn.model_conf(name, hidden=hidden)
         specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
         m = _lib.Mlp()
+        m.reserved = layout
         m.n_layers = len(specs)
         for l, s in enumerate(specs):
             m.layer[l].k_x, m.layer[l].k_e, m.layer[l].n_out, m.layer[l].n_pad = s.k_x, s.k_e, s.n_out, s.n_pad
