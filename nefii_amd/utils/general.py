@@ -1,14 +1,28 @@
 """Host glue with the reference's semantics and signatures (code/utils/general.py:10-37,68-107)."""
+import os
+from glob import glob
+
 import torch
 
 
 def get_class(kls):
     """Dotted path -> class (the drop-in hook: conf key train.model_class, general.py:10-16)."""
     parts = kls.split('.')
+    # the reference's confs name classes relative to its code/ directory (`datasets.scene_dataset.SceneDataset`,
+    # `model.implicit_differentiable_renderer.IDRNetwork`): those resolve to this package's counterparts
+    if parts[0] in ('datasets', 'model', 'training', 'utils'):
+        parts = ['nefii_amd'] + parts
     m = __import__('.'.join(parts[:-1]))
     for comp in parts[1:]:
         m = getattr(m, comp)
     return m
+
+
+def glob_imgs(path):                                             # general.py:18-22
+    imgs = []
+    for ext in ['*.png', '*.jpg', '*.JPEG', '*.JPG', '*.exr']:
+        imgs.extend(glob(os.path.join(path, ext)))
+    return imgs
 
 
 def split_input(model_input, total_pixels, num_rays=1, memory_capacity_level=18):

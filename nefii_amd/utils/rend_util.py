@@ -2,9 +2,44 @@
 
 Only the three functions the hot path uses exist here; image I/O, pose-optimisation helpers etc. are out of
 scope."""
+import numpy as np
 import torch
 
 from .. import ops
+
+
+def _imread(path):
+    """imageio.imread of the reference: float32 [H, W, C] for .exr (own reader, utils/exr.py), uint8 for the rest"""
+    if path.endswith('.exr'):
+        from . import exr
+        return exr.imread(path)
+    from PIL import Image
+    with Image.open(path) as im:
+        if im.mode not in ('L', 'RGB', 'RGBA'):
+            im = im.convert('RGBA' if 'A' in im.getbands() or 'transparency' in im.info else 'RGB')
+        return np.asarray(im)
+
+
+def load_rgb(path):                                              # rend_util.py:13-20
+    img = _imread(path)
+    if img.ndim == 2:
+        img = np.repeat(img[:, :, None], 3, axis=2)
+    img = np.float32(img[:, :, :3])
+    if not path.endswith('.exr'):
+        img = img / 255.
+    return img.transpose(2, 0, 1)                                # [C, H, W]
+
+
+def load_mask(path):                                             # rend_util.py:23-28
+    """`imageio.imread(path, as_gray=True)`: Pillow's mode 'F' conversion (ITU-R 601-2 luma), then > 0.5 of 255"""
+    if path.endswith('.exr'):
+        img = _imread(path)
+        alpha = img if img.ndim == 2 else img[:, :, :3] @ np.array([0.299, 0.587, 0.114], dtype=np.float32)
+    else:
+        from PIL import Image
+        with Image.open(path) as im:
+            alpha = np.asarray(im.convert('F'))
+    return np.float32(alpha) / 255. > 0.5
 
 
 def get_camera_params(uv, pose, intrinsics):

@@ -536,3 +536,53 @@ def test_prefetched_trace_gives_the_same_steps(graph):
     for k in p0:
         if p0[k].dtype.is_floating_point:
             assert rel_l2(p1[k], p0[k]) < 1e-4, (k, rel_l2(p1[k], p0[k]))
+
+
+@pytest.mark.gpu
+def test_runner_on_a_scene_directory_with_exr_ground_truth(tmp_path):
+    """The runner fed from an instance directory as the reference lays it out (cam_dict_norm.json, image/*.exr,
+    mask/*.png) through `datasets.scene_dataset.SceneDataset`, the class name the reference's confs carry."""
+    import json
+    import os
+    import numpy as np
+    from PIL import Image
+    from nefii_amd.training.idr_train import IDRTrainRunner
+    from nefii_amd.utils import exr
+    inst = tmp_path / 'scene'
+    (inst / 'image').mkdir(parents=True)
+    (inst / 'mask').mkdir()
+    H = W = 40
+    g = np.random.Generator(np.random.Philox(1))
+    cams = {}
+    for i in range(4):
+        phi = 2 * np.pi * i / 4
+        c2w = syn.look_at_origin_pose((2.4 * np.sin(phi), 0.4, 2.4 * np.cos(phi)))
+        K = np.eye(4)
+        K[0, 0] = K[1, 1] = 1111.0 * W / 800.0
+        K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+        name = 'rgb_%06d.exr' % i
+        cams[name] = {'K': K.reshape(-1).tolist(), 'W2C': np.linalg.inv(c2w).reshape(-1).tolist(), 'img_size': [W, H]}
+        exr.imwrite(str(inst / 'image' / name), g.uniform(0, 1.5, size=(H, W, 3)).astype(np.float32))
+        yy, xx = np.mgrid[0:H, 0:W]
+        Image.fromarray((((yy - H / 2) ** 2 + (xx - W / 2) ** 2 < 15 ** 2) * 255).astype(np.uint8)).save(
+            inst / 'mask' / ('mask_%06d.png' % i))
+    (inst / 'cam_dict_norm.json').write_text(json.dumps(cams))
+    cfg = _runner_conf(tmp_path, n_pix=128)
+    cfg['train']['dataset_class'] = 'datasets.scene_dataset.SceneDataset'
+    torch.manual_seed(0)
+    r = IDRTrainRunner(conf=cfg, exps_folder_name=str(tmp_path), freeze_geometry=True, nepochs=1000, graph=False,
+                       expname='scene', max_niters=5, new_timestamp='t0', data_split_dir=str(inst), gamma=2.2, log_freq=2)
+    assert type(r.train_dataset).__name__ == 'SceneDataset' and r.train_dataset.img_res == [H, W]
+    assert torch.allclose(r.train_dataset.rgb_images[0].max(), torch.tensor(1.5 ** 2.2), rtol=1e-2)
+    sd = syn.make_state_dict(cfg.get_config('model'), seed=4, bumpy=0.02)
+    r.model.load_state_dict(sd)
+    r.model.freeze_geometry()
+    before = {k: v.clone() for k, v in r.model.state_dict().items()}
+    r.run()
+    assert r.step.cur_iter == 6
+    after = r.model.state_dict()
+    moved = [k for k in before if before[k].dtype.is_floating_point and not torch.equal(before[k].to(after[k].device), after[k])]
+    assert any(k.startswith('envmap_material_network') for k in moved)
+    assert not any(k.startswith('implicit_network') for k in moved)
+    assert all(torch.isfinite(v).all() for v in after.values() if v.dtype.is_floating_point)
+    assert os.path.exists(os.path.join(str(tmp_path), 'scene', 't0', 'checkpoints', 'ModelParameters', 'latest.pth'))
