@@ -69,6 +69,7 @@ class ImplicitNetwork(nn.Module):
             setattr(self, 'lin' + str(l), lin)
         self._pm = None
         self._pm_version = None
+        self._pm_fit = None
 
     def effective_weights(self):
         ws, bs = [], []
@@ -101,9 +102,24 @@ class ImplicitNetwork(nn.Module):
                 'nefii_amd: differentiating through the SDF network (trainable geometry) is outside the Step-2 '
                 'hot path; call IDRNetwork.freeze_geometry() as every shipped Step-2 script does')
 
+    def _trainable(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+
     def forward(self, input, compute_grad=False):
-        self._check_frozen()
         x = ops._f32(input)
+        if self._trainable():
+            # Step-1 geometry fit (geometry_train.py:361): values at given positions, differentiable wrt the weights
+            # (fused forward / backward / weight-gradient kernels; weight_norm stays in autograd).  Gradients wrt the
+            # positions - what trainable geometry inside the renderer would need - are not provided: gradient() and the
+            # tracer keep refusing unfrozen parameters.
+            ws, bs = self.effective_weights()
+            pm = ops.PackedMLP(self.specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, self.enc, 0, x.device) \
+                if self._pm_fit is None or self._pm_fit.device != x.device else self._pm_fit
+            self._pm_fit = pm
+            if self.use_last_as_f:      # the feature columns (last hidden activation) come back as constants
+                out, hidden = ops.FusedMLPHiddenFn.apply(pm, x.detach(), *ws, *bs)
+                return torch.cat([out, hidden], dim=-1)
+            return ops.FusedMLPFn.apply(pm, x.detach(), None, None, None, *ws, *bs)
         out, hidden, _ = ops.mlp_forward(self.packed(), x, None, None, None, want_hidden=self.use_last_as_f)
         if self.use_last_as_f:
             out = torch.cat([out, hidden], dim=-1)

@@ -176,7 +176,8 @@ def encode_inputs(pm, in_a, in_b, in_c, feat):
 
 class FusedMLPFn(torch.autograd.Function):
     """y = MLP(PE(a), PE(b), PE(c), feat); differentiable wrt the layer weights and biases only
-    (the raw inputs come from frozen geometry: IDRNetwork.freeze_geometry, Step-2)."""
+    (the raw inputs come from frozen geometry: IDRNetwork.freeze_geometry, Step-2; in the Step-1 geometry fit the inputs
+    are sample positions)."""
 
     @staticmethod
     def forward(ctx, pm, in_a, in_b, in_c, feat, *wb):
@@ -210,9 +211,13 @@ class FusedMLPFn(torch.autograd.Function):
         for l, s in enumerate(pm.specs):
             if l == 0:
                 xin, xs = x0, x0.shape[1]
+            elif s.e_len:
+                # skip layer: its input is [previous activations | encoded network input] (the 1/sqrt(2) is s.scale)
+                # in the Linear's column order (x_src0 / e_src0 are column offsets into its weight)
+                blocks = [stash[l - 1][:, :s.x_len], x0[:, :s.e_len]]
+                xin = torch.cat(blocks if s.x_src0 < s.e_src0 else blocks[::-1], dim=1).contiguous()
+                xs = xin.shape[1]
             else:
-                if s.e_len:
-                    raise NotImplementedError('weight gradients of skip layers (geometry is frozen in Step-2)')
                 xin, xs = stash[l - 1], pm.hidden_stride
             g = torch.empty(s.n_out, s.k_in, device=d_out.device, dtype=torch.float32)
             b = torch.empty(s.n_out, device=d_out.device, dtype=torch.float32)
@@ -221,6 +226,29 @@ class FusedMLPFn(torch.autograd.Function):
             gw.append(g)
             gb.append(b)
         return (None, None, None, None, None) + tuple(gw) + tuple(gb)
+
+
+class FusedMLPHiddenFn(torch.autograd.Function):
+    """FusedMLPFn that also returns the last hidden activation (ImplicitNetwork with use_last_as_f) as a
+    non-differentiable output: the Step-1 fit consumes the SDF column only."""
+
+    @staticmethod
+    def forward(ctx, pm, in_a, *wb):
+        L = pm.n_layers
+        pm.pack(wb[:L], wb[L:])
+        need = any(t.requires_grad for t in wb)
+        out, hidden, stash = mlp_forward(pm, in_a, None, None, None, want_hidden=True, want_stash=need)
+        ctx.pm = pm
+        empty = in_a.new_empty(0)
+        ctx.save_for_backward(in_a, empty, empty, empty, stash if stash is not None else empty)
+        ctx.has = (False, False, False)
+        ctx.mark_non_differentiable(hidden)
+        return out, hidden
+
+    @staticmethod
+    def backward(ctx, d_out, _d_hidden):
+        g = FusedMLPFn.backward(ctx, d_out)
+        return g[:2] + g[5:]
 
 
 def sdf_value_grad(pm, x, want_feat=False):

@@ -3,11 +3,12 @@
 
 north_star tolerance: relative L2 <= 1e-3 on rendered RGB (sg_rgb_values) and albedo
 (sg_diffuse_albedo_values) on identical rays."""
+import numpy as np
 import pytest
 import torch
 
 from nefii_amd import conf, synthetic as syn
-from oracle import renderer as orr
+from oracle import nets, renderer as orr
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
@@ -586,3 +587,81 @@ def test_runner_on_a_scene_directory_with_exr_ground_truth(tmp_path):
     assert not any(k.startswith('implicit_network') for k in moved)
     assert all(torch.isfinite(v).all() for v in after.values() if v.dtype.is_floating_point)
     assert os.path.exists(os.path.join(str(tmp_path), 'scene', 't0', 'checkpoints', 'ModelParameters', 'latest.pth'))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name,hidden,n', [('physg', 64, 700), ('conf', 512, 300), ('neus', None, 257)])
+def test_sdf_weight_gradients_for_the_geometry_fit(name, hidden, n):
+    """Step-1: d L1(sdf(x), target) / d(weight_v, weight_g, bias) of the SDF network through the fused kernels (skip
+    layer included) against torch autograd on the fp64 oracle."""
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    mc = syn.model_conf(name, hidden=hidden)
+    sd = syn.make_state_dict(mc, seed=6, bumpy=0.02 if hidden == 64 else 0.004)
+    g = torch.Generator().manual_seed(8)
+    for l in mc['implicit_network']['skip_in']:
+        w = sd['implicit_network.lin%d.weight_v' % l]
+        w[:, -36:] = torch.randn(w.shape[0], 36, generator=g) * 0.02
+    m = IDRNetwork(conf.from_dict(mc))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    x = torch.randn(n, 3, generator=g) * 0.5
+    target = torch.randn(n, 1, generator=g) * 0.3
+    net = m.implicit_network
+    net.train()
+    pred = net(x.to(DEV))
+    assert pred.requires_grad and pred.shape == (n, 1 + mc['feature_vector_size'])
+    loss = torch.nn.functional.l1_loss(pred[:, 0:1], target.to(DEV))
+    loss.backward()
+    ref_sd = {k: v.double().clone().requires_grad_(k.startswith('implicit_network')) for k, v in sd.items()}
+    ref = nets.sdf_forward(ref_sd, mc['implicit_network'], x.double())
+    assert rel_l2(pred, ref) < 1e-5
+    ref_loss = torch.nn.functional.l1_loss(ref[:, 0:1], target.double())
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    for k, p in net.named_parameters():
+        want = ref_sd['implicit_network.' + k].grad
+        assert p.grad is not None and rel_l2(p.grad, want) < 1e-3, (k, rel_l2(p.grad, want))
+    with pytest.raises(NotImplementedError):      # gradients wrt positions stay out of scope
+        net.gradient(x.to(DEV))
+
+
+@pytest.mark.gpu
+def test_geometry_fit_runner_regresses_a_box(tmp_path):
+    """GeometryTrainRunner (geometry_train.py): L1 regression of the SDF net onto samples of a mesh; checkpoint layout of
+    the reference; the fitted geometry loads into a Step-2 model through the pretrain_geometry_path route."""
+    import os
+    from nefii_amd.training.geometry_train import GeometryTrainRunner, SUBDIRS
+    from test_geometry_cpu import box_mesh, box_sdf
+    lo, hi = (-0.45, -0.3, -0.35), (0.4, 0.35, 0.3)
+    v, f, _ = box_mesh(lo, hi)
+    cfg = _runner_conf(tmp_path)
+    cfg['train']['idr_learning_rate'] = 1e-3
+    cfg['train']['idr_sched_milestones'] = [200]
+    cfg['train']['ckpt_freq'] = 100
+    torch.manual_seed(0)
+    r = GeometryTrainRunner(conf=cfg, exps_folder_name=str(tmp_path), expname='s1', new_timestamp='t0', mesh=(v, f),
+                            scale_to_unit=False, sample_num=512, batch_size=4096, max_niters=1000, nepochs=1, log_freq=50)
+    # 1000 items of 512 samples, 8 per batch: 125 iterations per epoch, epochs 0 and 1 (geometry_train.py:347)
+    assert r.train_dataloader.batch_size == 8 and len(r.train_dataloader) == 125
+    hist = r.run()
+    assert r.cur_iter == 250 and hist[0][1] > 5 * hist[-1][1], hist
+    assert abs(r.idr_scheduler.get_last_lr()[0] - 5e-4) < 1e-12
+    ck = os.path.join(str(tmp_path), 's1', 't0', 'checkpoints')
+    for sub in SUBDIRS.values():
+        # keyed by the batch index within the epoch (geometry_train.py:352-353): iterations 0, 100, 200 = batches 0, 100, 75
+        assert sorted(os.listdir(os.path.join(ck, sub))) == ['0.pth', '1.pth', '100.pth', '75.pth', 'latest.pth'], sub
+    d = torch.load(os.path.join(ck, 'ModelParameters', 'latest.pth'))
+    assert set(d) == {'epoch', 'model_state_dict'}
+    # the fitted field through the frozen (Step-2) evaluation path
+    g = np.random.Generator(np.random.Philox(4))
+    p = g.uniform(-0.8, 0.8, size=(3000, 3))
+    m = build_model(cfg.get_config('model'), d['model_state_dict'], training=False)
+    with torch.no_grad():
+        pred = m.implicit_network(torch.from_numpy(p).float().to(DEV))[:, 0].cpu().numpy()
+    err = np.abs(pred - box_sdf(p, lo, hi))
+    assert err.mean() < 0.03, err.mean()
+    cont = GeometryTrainRunner(conf=cfg, exps_folder_name=str(tmp_path), expname='s1', new_timestamp='t1', mesh=(v, f),
+                               scale_to_unit=False, sample_num=512, batch_size=4096, max_niters=5, is_continue=True)
+    a, b = cont.model.state_dict(), d['model_state_dict']
+    assert all(torch.equal(a[k].cpu(), b[k].cpu()) for k in b)
+    assert cont.idr_optimizer.state_dict()['state'][0]['step'] == 250
