@@ -120,6 +120,9 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='cfg2')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side-measurement', action='store_true',
+                    help='skip the untimed side loop without the min-SDF search (profiling runs: every step of the process\n'
+                         'is then the headline step, so rocprofv3 per-kernel averages compare directly)')
     ap.add_argument('--cpu-sample-pixels', type=int, default=512)
     args = ap.parse_args()
 
@@ -201,17 +204,19 @@ def main():
 
     # side measurement, NOT the headline: the same step without the min-SDF search that is dead work under frozen
     # geometry (RayTracing.skip_min_sdf_search; same gradients, different mask_loss value)
-    model.ray_tracer.skip_min_sdf_search = True
-    for _ in range(3):
-        step(inp, gt, nxt)
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    for _ in range(max(args.steps // 2, 1)):
-        step(inp, gt, nxt)
-    torch.cuda.synchronize()
-    ms_skip = (time.perf_counter() - t2) / max(args.steps // 2, 1) * 1e3
-    model.ray_tracer.skip_min_sdf_search = False
-    step(inp, gt)
+    ms_skip = None
+    if not args.no_side_measurement:
+        model.ray_tracer.skip_min_sdf_search = True
+        for _ in range(3):
+            step(inp, gt, nxt)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(max(args.steps // 2, 1)):
+            step(inp, gt, nxt)
+        torch.cuda.synchronize()
+        ms_skip = (time.perf_counter() - t2) / max(args.steps // 2, 1) * 1e3
+        model.ray_tracer.skip_min_sdf_search = False
+        step(inp, gt)
 
     # ---- roofline of the dominant kernel: one extra, un-timed step with per-launch HIP events.  Every rank runs the step
     # (it contains the gradient all-reduce); only rank 0 instruments and reports it.
@@ -220,6 +225,8 @@ def main():
     model.ray_tracer.collect_counters = True
     model.ray_tracer.counter_sum = None
     model.ray_tracer.stream_groups = 1      # the profiled step runs the rounds back to back on one stream
+    if nxt is not None and not model.ray_tracer.bisect_levels:
+        model.ray_tracer.bisect_levels = 3  # as the timed steps' traces run (TrainStep.prefetch_trace): same rounds per step
     if rank == 0:
         lib.nefii_trace_profile_enable(1)
     torch.cuda.synchronize()

@@ -11,13 +11,14 @@ import sys
 
 def per_launch(path, counter, kern):
     """bytes summed over every dispatch of the kernel; launches = tracer rounds.  The pipelined kernel is dispatched twice
-    per round (64-query and 32-query instance, one of them exits at once): the `<8, 1>` (16p) / `<2>` (16q) dispatches add their bytes but
+    per round (64-query and 32-query instance, one of them exits at once): the `<8, 1>` (16p) / `<2, FT>` (16q) dispatches add their bytes but
     are not counted as launches, like the HIP events of bench.py bracket both dispatches of a round."""
     tot, disp = 0.0, set()
     for r in csv.DictReader(open(path)):
         if kern in r['Kernel_Name'] and r['Counter_Name'] == counter:
             tot += float(r['Counter_Value'])
-            if ', 1>(' not in r['Kernel_Name'] and '<2>(' not in r['Kernel_Name']:
+            name = r['Kernel_Name']
+            if ', 1>(' not in name and '<2>(' not in name and 'eval_kernel16q<2, ' not in name:
                 disp.add(r['Dispatch_Id'])
     return tot, len(disp)
 

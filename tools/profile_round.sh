@@ -7,7 +7,7 @@ TAG=${1:-r01b}; WL=${2:-cfg2}; KERN=${3:-eval_kernel16q}
 O=gpurun_out/$TAG; S=/tmp/prof_$TAG
 mkdir -p $O $S
 python3 bench.py --workload $WL --steps 20 --warmup 5 > $O/bench_$WL.json 2> $O/bench_err.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $S/ks -- python3 bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${WL}_under_rocprof.json 2> $O/ks_err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $S/ks -- python3 bench.py --workload $WL --steps 20 --warmup 5 --no-cpu-baseline --no-side-measurement > $O/bench_${WL}_under_rocprof.json 2> $O/ks_err.log
 cp $(find $S/ks -name "*kernel_stats.csv" | head -1) $O/bench_${WL}_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $S/pf -- python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pf_err.log
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $S/pw -- python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pw_err.log
