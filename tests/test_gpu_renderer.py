@@ -587,6 +587,20 @@ def test_runner_on_a_scene_directory_with_exr_ground_truth(tmp_path):
     assert not any(k.startswith('implicit_network') for k in moved)
     assert all(torch.isfinite(v).all() for v in after.values() if v.dtype.is_floating_point)
     assert os.path.exists(os.path.join(str(tmp_path), 'scene', 't0', 'checkpoints', 'ModelParameters', 'latest.pth'))
+    # ... and the render script over the same directory as its test split, from view 2 on, then evaluate.py
+    from nefii_amd.scripts.render import RenderRunner
+    from nefii_amd.scripts import evaluate as ev
+    rr = RenderRunner(conf=cfg, exps_folder_name=str(tmp_path), expname='scene', timestamp='latest', checkpoint='latest',
+                      new_timestamp='t1', data_split_dir_test=str(inst), gamma=2.2, memory_capacity_level=10, start_index=2,
+                      num_rays=4)
+    assert rr.run() == [2, 3]
+    plots = os.path.join(str(tmp_path), 'scene', 't1', 'plots')
+    files = sorted(os.listdir(plots))
+    assert 'envmap.exr' in files and 'render_002.png' in files and 'rerender_rgb-003.exr' in files and len(files) == 17
+    gt2 = exr.imread(os.path.join(plots, 'gt-002.exr'))
+    assert gt2.shape == (H, W, 3) and np.allclose(gt2.reshape(-1, 3), r.train_dataset.rgb_images[2].numpy())
+    pred = exr.imread(os.path.join(plots, 'rerender_rgb-002.exr'))
+    assert np.isfinite(pred).all() and pred.max() > 0
 
 
 @pytest.mark.gpu
