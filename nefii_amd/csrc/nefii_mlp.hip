@@ -435,6 +435,11 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const float *__restrict_
     }
 }
 
+__global__ void zero_fill_kernel(float *__restrict__ p, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.f;
+}
+
 extern "C" int nefii_mlp_wgrad(const float *dz, int dz_stride, const float *x, int x_stride, int64_t n, int n_out,
                                int k_in, float scale, float *dW, float *db, void *stream) {
     if (!dz || !x || !dW || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
@@ -443,11 +448,14 @@ extern "C" int nefii_mlp_wgrad(const float *dz, int dz_stride, const float *x, i
     if (split < 1) split = 1;
     if (split > 32) split = 32;
     if (split > 1 || n <= 0) {
-        hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * (size_t)n_out * k_in, st);
-        if (e != hipSuccess) return (int)e;
+        // a kernel, not hipMemsetAsync: inside a captured hipGraph (TrainStep(graph=True)) the memset node did not
+        // reliably precede the accumulating kernel on replay - weight gradients picked up non-finite garbage
+        const size_t nw = (size_t)n_out * k_in;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, dW, nw);
+        HIP_CHECK_LAUNCH();
         if (db) {
-            e = hipMemsetAsync(db, 0, sizeof(float) * n_out, st);
-            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, db, (size_t)n_out);
+            HIP_CHECK_LAUNCH();
         }
     }
     if (n <= 0) return 0;

@@ -739,3 +739,62 @@ def test_render_writes_the_buffers_evaluate_reads(tmp_path):
     res = ev.main(plots, str(gtd))
     assert 20 < res['rgb']['psnr'] < 60 and res['roughness']['mse'] == 0 and res['sp_rgb']['psnr'] == float('inf')
     assert res['diffuse_align']['psnr'] > res['diffuse']['psnr'] + 3
+
+
+@pytest.mark.gpu
+def test_step2_training_recovers_a_rendered_target():
+    """The whole Step-2 loop learns, eagerly and with the captured step alike: ground truth = renders of a 'teacher'
+    material / light on frozen geometry, the student starts from a different material / light; 120 TrainStep iterations
+    over 12 pixel batches (different hit counts, one padded size: one graph replayed ~115 times; the next batches'
+    traces prefetched) bring the rgb loss down several times.  In graph mode every gradient of every replay is also
+    compared with an eager recomputation: this is the test that caught weight gradients zeroed by a hipMemsetAsync
+    node going non-finite after a few replays (nefii_mlp_wgrad now zeroes with a kernel)."""
+    from nefii_amd.model.loss import IDRLoss
+    from nefii_amd.training.step import TrainStep
+    mc = syn.model_conf('physg', hidden=64)
+    lc = syn.loss_conf('physg')
+    teacher = build_model(mc, syn.make_state_dict(mc, seed=11, bumpy=0.0), training=False)
+    sd = syn.make_state_dict(mc, seed=12, bumpy=0.0)
+    for k, v in teacher.state_dict().items():           # same geometry (and radiance field), different material / light
+        if not k.startswith('envmap_material_network'):
+            sd[k] = v.cpu().clone()
+
+    def batch(seed):
+        inp, _ = syn.make_inputs(1024, (96, 96), 130.0, (0.3, 0.2, 2.2), -1, seed=seed)
+        inp = to_dev(inp)
+        with torch.no_grad():
+            target = teacher(inp)
+        return inp, {'rgb': target['sg_rgb_values'].reshape(1, -1, 3).clone()}
+
+    batches = [batch(100 + i) for i in range(12)]
+    loss_fn = IDRLoss(**lc)
+    final = {}
+    for graph in (False, True):
+        student = build_model(mc, sd, training=True)
+        shadow = build_model(mc, sd, training=True)
+        step = TrainStep(student, lc, idr_lr=5e-4, sg_lr=5e-3, graph=graph, graph_after=3)
+        losses = []
+        for it in range(120):
+            inp, gt = batches[it % 12]
+            nxt = [batches[(it + 1) % 12][0], batches[(it + 2) % 12][0]]
+            if graph:
+                shadow.load_state_dict(student.state_dict())
+            out, lo = step(inp, gt, nxt)
+            losses.append(lo['sg_rgb_loss'].item())
+            if graph and it >= 3:
+                for p in shadow.parameters():
+                    p.grad = None
+                loss_fn(shadow(inp), gt)['loss'].backward()
+                for (name, p), (_, q) in zip(student.named_parameters(), shadow.named_parameters()):
+                    if q.grad is not None:
+                        assert torch.isfinite(p.grad).all(), (it, name)
+                        assert rel_l2(p.grad, q.grad) < 1e-3, (it, name, rel_l2(p.grad, q.grad))
+        first, last = sum(losses[:12]) / 12, sum(losses[-12:]) / 12
+        assert last < 0.4 * first and all(l == l for l in losses), (graph, first, last)
+        for opt in (step.idr_optimizer, step.sg_optimizer):
+            for st in opt.state_dict()['state'].values():
+                assert torch.isfinite(st['exp_avg_sq']).all() and torch.isfinite(st['exp_avg']).all()
+        if graph:
+            assert len(step._graphs) == 1
+        final[graph] = last
+    assert abs(final[True] - final[False]) < 0.15 * final[False], final
