@@ -742,7 +742,8 @@ def test_render_writes_the_buffers_evaluate_reads(tmp_path):
 
 
 @pytest.mark.gpu
-def test_step2_training_recovers_a_rendered_target():
+@pytest.mark.parametrize('name,num_rays,iters,drop', [('physg', -1, 120, 0.4), ('physg', 4, 72, 0.5), ('conf', 4, 72, 0.8)])
+def test_step2_training_recovers_a_rendered_target(name, num_rays, iters, drop):
     """The whole Step-2 loop learns, eagerly and with the captured step alike: ground truth = renders of a 'teacher'
     material / light on frozen geometry, the student starts from a different material / light; 120 TrainStep iterations
     over 12 pixel batches (different hit counts, one padded size: one graph replayed ~115 times; the next batches'
@@ -751,8 +752,12 @@ def test_step2_training_recovers_a_rendered_target():
     node going non-finite after a few replays (nefii_mlp_wgrad now zeroes with a kernel)."""
     from nefii_amd.model.loss import IDRLoss
     from nefii_amd.training.step import TrainStep
-    mc = syn.model_conf('physg', hidden=64)
-    lc = syn.loss_conf('physg')
+    # also with several jittered rays per pixel, and - eager only: its Monte-Carlo shading draws fresh samples every call,
+    # so a recomputed gradient is not reproducible - for the conf.conf model (MC direct + near-field indirect shading,
+    # secondary-consistency step every 10 iterations)
+    mc = syn.model_conf(name, hidden=64)
+    lc = syn.loss_conf(name)
+    mc_shading = mc.get('render_type', 'sg') != 'sg'
     teacher = build_model(mc, syn.make_state_dict(mc, seed=11, bumpy=0.0), training=False)
     sd = syn.make_state_dict(mc, seed=12, bumpy=0.0)
     for k, v in teacher.state_dict().items():           # same geometry (and radiance field), different material / light
@@ -760,7 +765,7 @@ def test_step2_training_recovers_a_rendered_target():
             sd[k] = v.cpu().clone()
 
     def batch(seed):
-        inp, _ = syn.make_inputs(1024, (96, 96), 130.0, (0.3, 0.2, 2.2), -1, seed=seed)
+        inp, _ = syn.make_inputs(1024 if num_rays < 0 else 256, (96, 96), 130.0, (0.3, 0.2, 2.2), num_rays, seed=seed)
         inp = to_dev(inp)
         with torch.no_grad():
             target = teacher(inp)
@@ -769,12 +774,13 @@ def test_step2_training_recovers_a_rendered_target():
     batches = [batch(100 + i) for i in range(12)]
     loss_fn = IDRLoss(**lc)
     final = {}
-    for graph in (False, True):
+    for graph in ((False,) if mc_shading else (False, True)):
         student = build_model(mc, sd, training=True)
         shadow = build_model(mc, sd, training=True)
-        step = TrainStep(student, lc, idr_lr=5e-4, sg_lr=5e-3, graph=graph, graph_after=3)
+        step = TrainStep(student, lc, idr_lr=5e-4, sg_lr=5e-3, graph=graph, graph_after=3, num_rays=num_rays,
+                         secondary_train_interval=10 if mc_shading else 0, secondary_batch_size=256)
         losses = []
-        for it in range(120):
+        for it in range(iters):
             inp, gt = batches[it % 12]
             nxt = [batches[(it + 1) % 12][0], batches[(it + 2) % 12][0]]
             if graph:
@@ -790,11 +796,14 @@ def test_step2_training_recovers_a_rendered_target():
                         assert torch.isfinite(p.grad).all(), (it, name)
                         assert rel_l2(p.grad, q.grad) < 1e-3, (it, name, rel_l2(p.grad, q.grad))
         first, last = sum(losses[:12]) / 12, sum(losses[-12:]) / 12
-        assert last < 0.4 * first and all(l == l for l in losses), (graph, first, last)
+        assert last < drop * first and all(l == l for l in losses), (graph, first, last)
         for opt in (step.idr_optimizer, step.sg_optimizer):
             for st in opt.state_dict()['state'].values():
                 assert torch.isfinite(st['exp_avg_sq']).all() and torch.isfinite(st['exp_avg']).all()
         if graph:
-            assert len(step._graphs) == 1
+            assert 1 <= len(step._graphs) <= 4          # padded hit counts: a handful of graphs, replayed ~100 times
         final[graph] = last
-    assert abs(final[True] - final[False]) < 0.15 * final[False], final
+        for k, v in student.state_dict().items():
+            assert not v.dtype.is_floating_point or torch.isfinite(v).all(), k
+    if not mc_shading:
+        assert abs(final[True] - final[False]) < 0.15 * final[False], final
