@@ -234,7 +234,16 @@ def main():
     out, lo = step(inp, gt)
     torch.cuda.synchronize()
     prof_step_ms = (time.perf_counter() - t1) * 1e3
+    # data-parallel sanity: after identical initialisation and all-reduced gradients every rank must hold the same
+    # parameters - the relative spread of a parameter checksum over the ranks is reported (0.0 for one process)
+    param_spread = 0.0
     if world > 1:
+        chk = torch.stack([p.detach().double().abs().sum() for p in model.parameters()]).sum().reshape(1)
+        chk = chk.to(dev if backend == 'nccl' else 'cpu')
+        hi, lo_ = chk.clone(), chk.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        param_spread = float((hi - lo_).item() / max(abs(hi.item()), 1e-30))
         dist.barrier()
         dist.destroy_process_group()        # nothing below communicates (rank 0 alone runs the CPU baseline)
 
@@ -297,6 +306,7 @@ def main():
                                       else 'MC direct + near-field indirect ON'),
                        'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
                        'step_graph': bool(use_graph),
+                       'rank_param_spread': param_spread,
                        'trace_prefetch': len(nxt) if nxt is not None else 0,   # batches traced ahead, beside the tail of batch i
 
                        'loss': float(lo['loss'].item())},

@@ -500,6 +500,7 @@ def test_bench_two_processes_share_one_gpu():
     d = json.loads(line)
     assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['value'] > 0
     assert d['config']['primary_rays_per_step_per_gpu'] == 4096
+    assert d['config']['rank_param_spread'] < 1e-9       # both ranks hold the same parameters after 8+ synchronised steps
 
 
 @pytest.mark.parametrize('graph', [False, True])
