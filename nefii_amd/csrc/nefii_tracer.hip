@@ -631,15 +631,29 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
     const int n_tri = P.counters[round * 4 + 2];
     const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
     const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
-    if ((total <= SMALL_ROUND) != (QT == 2)) return;
-    constexpr int ROWS = 16 * QT;
-    const int64_t n_tiles = (total + ROWS - 1) / ROWS;
+    // Which instance takes which queries.  Rounds up to SMALL_ROUND: all in 32-query tiles.  Larger rounds: big tiles
+    // (64 / 96 queries); when the big tiles form whole waves of one tile per CU plus a remainder that fits one wave of
+    // 32-query tiles, that remainder goes to the 32-query instance (a wave of those is done in ~110 instead of ~160 us).
+    constexpr int ROWS = 16 * QT, BIG = QGeo<FT>::ROWS, NCU = 256;
+    int64_t first = 0, n_tiles;                     // this instance's tiles: first .. first + n_tiles - 1, ROWS queries each
+    if (total <= SMALL_ROUND) {
+        n_tiles = QT == 2 ? (total + 31) / 32 : 0;
+    } else {
+        const int64_t nbig = (total + BIG - 1) / BIG, whole = nbig / NCU * NCU, rem = nbig - whole;
+        const bool split = whole > 0 && rem > 0 && rem * (BIG / 32) <= NCU;
+        if (QT == 2) {
+            first = split ? whole * (BIG / 32) : 0;
+            n_tiles = split ? (total - whole * BIG + 31) / 32 : 0;
+        } else {
+            n_tiles = split ? whole : nbig;
+        }
+    }
     if (blockIdx.x >= n_tiles) return;
     P16<8>::Stage b[4];
     PCursor cur;
     prime16q<FT>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile<ROWS>(P, tile, total, n_single, n_sd, raw, dest);
+        decode_tile<ROWS>(P, first + tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
         sdf_tile16q<QT, FT>(m, lds, raw, dest, b, cur);
     }
