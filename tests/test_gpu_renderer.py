@@ -726,6 +726,12 @@ def test_render_writes_the_buffers_evaluate_reads(tmp_path):
         ref = (l[:, -3:].abs() * torch.exp(l[:, 3:4].abs() * ((dirs[..., None, :] * ax).sum(-1, keepdim=True) - 1))).sum(-2)
         assert rel_l2(env, ref) < 1e-5
     assert abs(R.envmap_directions(8, 16, False, 'blender')[0, 0] - torch.tensor([0., 0., 1.])).max() < 1e-6
+    import os as _os
+    gold = dict(np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'golden', 'envmap_ref.npz')))
+    for ct in ('mitsuba', 'blender'):           # the kernel against the reference's compute_envmap (make_envmap_golden.py)
+        for hemi in (False, True):
+            env = R.compute_envmap(torch.from_numpy(gold['lgtSGs']).to(DEV), 12, 20, upper_hemi=hemi, coordinate_type=ct)
+            assert rel_l2(env, torch.from_numpy(gold['%s_%d' % (ct, int(hemi))])) < 1e-5, (ct, hemi)
     R.write_envmap(m, plots)
     assert exr.imread(os.path.join(plots, 'envmap.exr')).shape == (256, 512, 3)
     # evaluate.py over a ground-truth directory built from the same buffers

@@ -80,3 +80,21 @@ def test_evaluate_directory_walk_and_results_file(tmp_path):
     assert set(res['diffuse']) == {'psnr', 'ssim', 'ms_ssim', 'lpips', 'mse'} and np.isnan(res['rgb']['lpips'])
     txt = (tmp_path / 'exp' / 'results.txt').read_text()
     assert '>>>>>>>>>>rgb        <<<<<<<<<<' in txt and 'psnr       ssim       ms_ssim    lpips' in txt
+
+
+def test_envmap_grid_matches_the_reference():
+    """lat-long direction grids of both axis conventions (+ upper hemisphere) and the SG sum over them, against
+    sg_render.compute_envmap run by tests/golden/make_envmap_golden.py"""
+    from nefii_amd.training.render import envmap_directions
+    g = dict(np.load(os.path.join(HERE, 'golden', 'envmap_ref.npz')))
+    l = torch.from_numpy(g['lgtSGs'])
+    ax = l[:, :3] / l[:, :3].norm(dim=-1, keepdim=True)
+    for ct in ('mitsuba', 'blender'):
+        for hemi in (False, True):
+            dirs = envmap_directions(12, 20, hemi, ct)
+            sg = (l[:, -3:].abs() * torch.exp(l[:, 3:4].abs() * ((dirs[..., None, :] * ax).sum(-1, keepdim=True) - 1.))).sum(-2)
+            ref = torch.from_numpy(g['%s_%d' % (ct, int(hemi))])
+            assert sg.shape == ref.shape == (12, 20, 3)
+            assert (sg - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), (ct, hemi)
+    with pytest.raises(ValueError):
+        envmap_directions(4, 8, False, 'opengl')
