@@ -169,3 +169,32 @@ def test_synthetic_dataset_follows_scene_dataset_contract():
     assert (jit[0] - jit[7]).abs().max() < 1e-6                          # one jitter set for every pixel
     batch = ds.collate_fn([ds[0], ds[2]])
     assert batch[0].tolist() == [0, 2] and batch[1]['uv'].shape == (2, 16, 5, 2) and batch[2]['rgb'].shape == (2, 16, 3)
+
+
+def test_chunking_helpers_match_the_reference():
+    """split_input / merge_output / scatter_list and render.py's round-robin chunk order, against arrays produced by the
+    reference's own functions (tests/golden/make_general_golden.py)."""
+    import os
+    import numpy as np
+    from nefii_amd.training import render as R
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'general_ref.npz')))
+    for tag, total, num_rays, level, batch in (('single', 77, -1, 4, 1), ('multi', 50, 3, 5, 2)):
+        uv, mask = torch.from_numpy(g[tag + '_uv']), torch.from_numpy(g[tag + '_mask'])
+        inp = {'uv': uv, 'object_mask': mask, 'pose': torch.eye(4)[None].repeat(batch, 1, 1)}
+        split = utils.split_input(inp, total, num_rays, level)
+        assert [s['uv'].shape[1] for s in split] == g[tag + '_sizes'].tolist()
+        assert np.array_equal(split[1]['uv'].numpy(), g[tag + '_first_uv'])
+        assert split[0]['pose'] is inp['pose'] or torch.equal(split[0]['pose'], inp['pose'])
+        res = [{'a': s['uv'].reshape(batch, s['uv'].shape[1], -1).sum(-1).reshape(-1),
+                'b': s['uv'].reshape(batch, s['uv'].shape[1], -1)[..., :2].reshape(-1, 2), 'none': None} for s in split]
+        merged = utils.merge_output(res, total, batch)
+        assert 'none' not in merged
+        assert np.array_equal(merged['a'].numpy(), g[tag + '_merged_a'])
+        assert np.array_equal(merged['b'].numpy(), g[tag + '_merged_b'])
+        for world in (2, 3):
+            order, slices = R.plan_chunks(len(split), world)
+            assert order == g['%s_order_w%d' % (tag, world)].tolist()
+            for rank in range(world):
+                want = g['%s_scatter_w%d_r%d' % (tag, world, rank)].tolist()
+                assert order[slices[rank][0]:slices[rank][1]] == want
+                assert utils.scatter_list(order, len(order), rank, world) == want
