@@ -45,6 +45,8 @@ def main(argv=None):
                    help="default: the conf's train.dataset_class; nefii_amd.datasets.synthetic_dataset."
                         "SyntheticSceneDataset needs no data on disk")
     p.add_argument('--no_graph', default=False, action='store_true')
+    p.add_argument('--plots', default=False, action='store_true',
+                   help="every train.plot_freq iterations render one training view and write its buffers under plots/")
     opt, _ignored = p.parse_known_args(argv)
     from nefii_amd.training.idr_train import IDRTrainRunner
     local_rank = opt.local_rank if opt.local_rank > -1 else (int(os.environ['LOCAL_RANK']) if 'RANK' in os.environ else -1)
@@ -60,7 +62,7 @@ def main(argv=None):
         pretrain_geometry_path=opt.pretrain_geometry_path, pretrain_idr_rendering_path=opt.pretrain_idr_rendering_path,
         pretrain_diffuse_path=opt.pretrain_diffuse_path, light_sg_path=opt.light_sg, geometry_neus=opt.geometry_neus,
         local_rank=local_rank, model_class=opt.model_class, dataset_class=opt.dataset_class or None,
-        graph=not opt.no_graph)
+        graph=not opt.no_graph, plots=opt.plots)
     runner.run()
 
 

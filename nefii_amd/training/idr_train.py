@@ -9,7 +9,7 @@ checkpoint continues here and vice versa:
 One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the launcher; the reference's --local_rank also works); the
 per-iteration work is training/step.py:TrainStep (forward, IDRLoss, backward, gradient all-reduce, 2x Adam, 2x
 MultiStepLR, alpha milestones, roughness/specular warm-up, secondary-consistency step).  Not built: tensorboard
-logging, plots (vis_train/vis_test/plot_to_disk), camera optimisation, the view-diff pixel pairing - the reference's
+logging (vis_train writes its images as files instead, `plot_freq`), vis_test / plot_to_disk, camera optimisation, the view-diff pixel pairing - the reference's
 image stack is not installed and none of it is on the hot path."""
 import os
 import sys
@@ -86,6 +86,15 @@ class IDRTrainRunner:
         self.train_dataloader = torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size,
                                                             collate_fn=self.train_dataset.collate_fn, sampler=sampler)
         self.n_batches = len(self.train_dataloader)
+        # vis_train (idr_train.py:380-610): every `train.plot_freq` iterations rank 0 renders one training view in eval mode
+        # and writes the frame's buffers (the reference sends the same images to tensorboard).  Off unless asked for:
+        # `plot_freq` keyword (None: the conf's value when `plots=True`, else never).
+        pf = kwargs.get('plot_freq')
+        if pf is None and kwargs.get('plots', False):
+            pf = self.conf.get_int('train.plot_freq', default=0)
+        self.plot_freq = int(pf or 0)
+        self.plot_num_rays = kwargs.get('plot_num_rays', 1)
+        self.memory_capacity_level = kwargs.get('memory_capacity_level', 18)
 
         model_cls = kwargs.get('model_class') or self.conf.get_string('train.model_class')
         self.model = utils.get_class(model_cls)(conf=self.conf.get_config('model')).to(self.device)
@@ -165,6 +174,28 @@ class IDRTrainRunner:
             for name in (str(epoch), 'latest'):
                 torch.save(payload[key], os.path.join(self.checkpoints_path, sub, name + '.pth'))
 
+    def vis_train(self, it):
+        """one training view through the eval-mode full-frame path, written to <timestamp>/plots as the render script
+        writes its frames (training/render.py:write_frame); the sampling state of the dataset is put back afterwards"""
+        from . import render as R
+        ds = self.train_dataset
+        keep = (ds.sampling_idx, ds.sampling_rays)
+        ds.sampling_idx, ds.sampling_rays = None, None
+        try:
+            if self.plot_num_rays > 1:
+                ds.change_sampling_rays(self.plot_num_rays)
+            view = (it // self.plot_freq) % len(ds)
+            idx, sample, gt = ds.collate_fn([ds[view]])
+            model_input = {k: v.to(self.device) for k, v in sample.items()}
+            self.model.eval()
+            out = R.render_frame(self.model, model_input, ds.total_pixels, num_rays=max(self.plot_num_rays, 1),
+                                 memory_capacity_level=self.memory_capacity_level)
+            plots = os.path.join(self.expdir, self.timestamp, 'plots')
+            R.write_frame(self.model, out, gt['rgb'].to(self.device), model_input['pose'], ds.img_res, plots, it)
+        finally:
+            ds.sampling_idx, ds.sampling_rays = keep
+            self.model.train()
+
     def _resample(self):
         r = self.loss.r_patch
         ds = self.train_dataset
@@ -212,6 +243,8 @@ class IDRTrainRunner:
                 it = self.step.cur_iter
                 if self.rank == 0 and it % self.ckpt_freq == 0:                      # :695-696 (before the step)
                     self.save_checkpoints(epoch)
+                if self.rank == 0 and self.plot_freq > 0 and it % self.plot_freq == 0:    # :698-700
+                    self.vis_train(it)
                 _, lo = self.step(model_input, ground_truth, next_input if self.prefetch else None)
                 if it % self.log_freq == 0:
                     loss = lo['loss'].item()

@@ -573,7 +573,8 @@ def test_runner_on_a_scene_directory_with_exr_ground_truth(tmp_path):
     cfg['train']['dataset_class'] = 'datasets.scene_dataset.SceneDataset'
     torch.manual_seed(0)
     r = IDRTrainRunner(conf=cfg, exps_folder_name=str(tmp_path), freeze_geometry=True, nepochs=1000, graph=False,
-                       expname='scene', max_niters=5, new_timestamp='t0', data_split_dir=str(inst), gamma=2.2, log_freq=2)
+                       expname='scene', max_niters=5, new_timestamp='t0', data_split_dir=str(inst), gamma=2.2, log_freq=2,
+                       plot_freq=3, memory_capacity_level=10)
     assert type(r.train_dataset).__name__ == 'SceneDataset' and r.train_dataset.img_res == [H, W]
     assert torch.allclose(r.train_dataset.rgb_images[0].max(), torch.tensor(1.5 ** 2.2), rtol=1e-2)
     sd = syn.make_state_dict(cfg.get_config('model'), seed=4, bumpy=0.02)
@@ -588,6 +589,11 @@ def test_runner_on_a_scene_directory_with_exr_ground_truth(tmp_path):
     assert not any(k.startswith('implicit_network') for k in moved)
     assert all(torch.isfinite(v).all() for v in after.values() if v.dtype.is_floating_point)
     assert os.path.exists(os.path.join(str(tmp_path), 'scene', 't0', 'checkpoints', 'ModelParameters', 'latest.pth'))
+    # vis_train wrote views 0 and 1 at iterations 0 and 3 (eval-mode full frames beside the training batches)
+    tp = os.path.join(str(tmp_path), 'scene', 't0', 'plots')
+    assert sorted(f for f in os.listdir(tp) if f.startswith('render_')) == ['render_000.png', 'render_003.png']
+    assert exr.imread(os.path.join(tp, 'rerender_rgb-003.exr')).shape == (H, W, 3)
+    assert r.train_dataset.sampling_idx is not None and r.model.training
     # ... and the render script over the same directory as its test split, from view 2 on, then evaluate.py
     from nefii_amd.scripts.render import RenderRunner
     from nefii_amd.scripts import evaluate as ev
