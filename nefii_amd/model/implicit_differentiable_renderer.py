@@ -321,7 +321,13 @@ class IDRNetwork(nn.Module):
                 pre = self.implicit_network.value_feature_gradient(points)
                 sdf_output = pre[0]
             else:
-                sdf_output = self.implicit_network(points)[:, 0:1]
+                # only the SDF column is needed here (the mask term of the loss): the tracer's split-precision tile
+                # evaluator computes it ~4x faster than the fp32 forward that also produces the feature columns
+                pm = self.implicit_network.packed(f16x3=True) if self.ray_tracer.precision.startswith('f16x3') else None
+                if pm is not None and pm.f16x3:
+                    sdf_output = ops.sdf_eval(pm, ops._f32(points)).unsqueeze(1)
+                else:
+                    sdf_output = self.implicit_network(points)[:, 0:1]
         ctx['sdf_output'], ctx['pre'] = sdf_output, pre
         return ctx
 
