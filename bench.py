@@ -45,6 +45,8 @@ def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
     w = dict(syn.WORKLOADS[workload])
     mc = syn.model_conf(w['model'])
     lc = syn.loss_conf(w['model'])
+    if w['num_rays'] > 0:       # several rays per pixel (and MC shading behind each): keep the sample at ~10-30 s of CPU work
+        sample_pixels = max(16, sample_pixels * 4 // w['num_rays'])
     inp, gt = syn.make_inputs(sample_pixels, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
     n_rays = inp['uv'].shape[1] * (w['num_rays'] if w['num_rays'] > 0 else 1)
     ncpu = os.cpu_count() or 1
@@ -82,9 +84,9 @@ def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
     value1, _ = run(1, 1, 0)
     res = {'value': value, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
            'value_1_thread': value1,
-           'sample': '%d of the workload\'s pixels, best of %d steps after %d warm-up, %d torch threads (measured '
+           'sample': '%d of the workload\'s pixels (%d primary rays), best of %d steps after %d warm-up, %d torch threads (measured '
                      'optimum on the host; value_1_thread = the reference\'s own setting, idr_train.py:26)'
-                     % (sample_pixels, steps, warmup, threads)}
+                     % (sample_pixels, n_rays, steps, warmup, threads)}
     parity = None
     if device is not None:
         from nefii_amd import conf
