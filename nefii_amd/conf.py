@@ -49,10 +49,24 @@ class ConfigTree(dict):
 _TOKEN = re.compile(r'''\s*(?:(?P<brace>[{}\[\],=:])|"(?P<dq>[^"]*)"|'(?P<sq>[^']*)'|(?P<bare>[^\s{}\[\],=:#"']+))''')
 
 
+def _strip_comment(line):
+    """cut the line at the first '#' or '//' that is not inside a quoted string"""
+    quote = None
+    for i, ch in enumerate(line):
+        if quote:
+            if ch == quote:
+                quote = None
+        elif ch in '"\'':
+            quote = ch
+        elif ch == '#' or line.startswith('//', i):
+            return line[:i]
+    return line
+
+
 def _tokens(text):
     out = []
     for line in text.splitlines():
-        line = re.split(r'#|//', line, maxsplit=1)[0]
+        line = _strip_comment(line)
         pos = 0
         while pos < len(line):
             m = _TOKEN.match(line, pos)

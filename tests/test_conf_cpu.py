@@ -1,0 +1,87 @@
+"""The HOCON-subset reader (nefii_amd/conf.py) that stands in for pyhocon: the constructs the reference's conf files use,
+and - in the build container, where the files exist - the four files of code/confs_sg themselves."""
+import os
+
+import pytest
+
+from nefii_amd import conf
+
+REF_CONFS = '/root/reference/code/confs_sg'
+
+TEXT = '''
+# comment line
+train{
+    expname = default          # trailing comment
+    dataset_class = datasets.scene_dataset.SceneDataset
+    num_pixels = 2048
+    idr_learning_rate = 5e-4
+    alpha_milestones = [250000,500000, 750000]   // another comment style
+    alpha_factor = 2
+    empty = []
+}
+loss { r_patch = 1.0
+       loss_type = L1 }
+model = {
+    render_background = True
+    fast_multi_ray = False
+    implicit_network
+    {
+        dims = [ 512, 512,
+                 512 ]
+        bias = 0.6
+        use_last_as_f=True
+        name = "quoted string # not a comment"
+    }
+    nested { deeper { value = -3 } }
+}
+'''
+
+
+def test_parser_constructs():
+    c = conf.parse_string(TEXT)
+    assert isinstance(c, conf.ConfigTree)
+    assert c.get_string('train.expname') == 'default'
+    assert c.get_string('train.dataset_class') == 'datasets.scene_dataset.SceneDataset'
+    assert c.get_int('train.num_pixels') == 2048 and isinstance(c.get_int('train.num_pixels'), int)
+    assert c.get_float('train.idr_learning_rate') == 5e-4
+    assert c.get_list('train.alpha_milestones') == [250000, 500000, 750000]
+    assert c.get_list('train.empty') == [] and c.get_int('train.alpha_factor') == 2
+    assert c.get_float('loss.r_patch') == 1.0 and c.get_string('loss.loss_type') == 'L1'
+    assert c.get_bool('model.render_background') is True and c.get_bool('model.fast_multi_ray') is False
+    net = c.get_config('model.implicit_network')
+    assert net.get_list('dims') == [512, 512, 512] and net.get_bool('use_last_as_f') is True
+    assert net.get_float('bias') == 0.6 and net.get_string('name') == 'quoted string # not a comment'
+    assert c.get_int('model.nested.deeper.value') == -3
+    assert dict(**c.get_config('loss')) == {'r_patch': 1.0, 'loss_type': 'L1'}          # the **kwargs use
+    # defaults and missing keys follow pyhocon: default returned when given, KeyError otherwise
+    assert c.get_int('train.num_rays', default=-1) == -1 and c.get_list('train.nope', default=[]) == []
+    assert c.get_float('train.idr_sched_factor', default=0.0) == 0.0
+    with pytest.raises(KeyError):
+        c.get_int('train.nope')
+    d = conf.from_dict({'a': {'b': 1}, 'c': [1, 2]})
+    assert d.get_int('a.b') == 1 and d.get_config('a').get_int('b') == 1 and d.get_list('c') == [1, 2]
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFS), reason='reference conf files exist in the build container only')
+def test_reference_conf_files_parse():
+    want = {
+        'conf.conf': {'train.num_pixels': 2048, 'train.num_rays': 64, 'model.render_type': 'pt_render_indirect_mlp',
+                      'model.feature_vector_size': 512, 'model.implicit_network.multires': 6,
+                      'model.envmap_material_network.num_lgt_sgs': 128, 'loss.mask_weight': 100.0},
+        'physg.conf': {'model.implicit_network.skip_in': [4]},
+        'conf_neus.conf': {'model.implicit_network.dims': [256] * 8},
+        'sdf.conf': {'train.model_class': 'model.implicit_differentiable_renderer.IDRNetwork'},
+    }
+    for name, checks in want.items():
+        c = conf.parse_file(os.path.join(REF_CONFS, name))
+        for sect in ('train', 'loss', 'model'):
+            assert isinstance(c.get_config(sect), conf.ConfigTree), (name, sect)
+        for key, val in checks.items():
+            got = c.get(key)
+            assert got == val, (name, key, got)
+        m = c.get_config('model')
+        assert m.get_config('implicit_network').get_bool('weight_norm') is True
+        assert len(m.get_config('rendering_network').get_list('dims')) >= 1
+        from nefii_amd.utils import general
+        assert general.get_class(c.get_string('train.model_class')).__name__ == 'IDRNetwork'
+        assert general.get_class(c.get_string('train.dataset_class')).__name__ == 'SceneDataset'
