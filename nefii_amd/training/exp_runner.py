@@ -38,6 +38,7 @@ def main(argv=None):
     p.add_argument('--pretrain_idr_rendering_path', type=str, default='')
     p.add_argument('--pretrain_diffuse_path', type=str, default='')
     p.add_argument('--light_sg', type=str, default='')
+    p.add_argument('--geometry', type=str, default='')
     p.add_argument('--geometry_neus', type=str, default='')
     p.add_argument('--local_rank', type=int, default=-1)
     p.add_argument('--model_class', type=str, default='nefii_amd.model.implicit_differentiable_renderer.IDRNetwork')
@@ -60,7 +61,7 @@ def main(argv=None):
         freeze_diffuse=opt.freeze_diffuse, wo_mask=opt.wo_mask, roughness_warmup=opt.roughness_warmup,
         specular_warmup=opt.specular_warmup, secondary_train_interval=opt.secondary_train_interval,
         pretrain_geometry_path=opt.pretrain_geometry_path, pretrain_idr_rendering_path=opt.pretrain_idr_rendering_path,
-        pretrain_diffuse_path=opt.pretrain_diffuse_path, light_sg_path=opt.light_sg, geometry_neus=opt.geometry_neus,
+        pretrain_diffuse_path=opt.pretrain_diffuse_path, light_sg_path=opt.light_sg, geometry=opt.geometry, geometry_neus=opt.geometry_neus,
         local_rank=local_rank, model_class=opt.model_class, dataset_class=opt.dataset_class or None,
         graph=not opt.no_graph, plots=opt.plots)
     runner.run()

@@ -110,6 +110,11 @@ class IDRTrainRunner:
                 self.model.load_state_dict(full)
         if kwargs.get('light_sg_path') and os.path.exists(kwargs['light_sg_path']):
             self.model.envmap_material_network.load_light(kwargs['light_sg_path'])
+        if str(kwargs.get('geometry', '')).endswith('.pth'):                        # idr_train.py:294-301
+            sd = torch.load(kwargs['geometry'], map_location=self.device)['model_state_dict']
+            full = self.model.state_dict()
+            full.update({k: v for k, v in sd.items() if 'implicit_network' in k})
+            self.model.load_state_dict(full)
         if str(kwargs.get('geometry_neus', '')).endswith('.pth'):                   # idr_train.py:303-306
             self.model.implicit_network.load_state_dict(
                 torch.load(kwargs['geometry_neus'], map_location=self.device)['sdf_network_fine'])

@@ -823,3 +823,48 @@ def test_step2_training_recovers_a_rendered_target(name, hidden, num_rays, iters
             assert not v.dtype.is_floating_point or torch.isfinite(v).all(), k
     if not mc_shading:
         assert abs(final[True] - final[False]) < 0.15 * final[False], final
+
+
+@pytest.mark.gpu
+def test_runner_partial_checkpoint_loads(tmp_path):
+    """The runner's partial loads (idr_train.py:205-249,294-306): --pretrain_geometry_path / --pretrain_idr_rendering_path
+    / --pretrain_diffuse_path take their sub-network from a full checkpoint, --geometry every key containing
+    'implicit_network', --geometry_neus a NeuS checkpoint's `sdf_network_fine` straight into the SDF net, --light_sg_path
+    an .npy of light lobes (7 columns: coloured light)."""
+    from nefii_amd.training.idr_train import IDRTrainRunner
+    cfg = _runner_conf(tmp_path)
+    mc = cfg.get_config('model')
+    donor = {k: syn.make_state_dict(mc, seed=s, bumpy=0.01) for k, s in (('geo', 21), ('idr', 22), ('dif', 23), ('neus', 24))}
+    for k in ('geo', 'idr', 'dif'):
+        torch.save({'epoch': 3, 'model_state_dict': donor[k]}, str(tmp_path / (k + '.pth')))
+    torch.save({'sdf_network_fine': {k[len('implicit_network.'):]: v for k, v in donor['neus'].items()
+                                     if k.startswith('implicit_network.')}}, str(tmp_path / 'neus.pth'))
+    lgt = np.random.Generator(np.random.Philox(3)).normal(size=(32, 7)).astype(np.float32)
+    np.save(str(tmp_path / 'light.npy'), lgt)
+    kw = dict(conf=cfg, exps_folder_name=str(tmp_path), freeze_geometry=True, nepochs=1, graph=False,
+              dataset_kwargs={'n_views': 2, 'img_res': (16, 16)})
+
+    def same(model_sd, src, prefix):
+        keys = [k for k in src if k.startswith(prefix)]
+        assert keys
+        return all(torch.equal(model_sd[k].cpu(), src[k]) for k in keys)
+
+    torch.manual_seed(0)
+    base = IDRTrainRunner(expname='a', new_timestamp='t', **kw).model.state_dict()
+    r = IDRTrainRunner(expname='b', new_timestamp='t', pretrain_geometry_path=str(tmp_path / 'geo.pth'),
+                       pretrain_idr_rendering_path=str(tmp_path / 'idr.pth'), pretrain_diffuse_path=str(tmp_path / 'dif.pth'),
+                       light_sg_path=str(tmp_path / 'light.npy'), **kw)
+    sd = r.model.state_dict()
+    assert same(sd, donor['geo'], 'implicit_network.') and same(sd, donor['idr'], 'rendering_network.')
+    assert same(sd, donor['dif'], 'envmap_material_network.diffuse_albedo_layers.')
+    assert not same(sd, donor['geo'], 'rendering_network.') and not same(sd, donor['idr'], 'implicit_network.')
+    mat = r.model.envmap_material_network
+    assert np.array_equal(mat.lgtSGs.detach().cpu().numpy(), lgt) and mat.numLgtSGs == 32 and mat.white_light is False
+    assert set(sd) == set(base)
+    r2 = IDRTrainRunner(expname='c', new_timestamp='t', geometry=str(tmp_path / 'idr.pth'),
+                        geometry_neus=str(tmp_path / 'neus.pth'), **kw)
+    sd2 = r2.model.state_dict()
+    assert same(sd2, donor['neus'], 'implicit_network.')            # applied after --geometry, as in the reference
+    r3 = IDRTrainRunner(expname='d', new_timestamp='t', geometry=str(tmp_path / 'idr.pth'), **kw)
+    assert same(r3.model.state_dict(), donor['idr'], 'implicit_network.')
+    assert not same(r3.model.state_dict(), donor['idr'], 'rendering_network.')
