@@ -947,6 +947,61 @@ __device__ __forceinline__ void qgemm(int units, P16<8>::Stage (&b)[4], QAct<QT>
     }
 }
 
+// ---- deep-prefetch variant for the 32-query instance (FT = 4, QT = 2) ---------------------------------------------------
+// A 32-query tile has half the matrix work of a 64-query one but pulls the same 7.6 MB of fragments through its CU: with
+// 3 units (12 KB per wave) in flight it is bound by the latency of that stream (~73 GB/s per CU however many CUs run),
+// ~105 us against ~55 us of MFMA time.  The small instance has the registers for 8 stages (7 units = 28 KB per wave in
+// flight); its stream is a second copy with every layer's K zero-padded to a multiple of 128 (unit counts = multiples
+// of the 8 stages, one loop body).
+template <int QT, int J, int HALF, int ABUF, bool LOADA>
+__device__ __forceinline__ void qstep8(P16<8>::Stage (&b)[8], QAct<QT> (&a)[2], PCursor &cur, const _Float16 *ah,
+                                       const _Float16 *al, int s32, f32x4 (&acc)[4 * QT]) {
+    pload<8>(b[(J + 7) % 8], cur);
+    if (LOADA) qload_a<QT, QGeo<4>::XP>(a[ABUF ^ 1], ah, al, s32 + 1);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 &c = acc[(2 * HALF + f) * QT + qt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 * f], a[ABUF].h[qt], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 * f + 1], a[ABUF].h[qt], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 * f], a[ABUF].l[qt], c, 0, 0, 0);
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    if (LOADA) {
+#pragma unroll
+        for (int i = 0; i < 2 * QT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// k-loop of one layer: `units` half steps, a multiple of 8, stage 0 first
+template <int QT>
+__device__ __forceinline__ void qgemm8(int units, P16<8>::Stage (&b)[8], QAct<QT> (&a)[2], PCursor &cur,
+                                       const _Float16 *ah, const _Float16 *al, f32x4 (&acc)[4 * QT]) {
+    for (int hs = 0; hs < units; hs += 8) {
+        const int s32 = hs >> 1;
+        qstep8<QT, 0, 0, 0, true>(b, a, cur, ah, al, s32, acc);
+        qstep8<QT, 1, 1, 0, false>(b, a, cur, ah, al, s32, acc);
+        qstep8<QT, 2, 0, 1, true>(b, a, cur, ah, al, s32 + 1, acc);
+        qstep8<QT, 3, 1, 1, false>(b, a, cur, ah, al, s32 + 1, acc);
+        qstep8<QT, 4, 0, 0, true>(b, a, cur, ah, al, s32 + 2, acc);
+        qstep8<QT, 5, 1, 0, false>(b, a, cur, ah, al, s32 + 2, acc);
+        qstep8<QT, 6, 0, 1, true>(b, a, cur, ah, al, s32 + 3, acc);
+        qstep8<QT, 7, 1, 1, false>(b, a, cur, ah, al, s32 + 3, acc);
+    }
+}
+
+// half steps of a layer in the padded stream
+__host__ __device__ __forceinline__ int q_units8(const nefii_layer &L) { return ((L.k_x + L.k_e + 127) & ~127) >> 4; }
+
 template <int QT, int FT, bool FAST>
 __device__ __forceinline__ void qepilogue(const f32x4 (&acc)[FT * QT], float bvec, float k16, int lane, int act,
                                           half4 (&phi)[FT * QT], half4 (&plo)[FT * QT]) {
@@ -985,22 +1040,25 @@ __device__ __forceinline__ void encode_tile16q(const nefii_mlp &m, const float *
 }
 
 // stages 0..2 <- units 0..2 of the stream (start of a workgroup)
-template <int FT>
-__device__ __forceinline__ void prime16q(const nefii_mlp &m, P16<8>::Stage (&b)[4], PCursor &cur) {
+template <int FT, int NB = 4>
+__device__ __forceinline__ void prime16q(const nefii_mlp &m, P16<8>::Stage (&b)[NB], PCursor &cur) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    int G = 0;
-    for (int l = 0; l < m.n_layers - 1; ++l) G += q_units<FT>(m.layer[l]);
+    int G = 0, G8 = 0;
+    for (int l = 0; l < m.n_layers - 1; ++l) G += q_units<FT>(m.layer[l]), G8 += q_units8(m.layer[l]);
+    const half8 *base = reinterpret_cast<const half8 *>(m.w_stream);
+    if (NB == 8) base += (size_t)8 * G * 256, G = G8;       // the padded copy follows the plain stream
     cur.bytes = (unsigned)G * 4096;
-    cur.base = reinterpret_cast<const half8 *>(m.w_stream) + (size_t)wave * G * 256 + lane;
+    cur.base = base + (size_t)wave * G * 256 + lane;
     cur.off = 0;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) pload<8>(b[u], cur);
+    for (int u = 0; u < NB - 1; ++u) pload<8>(b[u], cur);
 }
 
 // One tile of 16 * QT queries through the whole SDF network (FT = 4: QT = 4 / 2 for 64 / 32 queries; FT = 2: QT = 6 / 2).
-template <int QT, int FT>
+template <int QT, int FT, int NB = 4>
 __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, float *raw, float *const *dest,
-                                            P16<8>::Stage (&b)[4], PCursor &cur) {
+                                            P16<8>::Stage (&b)[NB], PCursor &cur) {
+    static_assert(NB == 4 || FT == 4, "the deep-prefetch variant is the 512-wide shape's");
     constexpr int NW = 8, RT = QT / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, RMAX = QGeo<FT>::ROWS;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int NH = m.n_layers - 1;
@@ -1011,7 +1069,7 @@ __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, f
     const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4), *ql0 = lds.Xl + (lane & 15) * XP + 8 * (lane >> 4);
     for (int l = 0; l < NH; ++l) {
         const nefii_layer &L = m.layer[l];
-        const int units = q_units<FT>(L);
+        const int units = NB == 8 ? q_units8(L) : q_units<FT>(L);
         const _Float16 *ah = qh0 + (EP - L.k_x), *al = ql0 + (EP - L.k_x);
         const float *bp = L.bias + 16 * FT * wave + (lane & (16 * FT - 1));
         asm volatile("" ::"s"(units), "v"(ah), "v"(al), "v"(bp));
@@ -1025,7 +1083,10 @@ __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, f
             for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
         QAct<QT> a[2];
         qload_a<QT, XP>(a[0], ah, al, 0);
-        qgemm<QT, FT>(units, b, a, cur, ah, al, acc);
+        if constexpr (NB == 8)
+            qgemm8<QT>(units, b, a, cur, ah, al, acc);
+        else
+            qgemm<QT, FT>(units, b, a, cur, ah, al, acc);
         half4 phi[FT * QT], plo[FT * QT];
         if (m.act == NEFII_ACT_SOFTPLUS100)
             qepilogue<QT, FT, true>(acc, bvec, k16, lane, m.act, phi, plo);

@@ -618,9 +618,18 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Param
     }
 }
 
+// the padded stream of the deep-prefetch instance multiplies whatever follows a layer's own K columns in the activation
+// image (the row's pad columns, the next row, `tail`) by zero weights: all of it must be finite from the first tile on
+template <int FT>
+__device__ __forceinline__ void zero_lds(LdsQ<FT> &lds) {
+    uint32_t *p = reinterpret_cast<uint32_t *>(&lds);
+    for (int i = threadIdx.x; i < (int)(sizeof(LdsQ<FT>) / 4); i += blockDim.x) p[i] = 0u;
+    __syncthreads();
+}
+
 // the same on v_mfma_f32_16x16x32_f16 (mlp_tile.h "16q"; nefii_mlp.reserved == 1).  FT = 4: 512-wide hidden layers,
 // 64- / 32-query tiles; FT = 2: 256-wide hidden layers (conf_neus.conf), 96- / 32-query tiles.
-template <int QT, int FT>
+template <int QT, int FT, bool DEEP = false>
 __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, int round) {
     constexpr int RMAX = QGeo<FT>::ROWS;
     __shared__ LdsQ<FT> lds;
@@ -649,13 +658,20 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
         }
     }
     if (blockIdx.x >= n_tiles) return;
-    P16<8>::Stage b[4];
+    // DEEP: 8 fragment stages instead of 4 for the 32-query instance of the 512-wide shape.  It pays when few CUs stream
+    // (batches of <= 1024 rays: <= 64 tiles per round, each bound by the latency of its own 7.6 MB stream - config 1:
+    // 2.49 -> 2.17 ms per step); with every CU streaming the tiles are bound by L2 bandwidth instead and the deeper
+    // pipeline only adds its priming (config 2's small rounds: 104 -> 110 us), so the host picks it by batch size.
+    constexpr int NB = DEEP ? 8 : 4;
+    static_assert(!DEEP || (QT == 2 && FT == 4), "deep prefetch: the 32-query instance of the 512-wide shape");
+    if (NB == 8) zero_lds(lds);
+    P16<8>::Stage b[NB];
     PCursor cur;
-    prime16q<FT>(m, b, cur);
+    prime16q<FT, NB>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         decode_tile<ROWS>(P, first + tile, total, n_single, n_sd, raw, dest);
         __syncthreads();
-        sdf_tile16q<QT, FT>(m, lds, raw, dest, b, cur);
+        sdf_tile16q<QT, FT, NB>(m, lds, raw, dest, b, cur);
     }
 }
 
@@ -756,6 +772,13 @@ int stream_steps(const nefii_mlp *m) {
     for (int l = 0; l < m->n_layers - 1; ++l) G += layer_units(m->layer[l], ft);
     return G;
 }
+// units of the second, K-padded copy the deep-prefetch 32-query instance reads (512-wide nets, 16x16x32 layout)
+int stream_steps8(const nefii_mlp *m) {
+    if (shape16p(m) != 4 || m->reserved != 1) return 0;
+    int G = 0;
+    for (int l = 0; l < m->n_layers - 1; ++l) G += q_units8(m->layer[l]);
+    return G;
+}
 
 // layout 0 (32x32x16 fragments): dst[(wave*G + g)*256 + i] <- the 4 KiB fragment block of (k-step g of the layer
 // sequence, column tiles 2 wave, 2 wave + 1), a straight copy.
@@ -764,10 +787,11 @@ int stream_steps(const nefii_mlp *m) {
 // + f) + (lane&15)][k = 32 s32 + 8 (lane>>4) + j], gathered from the layer's 32x32x16 fragments (one source half8 per
 // destination half8).  256-wide: unit g is a whole 32-deep k-step of the layer's K padded to a multiple of 128,
 // n = 32 wave + 16 f + (lane&15); k-steps past the layer's own K hold zeros.
-__global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int G, int ft) {
+__global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int G, int ft, int padded) {
     const int g = blockIdx.x, wave = blockIdx.y;
     int l = 0, s = g;
-    while (s >= layer_units_dev(m.layer[l], ft)) s -= layer_units_dev(m.layer[l], ft), ++l;
+    while (s >= (padded ? q_units8(m.layer[l]) : layer_units_dev(m.layer[l], ft)))
+        s -= padded ? q_units8(m.layer[l]) : layer_units_dev(m.layer[l], ft), ++l;
     const half8 *w = reinterpret_cast<const half8 *>(m.layer[l].w_f16x3);
     if (m.reserved != 1) {
         const half8 *src = w + ((size_t)s * 16 + 2 * wave) * 2 * 64;
@@ -788,7 +812,10 @@ __global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int
     const int half = s & 1, s32 = s >> 1;
     const int n = 64 * wave + 16 * (2 * half + f) + (lane & 15);
     const int s16 = 2 * s32 + (kg >> 1), t = n >> 5, lane_src = (n & 31) + 32 * (kg & 1);
-    dst[((size_t)wave * G + g) * 256 + threadIdx.x] = w[(((size_t)s16 * 16 + t) * 2 + part) * 64 + lane_src];
+    half8 v;
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;          // k-steps past the layer's own K (padded copy): zeros
+    if (s16 < ((m.layer[l].k_x + m.layer[l].k_e) >> 4)) v = w[(((size_t)s16 * 16 + t) * 2 + part) * 64 + lane_src];
+    dst[((size_t)wave * G + g) * 256 + threadIdx.x] = v;
 }
 
 // the same tile evaluator over an explicit point list (nefii_sdf_eval)
@@ -905,7 +932,7 @@ extern "C" int nefii_trace_profile_launches(float *h_ms, int cap) {
 
 extern "C" size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf) {
     if (!h_sdf || h_sdf->n_layers < 2 || h_sdf->n_layers > NEFII_MAX_LAYERS || !shape16p(h_sdf)) return 0;
-    return (size_t)8 * stream_steps(h_sdf) * 256 * sizeof(half8);
+    return (size_t)8 * (stream_steps(h_sdf) + stream_steps8(h_sdf)) * 256 * sizeof(half8);
 }
 
 extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, void *stream) {
@@ -915,8 +942,14 @@ extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, voi
         if (!h_sdf->layer[l].w_f16x3) return NEFII_E_ARG;
     const int G = stream_steps(h_sdf);
     hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, (half8 *)w_stream, G,
-                       shape16p(h_sdf));
+                       shape16p(h_sdf), 0);
     HIP_CHECK_LAUNCH();
+    const int G8 = stream_steps8(h_sdf);
+    if (G8 > 0) {
+        hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G8, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf,
+                           (half8 *)w_stream + (size_t)8 * G * 256, G8, 4, 1);
+        HIP_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -1061,8 +1094,12 @@ int launch_round(const TraceJob &J, int r, bool profile) {
             hipLaunchKernelGGL((eval_kernel16q<4, 4>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();
             const int64_t small_tiles = (J.P.n * 2 + 31) / 32 < 256 ? (J.P.n * 2 + 31) / 32 : 256;
-            hipLaunchKernelGGL((eval_kernel16q<2, 4>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(512), 0, st, J.P,
-                               *J.sdf, r);
+            if (J.P.n <= 1024)
+                hipLaunchKernelGGL((eval_kernel16q<2, 4, true>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(512), 0,
+                                   st, J.P, *J.sdf, r);
+            else
+                hipLaunchKernelGGL((eval_kernel16q<2, 4>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(512), 0, st,
+                                   J.P, *J.sdf, r);
         } else if (J.precision == 2 && J.pipelined) {
             hipLaunchKernelGGL((eval_kernel16p<P16W, 2>), dim3(J.eval_blocks_w), dim3(64 * P16W), 0, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();

@@ -259,10 +259,11 @@ def test_tracer_golden(golden, tag, name, hidden, bumpy):
 
 
 @pytest.mark.parametrize('precision', ['f32', 'f16x3', 'f16x3w'])
-@pytest.mark.parametrize('hidden,bumpy,n', [(64, 0.03, 5000), (64, 0.0, 3000), (512, 0.004, 1500)])
+@pytest.mark.parametrize('hidden,bumpy,n', [(64, 0.03, 5000), (64, 0.0, 3000), (512, 0.004, 1500), (512, 0.004, 700)])
 def test_tracer_vs_oracle_and_counts(hidden, bumpy, n, precision):
     """Larger seeded batches incl. rays that miss the bounding sphere, ragged tile counts, masked-out rays;
-    the kernel's per-round query counters must equal the oracle's SDF evaluation counts."""
+    the kernel's per-round query counters must equal the oracle's SDF evaluation counts.  n = 700 at width 512: batches of
+    up to 1024 rays run their 32-query tiles on the deep-prefetch instance (8 fragment stages, K-padded stream copy)."""
     mc = syn.model_conf('physg', hidden=hidden)
     sd = syn.make_state_dict(mc, seed=2, bumpy=bumpy)
     sdf = lambda x: nets.sdf_forward(sd, mc['implicit_network'], x)[:, 0]

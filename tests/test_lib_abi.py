@@ -70,7 +70,9 @@ def test_sdf_stream_size():
     lib = _lib.lib()
     # 512-wide: 16-deep k-steps (either layout); 256-wide: 32-deep k-steps of K padded to 128, 16x16x32 layout only
     for name, hidden, layout, want in [('physg', 512, 0, 8 * (4 + 32 * 3 + 36 + 32 * 3) * 4096),
-                                       ('physg', 512, 1, 8 * (4 + 32 * 3 + 36 + 32 * 3) * 4096), ('physg', 64, 1, 0),
+                                       # 16x16x32 layout: + the K-padded copy of the deep-prefetch 32-query instance
+                                       ('physg', 512, 1, 8 * ((4 + 32 * 3 + 36 + 32 * 3) + (8 + 32 * 3 + 40 + 32 * 3)) * 4096),
+                                       ('physg', 64, 1, 0),
                                        ('neus', None, 0, 0), ('neus', None, 1, 8 * (4 + 8 * 3 + 12 + 8 * 3) * 4096)]:
         mc = syn.model_conf(name, hidden=hidden)
         specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
