@@ -14,6 +14,8 @@ CSRC = os.path.join(HERE, 'csrc')
 SOURCES = ['nefii_mlp.hip', 'nefii_tracer.hip', 'nefii_shading.hip']
 HEADERS = ['mlp_tile.h', os.path.join('..', '..', 'include', 'nefii_amd.h')]
 OUT = os.path.join(CSRC, 'libnefii_hip.so')
+HOST_SRC = os.path.join(CSRC, 'exr_huf.c')          # host-only helper of utils/exr.py (PIZ Huffman loop)
+HOST_OUT = os.path.join(CSRC, 'libnefii_host.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 
 
@@ -25,7 +27,18 @@ def _stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_host(force=False, verbose=True):
+    if not force and os.path.exists(HOST_OUT) and os.path.getmtime(HOST_OUT) >= os.path.getmtime(HOST_SRC):
+        return HOST_OUT
+    cmd = [os.environ.get('CC', 'gcc'), '-O2', '-shared', '-fPIC', '-o', HOST_OUT, HOST_SRC]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return HOST_OUT
+
+
 def build(force=False, verbose=True):
+    build_host(force, verbose)
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

@@ -132,7 +132,9 @@ class _Bits:
             self.p += 1
             self.lc += 8
         self.lc -= n
-        return (self.c >> self.lc) & ((1 << n) - 1)
+        v = self.c >> self.lc
+        self.c &= (1 << self.lc) - 1          # keep the accumulator at a few bits (it would grow with the stream)
+        return v & ((1 << n) - 1)
 
 
 def _huf_unpack_table(data, pos, ni, im, iM):
@@ -172,7 +174,44 @@ def _huf_canonical_codes(lengths):
     return codes
 
 
+_HOST = [None, False]      # (ctypes library or None, looked for already)
+
+
+def _host_lib():
+    """nefii_amd/csrc/libnefii_host.so (nefii_amd.build.build_host; built on first use when a C compiler is there)"""
+    if not _HOST[1]:
+        _HOST[1] = True
+        try:
+            import ctypes
+            from .. import build as _build
+            lib = ctypes.CDLL(_build.build_host(verbose=False))
+            lib.nefii_exr_huf_decode.restype = ctypes.c_long
+            lib.nefii_exr_huf_decode.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_long, ctypes.c_long, ctypes.c_void_p, ctypes.c_long]
+            _HOST[0] = lib
+        except Exception:                                   # no compiler / read-only tree: the Python loop below
+            _HOST[0] = None
+    return _HOST[0]
+
+
 def _huf_decode(data, pos, n_bits, lengths, codes, rlc, n_out):
+    lib = _host_lib()
+    if lib is not None:
+        n_bytes = (n_bits + 7) // 8
+        if pos + n_bytes > len(data):
+            raise ExrError('PIZ: Huffman bit stream runs past its block')
+        buf = np.frombuffer(data, dtype=np.uint8, count=n_bytes, offset=pos).copy()
+        ln, cd = np.ascontiguousarray(lengths, dtype=np.int64), np.ascontiguousarray(codes, dtype=np.int64)
+        out = np.empty(n_out, dtype=np.uint16)
+        got = lib.nefii_exr_huf_decode(buf.ctypes.data, n_bytes, n_bits, ln.ctypes.data, cd.ctypes.data, ln.shape[0], rlc,
+                                       out.ctypes.data, n_out)
+        if got != n_out:
+            raise ExrError('PIZ: Huffman stream ends after %d of %d symbols' % (max(got, 0), n_out))
+        return out
+    return _huf_decode_py(data, pos, n_bits, lengths, codes, rlc, n_out)
+
+
+def _huf_decode_py(data, pos, n_bits, lengths, codes, rlc, n_out):
     """bit stream (MSB first) -> n_out uint16 symbols; symbol `rlc` followed by an 8-bit count repeats the previous
     symbol (ImfHuf.cpp hufDecode / getCode).  Codes up to HUF_DECBITS bits resolve through a prefix table, longer ones
     by search."""
