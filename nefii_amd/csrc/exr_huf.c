@@ -35,6 +35,9 @@ long nefii_exr_huf_decode(const uint8_t *data, size_t n_bytes, long n_bits, cons
     for (long s = 0; s < n_sym; ++s) {
         const int l = (int)lengths[s];
         if (l <= 0 || l >= 64) continue;
+        /* an over-subscribed length table yields codes that do not fit their length (ImfHuf.cpp hufBuildDecTable rejects
+         * it with `if (c >> l)`): such a code would index past the decoding tables */
+        if (codes[s] < 0 || (codes[s] >> l) != 0 || codes[s] - first[l] >= count[l]) { free(by_len); return -1; }
         by_len[start[l] + (long)(codes[s] - first[l])] = (int32_t)s;
         if (l <= DEC) {
             const long base = (long)(codes[s] << (DEC - l)), span = 1L << (DEC - l);

@@ -110,6 +110,16 @@ class IDRTrainRunner:
                 self.model.load_state_dict(full)
         if kwargs.get('light_sg_path') and os.path.exists(kwargs['light_sg_path']):
             self.model.envmap_material_network.load_light(kwargs['light_sg_path'])
+        self.start_epoch = 0
+        saved = {}
+        if is_continue:
+            old = os.path.join(str(kwargs.get('old_expdir') or '') or self.expdir, timestamp, 'checkpoints')
+            ck = str(kwargs.get('checkpoint', 'latest')) + '.pth'
+            saved = {k: torch.load(os.path.join(old, sub, ck), map_location=self.device) for k, sub in SUBDIRS.items()}
+            self.model.load_state_dict(saved['model']['model_state_dict'])
+            self.start_epoch = saved['model']['epoch']
+        # --geometry / --geometry_neus override whatever was loaded before them, the continued run's checkpoint
+        # included (idr_train.py:294-306 come after the is_continue block :251-292)
         if str(kwargs.get('geometry', '')).endswith('.pth'):                        # idr_train.py:294-301
             sd = torch.load(kwargs['geometry'], map_location=self.device)['model_state_dict']
             full = self.model.state_dict()
@@ -119,14 +129,6 @@ class IDRTrainRunner:
             self.model.implicit_network.load_state_dict(
                 torch.load(kwargs['geometry_neus'], map_location=self.device)['sdf_network_fine'])
 
-        self.start_epoch = 0
-        saved = {}
-        if is_continue:
-            old = os.path.join(str(kwargs.get('old_expdir') or '') or self.expdir, timestamp, 'checkpoints')
-            ck = str(kwargs.get('checkpoint', 'latest')) + '.pth'
-            saved = {k: torch.load(os.path.join(old, sub, ck), map_location=self.device) for k, sub in SUBDIRS.items()}
-            self.model.load_state_dict(saved['model']['model_state_dict'])
-            self.start_epoch = saved['model']['epoch']
 
         self.num_pixels = self.conf.get_int('train.num_pixels')
         self.num_rays = self.conf.get_int('train.num_rays', default=-1)
@@ -170,6 +172,11 @@ class IDRTrainRunner:
         if self.rank != 0:
             return
         st = self.step
+        # never overwrite latest.pth with poisoned weights (the reference checks the loss before backward / step, so its
+        # emergency checkpoint is usable, idr_train.py:754-757; TrainStep._update cancels such a step, this is the belt)
+        bad = [k for k, v in self.model.state_dict().items() if v.dtype.is_floating_point and not torch.isfinite(v).all()]
+        if bad:
+            raise FloatingPointError('refusing to checkpoint non-finite parameters: %s' % ', '.join(bad[:4]))
         payload = {'model': {'epoch': epoch, 'model_state_dict': self.model.state_dict()},
                    'idr_opt': {'epoch': epoch, 'optimizer_state_dict': st.portable_state_dict(st.idr_optimizer)},
                    'idr_sched': {'epoch': epoch, 'scheduler_state_dict': st.idr_scheduler.state_dict()},
@@ -253,9 +260,12 @@ class IDRTrainRunner:
                 _, lo = self.step(model_input, ground_truth, next_input if self.prefetch else None)
                 if it % self.log_freq == 0:
                     loss = lo['loss'].item()
-                    if not np.isfinite(loss):                                       # :752-755
+                    # :752-757.  The per-step check runs on the device (TrainStep._update: a step whose loss is not
+                    # finite on any rank has its gradients zeroed on every rank before Adam runs); its counter is
+                    # read here, at the logging points, and is the same number on every rank - they all stop together
+                    if self.step.nonfinite_steps.item() > 0 or not np.isfinite(loss):
                         self.save_checkpoints(epoch)
-                        raise FloatingPointError('nan/inf in loss at iteration %d' % it)
+                        raise FloatingPointError('nan/inf in loss at or before iteration %d' % it)
                     rec = {'iter': it, 'epoch': epoch, 'loss': loss, 'sg_rgb_loss': lo['sg_rgb_loss'].item(),
                            'sg_psnr': float(mse2psnr(lo['sg_rgb_loss'].item())),
                            'idr_lr': float(self.step.idr_optimizer.param_groups[0]['lr']),

@@ -13,28 +13,80 @@ import torch.distributed as dist
 from ..model.loss import IDRLoss
 
 
-def allreduce_mean_gradients(params, world_size, group=None):
-    """Average .grad of `params` across ranks with a single flat all-reduce (no-op for world_size 1)."""
-    if world_size <= 1:
-        return 0
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads:
-        return 0
-    flat = torch.cat([g.reshape(-1) for g in grads])
+def _all_reduce_sum(flat, group=None):
+    """SUM all-reduce of one flat tensor; GPU tensors on a gloo group (multi-process smoke tests on a box without RCCL
+    peers) are staged through the host."""
     if flat.is_cuda and dist.get_backend(group) == 'gloo':
-        # CPU-staged path for smoke-testing the multi-process logic on a box without RCCL peers
         host = flat.cpu()
         dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
         flat.copy_(host)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    flat.div_(world_size)
+    return flat
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Every rank takes rank `src`'s parameters and buffers (what DistributedDataParallel does when the reference wraps
+    the model, idr_train.py:308-309): ranks build their networks from their own unseeded RNG, and only gradients are
+    exchanged afterwards.  One flat broadcast per dtype."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return 0
+    tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.numel() > 0]
+    total = 0
+    for dtype in sorted({t.dtype for t in tensors}, key=str):
+        part = [t for t in tensors if t.dtype == dtype]
+        flat = torch.cat([t.detach().reshape(-1) for t in part])
+        if flat.is_cuda and dist.get_backend(group) == 'gloo':
+            host = flat.cpu()
+            dist.broadcast(host, src=src, group=group)
+            flat.copy_(host)
+        else:
+            dist.broadcast(flat, src=src, group=group)
+        off = 0
+        with torch.no_grad():
+            for t in part:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+        total += flat.numel() * flat.element_size()
+    return total
+
+
+def allreduce_mean_gradients(params, world_size, group=None, flags=None):
+    """Average .grad of `params` across ranks with ONE flat all-reduce (no-op for world_size 1).
+
+    The buffer has a FIXED layout: one slot per parameter of `params` whether or not it received a gradient on this
+    rank (zeros then), followed by the caller's `flags` (a 1-D float tensor, summed over the ranks and returned).
+    Every rank therefore sends the same number of bytes and always enters the collective - a rank whose pixel slice
+    contains no hit has no gradient at all for the radiance and material networks, and must neither skip the
+    all-reduce nor send a shorter buffer.  Semantics of DistributedDataParallel(find_unused_parameters=True) under
+    the reference's zero-filling optimizer.zero_grad() (idr_train.py:309,760-761): the mean is over ALL ranks, a rank
+    without a gradient contributes zeros, and afterwards every parameter holds a gradient tensor (Adam on an
+    all-zero gradient with zero moments is a no-op).  No host synchronisation.
+    Returns (bytes reduced, summed flags or None)."""
+    if world_size <= 1:
+        return 0, flags
+    params = list(params)
+    if not params:
+        return 0, flags
+    dev, dtype = params[0].device, params[0].dtype
+    parts = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dtype) for p in params]
+    if flags is not None:
+        parts.append(flags.reshape(-1).to(device=dev, dtype=dtype))
+    flat = torch.cat(parts)
+    _all_reduce_sum(flat, group)
+    n_par = sum(p.numel() for p in params)
+    flat[:n_par].div_(world_size)
     off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+    for p in params:
+        n = p.numel()
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
         off += n
-    return flat.numel() * flat.element_size()
+    out_flags = flat[n_par:].clone() if flags is not None else None
+    return flat.numel() * flat.element_size(), out_flags
 
 
 def _detached(d):
@@ -59,8 +111,7 @@ class _StepGraph:
             self.lo = step.loss(self.out, self.gt)
             self.lo['loss'].backward()
             if step.world_size <= 1:
-                step.idr_optimizer.step()
-                step.sg_optimizer.step()
+                step._update(self.lo['loss'])
         self.grads = [(p, p.grad) for p in step.trainable]      # the tensors every replay writes its gradients to
         # keep the static result tensors, not the autograd graph behind them: AccumulateGrad nodes that outlive their
         # iteration are re-used by the next backward on THEIR stream, which breaks the next capture
@@ -134,10 +185,35 @@ class TrainStep:
         self.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.sg_optimizer, list(sg_sched_milestones),
                                                                  gamma=sg_sched_factor)
         self.trainable = [p for p in model.parameters() if p.requires_grad]
+        # steps whose loss was not finite on some rank: their gradients were zeroed on every rank before Adam ran
+        # (device counter: the runner reads it at its logging points only)
+        self.nonfinite_steps = torch.zeros((), device=next(model.parameters()).device, dtype=torch.float32)
+        if world_size > 1:
+            # the reference's DDP wrap broadcasts rank 0's parameters and buffers at construction (idr_train.py:308-309);
+            # without it every rank would train the replica its own RNG initialised
+            broadcast_parameters(model)
+
+    def _update(self, loss):
+        """Gradient exchange + both Adam updates, with the reference's NaN check (idr_train.py:754-757: before
+        backward / step) as a device-side guard: when the loss is not finite on ANY rank, every rank zeroes its
+        gradients before Adam runs, so parameters and optimizer moments stay finite and the runner can still write a
+        usable emergency checkpoint.  The flag travels in the gradient all-reduce: one collective, no host sync."""
+        bad = (~torch.isfinite(loss.detach())).reshape(1).to(torch.float32)
+        if self.world_size > 1:
+            _, bad = allreduce_mean_gradients(self.trainable, self.world_size, flags=bad)
+        bad = bad.reshape(()) > 0
+        for p in self.trainable:
+            if p.grad is not None:
+                p.grad.masked_fill_(bad, 0.0)
+        self.nonfinite_steps += bad.to(self.nonfinite_steps.dtype)
+        self.idr_optimizer.step()
+        self.sg_optimizer.step()
 
     def retensor_lr(self):
-        """After optimizer.load_state_dict (which installs the checkpoint's python-float learning rates): graph mode keeps
-        them in device tensors that the captured Adam reads and the schedulers fill in place."""
+        """After optimizer.load_state_dict, which installs the CHECKPOINT's param_groups and state: a reference checkpoint
+        (or one saved by an eager run) carries python-float learning rates, capturable=False / fused=None and 'step'
+        counters on the CPU.  Graph mode needs them as device tensors that the captured Adam reads and the schedulers
+        fill in place, with capturable=True - otherwise the capture at iteration `graph_after` raises."""
         if not self.graph:
             return
         for opt in (self.idr_optimizer, self.sg_optimizer):
@@ -145,6 +221,12 @@ class TrainStep:
             for g in opt.param_groups:
                 if not torch.is_tensor(g['lr']):
                     g['lr'] = torch.tensor(float(g['lr']), device=dev)
+                g['capturable'] = True
+                g['fused'] = True
+                g['foreach'] = None
+            for st in opt.state.values():
+                if 'step' in st:
+                    st['step'] = torch.as_tensor(st['step'], dtype=torch.float32).to(dev)
         self._graphs.clear()          # captured graphs hold the old tensors
 
     @staticmethod
@@ -256,9 +338,7 @@ class TrainStep:
         for p, grad in g.grads:       # an eager step in between may have re-pointed .grad
             p.grad = grad
         if self.world_size > 1:
-            allreduce_mean_gradients(self.trainable, self.world_size)
-            self.idr_optimizer.step()
-            self.sg_optimizer.step()
+            self._update(g.lo['loss'])
         return g.out, g.lo
 
     def __call__(self, model_input, ground_truth, next_input=None):
@@ -299,10 +379,9 @@ class TrainStep:
         lo = self.loss(out, ground_truth)
         self.idr_optimizer.zero_grad()
         self.sg_optimizer.zero_grad()
-        lo['loss'].backward()
-        allreduce_mean_gradients(self.trainable, self.world_size)
-        self.idr_optimizer.step()
-        self.sg_optimizer.step()
+        if lo['loss'].requires_grad:        # a slice without a single hit (and no background term) has nothing to
+            lo['loss'].backward()           # differentiate; the reference wraps backward in try/except (:764-770)
+        self._update(lo['loss'])
         if self.secondary_train_interval > 0 and self.cur_iter % self.secondary_train_interval == 0:
             self.train_with_secondary(out)
         self._post_iteration()
@@ -317,18 +396,20 @@ class TrainStep:
             return None
         m = mask.reshape(-1)
         idx = torch.nonzero(m).flatten()[:self.secondary_batch_size]
-        if idx.numel() == 0:
+        if idx.numel() == 0 and self.world_size <= 1:
             return None
-        p = pts.detach().reshape(-1, 3).index_select(0, idx)
-        d = dirs.detach().reshape(-1, 3).index_select(0, idx)
-        n = p.shape[0]
-        ret = self.model({'points': p.unsqueeze(1).expand(n, self.num_rays, 3),
-                          'ray_dirs': d.unsqueeze(1).expand(n, self.num_rays, 3)}, with_point=True)
-        loss = torch.nn.functional.l1_loss(ret['sg_rgb_values'], ret['idr_rgb_values'])
         self.idr_optimizer.zero_grad()
         self.sg_optimizer.zero_grad()
-        loss.backward()
-        allreduce_mean_gradients(self.trainable, self.world_size)
-        self.idr_optimizer.step()
-        self.sg_optimizer.step()
+        loss = None
+        if idx.numel() > 0:
+            p = pts.detach().reshape(-1, 3).index_select(0, idx)
+            d = dirs.detach().reshape(-1, 3).index_select(0, idx)
+            n = p.shape[0]
+            ret = self.model({'points': p.unsqueeze(1).expand(n, self.num_rays, 3),
+                              'ray_dirs': d.unsqueeze(1).expand(n, self.num_rays, 3)}, with_point=True)
+            loss = torch.nn.functional.l1_loss(ret['sg_rgb_values'], ret['idr_rgb_values'])
+            loss.backward()
+        # several ranks: whether this rank has secondary hits is data, whether the collective runs must not be - a rank
+        # without any still enters the all-reduce (with zero gradients) and steps its optimizers like its peers
+        self._update(loss if loss is not None else torch.zeros((), device=pts.device))
         return loss

@@ -171,6 +171,11 @@ def _huf_canonical_codes(lengths):
         l = lengths[s]
         codes[s] = nxt[l]
         nxt[l] += 1
+    # Kraft inequality: an over-subscribed table hands out codes that do not fit their length (OpenEXR's
+    # hufBuildDecTable: "if (c >> l) invalidTableEntry") - refuse it here, whichever decoder loop runs afterwards
+    for l in range(1, 59):
+        if n[l] and (int(nxt[l]) - 1) >> l:
+            raise ExrError('PIZ: invalid Huffman table (code lengths over-subscribed)')
     return codes
 
 

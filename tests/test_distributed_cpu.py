@@ -56,7 +56,7 @@ def _worker(rank, world, port, tmp):
     out = model(inp)
     loss = (out['sg_rgb_values'] - gt.reshape(-1, 3)).abs().mean()
     loss.backward()
-    nbytes = allreduce_mean_gradients(list(model.parameters()), world)
+    nbytes, _ = allreduce_mean_gradients(list(model.parameters()), world)
     assert nbytes == sum(p.numel() for p in model.parameters()) * 4
     torch.save([p.grad.clone() for p in model.parameters()], os.path.join(tmp, 'grad%d.pt' % rank))
     # ---- rendering: chunk / round-robin / gather / merge
@@ -198,3 +198,128 @@ def test_chunking_helpers_match_the_reference():
                 want = g['%s_scatter_w%d_r%d' % (tag, world, rank)].tolist()
                 assert order[slices[rank][0]:slices[rank][1]] == want
                 assert utils.scatter_list(order, len(order), rank, world) == want
+
+
+# ---- TrainStep across ranks: fixed gradient layout, collective skip decisions, initial broadcast, NaN guard ---------
+class FakeIDR(torch.nn.Module):
+    """Stand-in with IDRNetwork's module surface and output keys (no HIP compute): hit pixels are shaded by two small
+    linear maps, pixels that miss keep the constant defaults - so a batch without a single hit carries no gradient."""
+
+    def __init__(self, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.implicit_network = torch.nn.Linear(3, 1)
+        self.rendering_network = torch.nn.Linear(2, 3)
+        self.envmap_material_network = torch.nn.Linear(2, 3)
+        self.unused = torch.nn.Parameter(torch.randn(5, generator=g))       # never receives a gradient on any rank
+        for p in self.parameters():
+            with torch.no_grad():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+        for p in self.implicit_network.parameters():
+            p.requires_grad = False
+        self.render_type = 'pt'
+        self.poison = False
+
+    def forward(self, inp, with_point=False):
+        if with_point:
+            x = inp['points'][:, 0, :2]
+            return {'idr_rgb_values': self.rendering_network(x), 'sg_rgb_values': self.envmap_material_network(x)}
+        uv = inp['uv'].reshape(-1, 2) * 0.05
+        hit = inp['hit'].reshape(-1)
+        n = uv.shape[0]
+        ones = torch.ones(n, 3)
+        idr = torch.where(hit[:, None], torch.sigmoid(self.rendering_network(uv)), ones)
+        sg = torch.where(hit[:, None], torch.sigmoid(self.envmap_material_network(uv)), ones)
+        if not hit.any():
+            idr, sg = ones.clone(), ones.clone()
+        if self.poison:
+            sg = sg * float('nan')
+        sec = inp.get('sec_mask')
+        return {'idr_rgb_values': idr, 'sg_rgb_values': sg, 'network_object_mask': hit,
+                'object_mask': inp['object_mask'].reshape(-1), 'sdf_output': torch.full((n, 1), 0.1),
+                'normal_values': ones, 'grad_theta': None,
+                'secondary_points': torch.cat([uv, uv[:, :1]], 1).reshape(1, n, 3) if sec is not None else None,
+                'secondary_mask': sec.reshape(1, n, 1) if sec is not None else None,
+                'secondary_dir': torch.ones(1, n, 3) if sec is not None else None}
+
+
+def _fake_batch(rank, hits, sec=None):
+    inp, gt = syn.make_inputs(32, (32, 32), 40.0, (0., 0., 3.), -1, seed=5 + rank)
+    n = inp['uv'].shape[1]
+    inp['hit'] = torch.full((n,), bool(hits))
+    if sec is not None:
+        inp['sec_mask'] = torch.full((n,), bool(sec))
+    return inp, {'rgb': gt}
+
+
+LOSS_CONF = dict(idr_rgb_weight=1.0, sg_rgb_weight=1.0, eikonal_weight=0.0, mask_weight=1.0, alpha=50.0)
+
+
+def _step_worker(rank, world, port, tmp):
+    from nefii_amd.training.step import TrainStep
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = FakeIDR(seed=10 + rank)                 # every rank starts from its own initialisation ...
+    st = TrainStep(model, LOSS_CONF, world_size=world, secondary_train_interval=2, secondary_batch_size=64, num_rays=2)
+    torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(tmp, 'init%d.pt' % rank))
+    # iteration 0: rank 1's slice has no hit at all (no gradient there) and no secondary hit (its secondary step has
+    # nothing to differentiate); iteration 1: everyone has hits; iteration 2: rank 1's loss is not finite
+    plan = [(rank == 0, rank == 0), (True, None), (True, True)]
+    for it, (hits, sec) in enumerate(plan):
+        model.poison = it == 2 and rank == 1
+        inp, gt = _fake_batch(rank, hits, sec)
+        st(inp, gt)
+        torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(tmp, 'it%d_r%d.pt' % (it, rank)))
+    torch.save(st.nonfinite_steps.clone(), os.path.join(tmp, 'bad%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_step_collectives_do_not_depend_on_the_data(tmp_path):
+    """A rank without hits (no gradients), a rank without secondary hits, and a rank whose loss is NaN all enter the same
+    collectives as their peers with same-sized buffers; parameters stay identical across ranks and finite; the initial
+    parameters are rank 0's (DDP's construction-time broadcast, idr_train.py:308-309)."""
+    from nefii_amd.training.step import TrainStep
+    world = 2
+    mp.spawn(_step_worker, args=(world, free_port(), str(tmp_path)), nprocs=world, join=True)
+    L = lambda name: torch.load(os.path.join(tmp_path, name))
+    ref0 = FakeIDR(seed=10).state_dict()
+    for r in range(world):
+        got = L('init%d.pt' % r)
+        for k in ref0:
+            assert torch.equal(got[k], ref0[k]), (r, k)
+    for it in range(3):
+        a, b = L('it%d_r0.pt' % it), L('it%d_r1.pt' % it)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (it, k)
+            assert torch.isfinite(a[k]).all(), (it, k)
+    assert L('bad0.pt').item() == 1 and L('bad1.pt').item() == 1
+    # iteration 0 against one process: primary gradient = (rank 0's gradient + 0) / 2, then the secondary step likewise
+    model = FakeIDR(seed=10)
+    st = TrainStep(model, LOSS_CONF, world_size=1, secondary_train_interval=0, num_rays=2)
+    inp, gt = _fake_batch(0, True, True)
+    out = model(inp)
+    lo = st.loss(out, gt)
+    lo['loss'].backward()
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.mul_(0.5)
+    st.idr_optimizer.step()
+    st.sg_optimizer.step()
+    st.world_size = 2           # halve the secondary gradient the same way: emulate by hand
+    idx = torch.nonzero(out['secondary_mask'].reshape(-1)).flatten()[:32]      # secondary_batch_size // world
+    p_ = out['secondary_points'].detach().reshape(-1, 3).index_select(0, idx)
+    ret = model({'points': p_.unsqueeze(1).expand(-1, 2, 3), 'ray_dirs': p_.unsqueeze(1).expand(-1, 2, 3)}, with_point=True)
+    st.idr_optimizer.zero_grad()
+    st.sg_optimizer.zero_grad()
+    torch.nn.functional.l1_loss(ret['sg_rgb_values'], ret['idr_rgb_values']).backward()
+    for p in model.parameters():
+        if p.grad is not None:
+            p.grad.mul_(0.5)
+    st.idr_optimizer.step()
+    st.sg_optimizer.step()
+    got = L('it0_r1.pt')
+    for k, v in model.state_dict().items():
+        assert torch.allclose(got[k], v, atol=1e-6), k
+    assert torch.equal(got['unused'], ref0['unused'])         # no gradient on any rank: untouched
