@@ -53,7 +53,7 @@ def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
 
     def run(threads, n_steps, n_warm):
         torch.set_num_threads(threads)
-        sd = syn.make_state_dict(mc, seed=0)
+        sd = syn.make_state_dict(mc, seed=0, scene=w.get('scene'))
         params = [v for k, v in sd.items() if not k.startswith('implicit')]
         for v in params:
             v.requires_grad_(True)
@@ -92,7 +92,7 @@ def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
         from nefii_amd import conf
         from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
         m = IDRNetwork(conf.from_dict(mc))
-        m.load_state_dict(syn.make_state_dict(mc, seed=0), strict=True)
+        m.load_state_dict(syn.make_state_dict(mc, seed=0, scene=w.get('scene')), strict=True)
         m = m.to(device)
         m.freeze_geometry()
         m.train()
@@ -155,7 +155,7 @@ def main():
 
     w = dict(syn.WORKLOADS[args.workload])
     mc = syn.model_conf(w['model'])
-    sd = syn.make_state_dict(mc, seed=0)
+    sd = syn.make_state_dict(mc, seed=0, scene=w.get('scene'))
     lc = syn.loss_conf(w['model'])
     torch.manual_seed(1234 + rank)
     model = IDRNetwork(conf.from_dict(mc))

@@ -102,8 +102,57 @@ def fibonacci_sphere(n):
     return np.stack([np.cos(th) * r, y, np.sin(th) * r], -1)
 
 
-def make_state_dict(model, seed=0, radius=None, bumpy=0.0):
+SCENES = {'bowl': 'scene_bowl_sdf64.npz'}
+
+
+def embed_scene_sdf(model, sd, scene, g):
+    """Overwrite the SDF network of state dict `sd` with the fitted 8 x 64 stand-in geometry `scene`
+    (tools/fit_scene_sdf.py: a ball resting in a tilted bowl - a NON-convex body, so that secondary rays re-hit the
+    surface and the indirect branch does work), embedded in the conf's own width by padding (SURVEY.md section 8d,
+    config 3): the small network's effective weights fill the leading rows / columns of every layer, the encoded input of
+    the skip layer keeps its place at the end of the concatenation, the remaining rows get weight_g = 0 with a tiny
+    non-zero weight_v (a zero row would make g*v/|v| NaN) and bias 0, the remaining columns are zero.  Same function,
+    full-size compute; the padded hidden units all output Softplus(0)."""
+    import os
+    small = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', SCENES[scene])))
+    ic = model['implicit_network']
+    F = int(model['feature_vector_size'])
+    shapes = sdf_layer_dims(ic, F)
+    d0 = shapes[0][1]
+    skip = tuple(ic.get('skip_in', ()))
+    nl = len(shapes)
+    assert nl == 9 and d0 == 39 and skip == (4,), 'the stand-in was fitted for the 8-layer PE6 skip-4 architecture'
+    for l, (o, i) in enumerate(shapes):
+        v, gg, b = (small['lin%d.%s' % (l, k)].astype(np.float64) for k in ('weight_v', 'weight_g', 'bias'))
+        ws = v * (gg / np.linalg.norm(v, axis=1, keepdims=True))          # effective small weight [o_s, i_s]
+        o_s, i_s = ws.shape
+        w = np.zeros((o, i))
+        if l in skip:
+            w[:o_s, :i_s - (d0)] = ws[:, :i_s - d0]
+            w[:o_s, i - d0:] = ws[:, i_s - d0:]
+        else:
+            w[:o_s, :i_s] = ws
+        bias = np.zeros((o,))
+        bias[:o_s] = b
+        if l == nl - 1 and o > 1:       # NeuS-style feature outputs (conf_neus.conf): random rows, zero bias
+            w[1:] = g.normal(0.0, math.sqrt(2) / math.sqrt(i), size=(o - 1, i))
+            o_s = o
+        if o_s < o:
+            w[o_s:] = g.normal(0.0, 1e-3, size=(o - o_s, i))
+        w32 = w.astype(np.float32)
+        wg = np.linalg.norm(w32, axis=1, keepdims=True)
+        wg[o_s:] = 0.0
+        sd['implicit_network.lin%d.weight_v' % l] = _t(w32)
+        sd['implicit_network.lin%d.weight_g' % l] = _t(wg)
+        sd['implicit_network.lin%d.bias' % l] = _t(bias)
+    return sd
+
+
+def make_state_dict(model, seed=0, radius=None, bumpy=0.0, scene=None):
     """Procedural weights with the reference's state-dict keys.
+
+    ``scene`` (e.g. 'bowl'): the SDF network is the fitted non-convex stand-in instead (embed_scene_sdf); the
+    radiance / material / light parameters are generated exactly as without it.
 
     ``bumpy`` > 0 puts N(0, bumpy) weights on the sin/cos columns of the first SDF layer: a
     bumpy, non-exact distance field that exercises the tracer's back-off line search,
@@ -170,6 +219,8 @@ def make_state_dict(model, seed=0, radius=None, bumpy=0.0):
         sd['envmap_material_network.specular_reflectance'] = _t(np.abs(g.normal(size=(1, 1 if mc.get('white_specular') else 3))))
     if not mc.get('roughness_mlp'):
         sd['envmap_material_network.roughness'] = _t(g.uniform(1.5, 2.0, size=(1, 1)))
+    if scene is not None:
+        embed_scene_sdf(model, sd, scene, _rng(seed + 1000))
     return sd
 
 
@@ -222,9 +273,42 @@ def make_inputs(num_pixels, image_hw=(800, 800), focal=1111.0, cam_pos=(0.0, 0.0
 
 
 WORKLOADS = {
-    # BASELINE.json configs (1-based index in SURVEY.md section 8d)
-    'cfg1': dict(model='physg', num_pixels=512, image_hw=(64, 64), focal=137.0, cam_pos=(0., 0., 3.0), num_rays=-1),
-    'cfg2': dict(model='physg', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=-1),
-    'cfg3': dict(model='conf', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64),
-    'cfg4': dict(model='neus', num_pixels=8192, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64),
+    # BASELINE.json configs (1-based index in SURVEY.md section 8d).  `scene`: None = the geometric-init sphere
+    # (configs 1-2, convex), 'bowl' = the fitted non-convex stand-in (a ball in a tilted bowl: ~44 % of the primary rays
+    # hit, ~50 % of the secondary rays re-hit, so visibility and the indirect branch do real work)
+    'cfg1': dict(model='physg', num_pixels=512, image_hw=(64, 64), focal=137.0, cam_pos=(0., 0., 3.0), num_rays=-1,
+                 scene=None),
+    'cfg2': dict(model='physg', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=-1,
+                 scene=None),
+    'cfg3': dict(model='conf', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64,
+                 scene='bowl'),
+    'cfg4': dict(model='neus', num_pixels=8192, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64,
+                 scene='bowl'),
+    # config 5: eval-mode full-frame render (render.py: 800 x 800 pixels in raster order, 256 rays per pixel,
+    # memory_capacity_level 18, chunks dealt round-robin over the ranks); num_pixels = pixels per frame
+    'cfg5': dict(model='conf', num_pixels=640000, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=256,
+                 scene='bowl', eval=True, memory_capacity_level=18),
 }
+
+
+def workload_state_dict(name, seed=0, hidden=None):
+    """(model conf, state dict) of a WORKLOADS entry."""
+    w = WORKLOADS[name]
+    mc = model_conf(w['model'], hidden=hidden)
+    return mc, make_state_dict(mc, seed=seed, scene=w.get('scene') if hidden is None else None)
+
+
+def frame_inputs(image_hw=(800, 800), focal=1111.0, cam_pos=(0.0, 0.0, 2.4), num_rays=-1, rows=None, seed=2):
+    """Full-frame render input (render.py:267-283 / scene_dataset.py:149-216 with sampling_idx None): every pixel of the
+    image in raster order - or of the rows `rows` = (first, count) - with the shared sub-pixel jitter when num_rays > 0."""
+    H, W = image_hw
+    r0, nr = (0, H) if rows is None else rows
+    ys, xs = np.mgrid[r0:r0 + nr, 0:W]
+    uv = np.stack([xs, ys], -1).reshape(-1, 2).astype(np.float64)
+    if num_rays > 0:
+        uv = uv[:, None, :] + _rng(seed).uniform(-0.5, 0.5, size=(1, num_rays, 2))
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = focal
+    K[0, 2], K[1, 2] = W / 2.0, H / 2.0
+    return {'uv': _t(uv)[None], 'intrinsics': _t(K)[None], 'pose': _t(look_at_origin_pose(cam_pos))[None],
+            'object_mask': torch.ones(1, uv.shape[0], dtype=torch.bool)}

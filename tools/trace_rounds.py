@@ -13,7 +13,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else 'cfg2'
 mode = sys.argv[2] if len(sys.argv) > 2 else 'train'
 w = dict(syn.WORKLOADS[wl])
 mc = syn.model_conf(w['model'])
-sd = syn.make_state_dict(mc, seed=0)
+sd = syn.make_state_dict(mc, seed=0, scene=w.get('scene'))
 dev = torch.device('cuda:0')
 m = IDRNetwork(conf.from_dict(mc))
 m.load_state_dict(sd)
