@@ -258,10 +258,12 @@ def main():
         n_steps = model.ray_tracer.n_steps
         # algorithmic evaluations (what the reference's recurrences need) vs executed (incl. the unused nodes of
         # the speculative 3-level bisection tree); the roofline credits only the algorithmic ones
-        queries = int((cnt[:, 0] + cnt[:, 1] * n_steps + cnt[:, 3]).sum().item())
+        from nefii_amd import ops as _ops
+        queries = int(_ops.algorithmic_evals(cnt, n_steps).sum().item())
         nodes = 2 ** (model.ray_tracer.bisect_levels or (5 if rays_per_rank <= 16384 else 3)) - 1
-        executed = int((cnt[:, 0] + cnt[:, 1] * n_steps + cnt[:, 2] * nodes).sum().item())
-        launches = int(((cnt[:, 0] + cnt[:, 1] + cnt[:, 2]) > 0).sum().item())
+        ex_split, ex_coarse = _ops.executed_evals(cnt, n_steps, nodes)
+        executed, executed_coarse = int(ex_split.sum().item()), int(ex_coarse.sum().item())
+        launches = int((cnt[:, [0, 1, 2, 4, 5]].sum(dim=1) > 0).sum().item())
         f_eval = sdf_flops_per_eval(model.implicit_network.specs)
         achieved = queries * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
         hit_frac = out['network_object_mask'].float().mean().item()
@@ -288,7 +290,8 @@ def main():
                     'arithmetic': ('3x v_mfma_f32_{16x16x32,32x32x16}_f16 per k-step on fp16 hi/lo operand pairs, fp32 accumulate: '
                                    'achieved counts ALGORITHMIC flops (the matrix cores issue 3x that)') if split
                                   else 'v_mfma_f32_32x32x2_f32 (exact fp32)',
-                    'flops_per_sdf_eval': f_eval, 'sdf_evals_per_step': queries, 'sdf_evals_executed': executed,
+                    'flops_per_sdf_eval': f_eval, 'sdf_evals_per_step': queries, 'sdf_evals_executed_split_precision': executed,
+                    'sdf_evals_executed_single_pass': executed_coarse,
                     'sdf_evals_per_primary_ray': queries / rays_per_rank,
                     'nonempty_launches_per_step': launches, 'launches_per_step': n_eval.value,
                     'kernel_ms_per_step': eval_ms.value, 'tracer_span_ms': span_ms.value,

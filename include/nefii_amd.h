@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 4
+#define NEFII_ABI_VERSION 5
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -141,12 +141,24 @@ typedef struct nefii_tracer_params {
     int32_t precision;       /* SDF evaluation inside the tracer: 0 = f32-input MFMA (exact fp32),
                                 1 = 3x fp16 split MFMA, 32-query tiles; 2 = the same arithmetic on 64-query tiles
                                 (8 waves, weight fragments shared by two row tiles); 1 and 2 need w_f16x3 */
+    float coarse_tau;        /* > 0 (precision 2, pipelined shapes, 16x16x32 stream layout): the n_steps samples of the
+                                bracket search (:203-219) and of the min-SDF search (:316-331) are first evaluated in ONE
+                                fp16 pass (a third of the matrix work); coarse_tau bounds |coarse - split| of a sample.
+                                Only samples whose coarse value cannot decide - within coarse_tau of zero where the
+                                first sign change is looked for, within 2 coarse_tau of the minimum where the argmin
+                                is - are re-evaluated in split precision, so every decision (and the outputs) is the
+                                split evaluator's.  0 = off.  nefii_sdf_eval_coarse measures the bound for a net. */
+    int32_t coarse_cap;      /* most samples of one ray re-evaluated individually; a ray with more takes all n_steps
+                                in split precision instead.  <= 0: 24.  At most 100. */
 } nefii_tracer_params;
+#define NEFII_TRACE_COUNTERS 8   /* int32 counters per round, see nefii_trace_rays */
 
 /* The pipelined evaluator behind nefii_trace_rays (precision 2) and nefii_sdf_eval reads the hidden layers' fragments as
  * ONE stream per wave, 4 KiB per 16-deep unit of the layer sequence: [8 waves][units][4 fragments][64 lanes][8 halves];
  * the fragments are 32x32x16 ones (hi/lo of the wave's two column tiles) or, with nefii_mlp.reserved == 1, 16x16x32 ones
  * (hi/lo of two of the wave's four 16-feature tiles, alternating between the halves of a 32-deep k-step).
+ * With reserved == 1 a third copy follows for the single-pass (coarse) evaluator: hi fragments only, one 32-deep k-step
+ * of the wave's feature tiles per unit, K zero-padded to multiples of 128.
  * nefii_sdf_stream_bytes: size of that buffer, 0 if the net's shape does not qualify (every hidden layer 512 wide,
  * k_x in {0,512}, k_e in {0,64}, 512-deep last layer) - such nets run on the generic kernel and leave w_stream NULL.
  * nefii_pack_sdf_stream: device-side copy from the layers' w_f16x3 (call after nefii_pack_linear_f16x3). */
@@ -163,15 +175,22 @@ int nefii_pack_linear_f16x3_bwd(const float *W, int n_out, int k_in, int x_src0,
  * ray_tracing.py:128-131,211-216,322-327 and pixel_pair_generator.py:52, as a stand-alone call.  x [n][3], needs
  * w_f16x3 in every layer (and uses w_stream when set); bias arrays hold n_pad floats, 16-byte aligned. */
 int nefii_sdf_eval(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream);
+/* The same points through the tracer's single-pass (coarse) evaluator; NEFII_E_UNSUPPORTED when the net has no
+ * single-pass stream (nefii_sdf_coarse_supported).  max |nefii_sdf_eval_coarse - nefii_sdf_eval| over points of the
+ * bounding sphere, with a safety factor, is what a caller passes as nefii_tracer_params.coarse_tau. */
+int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream);
+int nefii_sdf_coarse_supported(const nefii_mlp *h_sdf);
 
 size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *h_params);
 int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
 /* lin_steps: the n_steps values of torch.linspace(0,1,n_steps); minsdf_steps: the n_steps uniforms of
- * minimal_sdf_points (only read when training).  counters (optional, int32 [max_rounds][4]) receives per round:
- * [r][0] single queries, [r][1] rays with n_steps dense queries, [r][2] rays in bisection (2^levels - 1 speculative
- * queries each), [r][3] bisection evaluations actually consumed.
- * Executed SDF evaluations = [0] + n_steps*[1] + (2^levels - 1)*[2]; algorithmic (what the reference's recurrence needs)
- * = [0] + n_steps*[1] + [3]. */
+ * minimal_sdf_points (only read when training).  counters (optional, int32 [max_rounds][NEFII_TRACE_COUNTERS])
+ * receives per round: [r][0] single queries, [r][1] rays with n_steps dense queries in split precision, [r][2] rays in
+ * bisection (2^levels - 1 speculative queries each), [r][3] bisection evaluations actually consumed, [r][4] coarse-pass
+ * samples re-evaluated in split precision, [r][5] rays with n_steps dense queries in the single-pass (coarse) evaluator,
+ * [r][6] rays entering a dense search (the reference evaluates n_steps samples for each), [r][7] reserved.
+ * Algorithmic evaluations (what the reference's recurrences need) = [0] + n_steps*[6] + [3]; executed in split
+ * precision = [0] + n_steps*[1] + (2^levels - 1)*[2] + [4]; executed in the coarse evaluator = n_steps*[5]. */
 int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
                      const float *origins, const float *dirs, const uint8_t *object_mask, int64_t n_rays,
                      const float *lin_steps, const float *minsdf_steps,

@@ -14,7 +14,8 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 4
+ABI_VERSION = 5
+TRACE_COUNTERS = 8          # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
 HEAD_NONE, HEAD_TANH01, HEAD_POW2, HEAD_SIGMOID, HEAD_RELU, HEAD_ABS, HEAD_RELU_INIT = range(7)
@@ -39,7 +40,7 @@ class TracerParams(ctypes.Structure):
                 ('line_search_step', ctypes.c_float), ('line_step_iters', ctypes.c_int32),
                 ('sphere_tracing_iters', ctypes.c_int32), ('n_steps', ctypes.c_int32),
                 ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32), ('bisect_levels', ctypes.c_int32),
-                ('precision', ctypes.c_int32)]
+                ('precision', ctypes.c_int32), ('coarse_tau', ctypes.c_float), ('coarse_cap', ctypes.c_int32)]
 
 
 class LossParams(ctypes.Structure):
@@ -70,6 +71,8 @@ SIGNATURES = {
     'nefii_sdf_stream_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp)]),
     'nefii_pack_sdf_stream': (I, [ctypes.POINTER(Mlp), P, P]),
     'nefii_sdf_eval': (I, [ctypes.POINTER(Mlp), P, I64, P, P]),
+    'nefii_sdf_eval_coarse': (I, [ctypes.POINTER(Mlp), P, I64, P, P]),
+    'nefii_sdf_coarse_supported': (I, [ctypes.POINTER(Mlp)]),
     'nefii_trace_workspace_bytes': (ctypes.c_size_t, [I64, ctypes.POINTER(TracerParams)]),
     'nefii_trace_max_rounds': (I, [ctypes.POINTER(TracerParams)]),
     'nefii_trace_rays': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(TracerParams), P, P, P, I64, P, P, P, P, P, P,

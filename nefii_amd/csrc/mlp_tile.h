@@ -1147,6 +1147,232 @@ __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, f
     }
 }
 
+// ================================================================================================
+// "16s": the pipelined evaluator in ONE fp16 pass (hi x hi only, fp32 accumulate) - the tracer's COARSE pass.
+// The 100-sample bracket search and the min-SDF search of RayTracing (ray_tracing.py:195-257,309-337; ~85 % of all SDF
+// evaluations) only ask for a sign / an argmin: their samples are evaluated here at a third of the split evaluator's
+// matrix work and half its fragment stream, and only the samples whose coarse value is within the error bound
+// nefii_tracer_params.coarse_tau of a decision (a sign change, the minimum) are re-evaluated in split precision
+// (advance_kernel) - the decisions, and with them the tracer's outputs, stay those of the split evaluator.
+// Same tile, cursor, 4 register stages and epilogue idea as "16q"; what changes:
+//   * the stream unit is one 32-deep k-step of the wave's FT feature tiles, hi fragments only (FT KiB), every layer's
+//     K zero-padded to a multiple of 128 (unit counts = multiples of the 4 stages): nefii_pack_sdf_stream's third copy;
+//   * the activation image has the hi halves only (64 or 96 rows x XP halves);
+//   * FT * QT MFMAs per unit, one activation fragment read per query tile and unit.
+// ================================================================================================
+template <int FT>
+struct SStage {
+    half8 f[FT];
+};
+template <int QT>
+struct SAct {
+    half8 h[QT];
+};
+template <int FT>
+struct LdsS {
+    _Float16 Xh[QGeo<FT>::ROWS * QGeo<FT>::XP];
+    _Float16 tail[128];
+};
+// units (32-deep k-steps of the 128-padded K) of a layer in the single-pass stream
+__host__ __device__ __forceinline__ int s_units(const nefii_layer &L) { return ((L.k_x + L.k_e + 127) & ~127) >> 5; }
+
+template <int FT>
+__device__ __forceinline__ void sload(SStage<FT> &st, PCursor &c) {
+    const half8 *p = reinterpret_cast<const half8 *>(reinterpret_cast<const char *>(c.base) + c.off);
+#pragma unroll
+    for (int i = 0; i < FT; ++i) st.f[i] = p[64 * i];
+    c.off += FT * 1024;
+    c.off = c.off == c.bytes ? 0u : c.off;
+}
+
+template <int QT, int XP>
+__device__ __forceinline__ void sload_a(SAct<QT> &st, const _Float16 *ah, int s32) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) st.h[qt] = *reinterpret_cast<const half8 *>(ah + qt * 16 * XP + 32 * s32);
+}
+
+template <int QT, int FT, int J>
+__device__ __forceinline__ void sstep(SStage<FT> (&b)[4], SAct<QT> (&a)[2], PCursor &cur, const _Float16 *ah, int s32,
+                                      f32x4 (&acc)[FT * QT]) {
+    static_assert(QT % FT == 0, "the issue pattern below hands QT / FT activation reads to each feature tile");
+    sload<FT>(b[(J + 3) % 4], cur);
+    sload_a<QT, QGeo<FT>::XP>(a[(J + 1) & 1], ah, s32 + 1);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 &c = acc[ft * QT + qt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[ft], a[J & 1].h[qt], c, 0, 0, 0);
+        }
+    // MFMAs lead; the unit's FT fragment loads and QT activation reads are spread between them (see pstep)
+#pragma unroll
+    for (int i = 0; i < FT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, QT / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, QT - QT / 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, QT / FT, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int QT, int FT>
+__device__ __forceinline__ void sgemm(int units, SStage<FT> (&b)[4], SAct<QT> (&a)[2], PCursor &cur, const _Float16 *ah,
+                                      f32x4 (&acc)[FT * QT]) {
+    for (int s = 0; s < units; s += 4) {
+        sstep<QT, FT, 0>(b, a, cur, ah, s, acc);
+        sstep<QT, FT, 1>(b, a, cur, ah, s + 1, acc);
+        sstep<QT, FT, 2>(b, a, cur, ah, s + 2, acc);
+        sstep<QT, FT, 3>(b, a, cur, ah, s + 3, acc);
+    }
+}
+
+template <int QT, int FT, bool FAST>
+__device__ __forceinline__ void sepilogue(const f32x4 (&acc)[FT * QT], float bvec, float k16, int lane, int act,
+                                          half4 (&phi)[FT * QT]) {
+    const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
+#pragma unroll
+    for (int ft = 0; ft < FT; ++ft) {
+        float4v bs;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            bs[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const f32x4 &av = acc[ft * QT + qt];
+            float4v hs;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float zs = __builtin_fmaf(av[k], k16, bs[k]);
+                hs[k] = FAST ? softplus100_s16(zs) : act_fwd(zs * (1.f / A16_SCALE), act) * A16_SCALE;
+            }
+            phi[ft * QT + qt] = __builtin_convertvector(hs, half4);
+        }
+    }
+}
+
+template <int FT>
+__device__ __forceinline__ void encode_tile16s(const nefii_mlp &m, const float *raw, LdsS<FT> &lds, int rows) {
+    constexpr int XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, EW = QGeo<FT>::EW;
+    const int w0 = enc_width(m.enc_freqs[0]);
+    for (int i = threadIdx.x; i < rows * EW; i += 512) {
+        const int p = i / EW, c = i - p * EW;
+        const float val = c < w0 ? enc_value(raw + p * 9, c) : 0.f;
+        lds.Xh[p * XP + EP + c] = (_Float16)(val * A16_SCALE);
+    }
+}
+
+// units of the split-precision streams that precede the single-pass copy in nefii_mlp.w_stream, in 4 KiB blocks per wave
+template <int FT>
+__host__ __device__ __forceinline__ void s_stream_geometry(const nefii_mlp &m, int &blocks_before, int &G) {
+    int Gq = 0, G8 = 0;
+    G = 0;
+    for (int l = 0; l < m.n_layers - 1; ++l) {
+        Gq += q_units<FT>(m.layer[l]);
+        G8 += q_units8(m.layer[l]);
+        G += s_units(m.layer[l]);
+    }
+    blocks_before = Gq + (FT == 4 ? G8 : 0);
+}
+
+template <int FT>
+__device__ __forceinline__ void prime16s(const nefii_mlp &m, SStage<FT> (&b)[4], PCursor &cur) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int before, G;
+    s_stream_geometry<FT>(m, before, G);
+    const half8 *base = reinterpret_cast<const half8 *>(m.w_stream) + (size_t)8 * before * 256;
+    cur.bytes = (unsigned)G * FT * 1024;
+    cur.base = base + (size_t)wave * G * FT * 64 + lane;
+    cur.off = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) sload<FT>(b[u], cur);
+}
+
+// One tile of 16 * QT queries through the whole SDF network in a single fp16 pass.
+template <int QT, int FT>
+__device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT> &lds, float *raw, float *const *dest,
+                                            SStage<FT> (&b)[4], PCursor &cur) {
+    constexpr int NW = 8, RT = (QT + 1) / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, RMAX = QGeo<FT>::ROWS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NH = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    const float k16 = inv_scale * A16_SCALE;
+    encode_tile16s<FT>(m, raw, lds, 16 * QT);
+    __syncthreads();
+    const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4);
+    for (int l = 0; l < NH; ++l) {
+        const nefii_layer &L = m.layer[l];
+        const int units = s_units(L);
+        const _Float16 *ah = qh0 + (EP - L.k_x);
+        const float *bp = L.bias + 16 * FT * wave + (lane & (16 * FT - 1));
+        asm volatile("" ::"s"(units), "v"(ah), "v"(bp));
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see 16p)
+        __builtin_amdgcn_sched_barrier(0);
+        const float bvec = *bp;
+        f32x4 acc[FT * QT];
+#pragma unroll
+        for (int j = 0; j < FT * QT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+        SAct<QT> a[2];
+        sload_a<QT, XP>(a[0], ah, 0);
+        sgemm<QT, FT>(units, b, a, cur, ah, acc);
+        half4 phi[FT * QT];
+        if (m.act == NEFII_ACT_SOFTPLUS100)
+            sepilogue<QT, FT, true>(acc, bvec, k16, lane, m.act, phi);
+        else
+            sepilogue<QT, FT, false>(acc, bvec, k16, lane, m.act, phi);
+        __syncthreads();
+        _Float16 *xh = lds.Xh + (EP - L.n_pad);
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+            const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int query = 16 * qt + (lane & 15);
+                *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+            }
+        }
+        __syncthreads();
+    }
+    // last layer, column 0 only: hi fragments of the layer's own w_f16x3 (32x32x16), K split over the waves
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const nefii_layer &L = m.layer[NH];
+        const int NT = L.n_pad >> 5;
+        const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
+        const _Float16 *ah = lds.Xh + r * XP + 8 * h + (EP - L.k_x);
+        const int ksw = (L.k_x >> 4) / NW;
+        f32x16 acc2[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
+        for (int u = 0; u < ksw; ++u) {
+            const int s = wave * ksw + u;
+            const half8 wh = wl[(size_t)s * NT * 128];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const half8 xh8 = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP + 16 * s);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh8, acc2[rt], 0, 0, 0);
+            }
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                if (32 * rt + r < RMAX) raw[wave * RMAX + 32 * rt + r] = acc2[rt][0];
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 * QT) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += raw[w * RMAX + threadIdx.x];
+            float *d = dest[threadIdx.x];
+            if (d) *d = sum * inv_scale + L.bias[0];
+        }
+        __syncthreads();
+    }
+}
+
 // accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
 #define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \

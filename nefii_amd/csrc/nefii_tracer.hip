@@ -26,7 +26,11 @@ using namespace nefii;
 
 namespace {
 
-enum Phase : int { PH_DONE = 0, PH_TRACE = 1, PH_SAMPLER = 2, PH_BISECT = 3, PH_MINSDF = 4 };
+// PH_SAMPLER_C / PH_MINSDF_C: the ray's n_steps samples are being evaluated by the single-pass (coarse) evaluator; the
+// exact phases PH_SAMPLER / PH_MINSDF follow once the samples that decide have been re-evaluated in split precision
+enum Phase : int { PH_DONE = 0, PH_TRACE = 1, PH_SAMPLER = 2, PH_BISECT = 3, PH_MINSDF = 4, PH_SAMPLER_C = 5, PH_MINSDF_C = 6 };
+constexpr int PH_POST = 100;      // local to advance_kernel: the stage behind tracing / sampler / bisection
+constexpr int NCNT = NEFII_TRACE_COUNTERS;
 enum Kind : int { Q_START = 0, Q_END = 1, Q_MID = 2 };
 
 struct RayState {            // SoA views into the workspace
@@ -36,6 +40,8 @@ struct RayState {            // SoA views into the workspace
     unsigned *singles;       // [2n]  (ray << 2 | kind)
     unsigned *dense;         // [n]   (ray << 1 | which)  which: 0 sampler, 1 min-sdf
     unsigned *tri;           // [n]   rays in bisection: 7 speculative queries each (3 levels of the bisection tree)
+    unsigned *cdense;        // [n]   (ray << 1 | which): rays whose n_steps samples go through the coarse evaluator
+    unsigned *refine;        // [n * cap]  (ray << 7 | sample): coarse samples to re-evaluate in split precision
 };
 
 // flags layout
@@ -60,45 +66,78 @@ struct Params {
     uint8_t *out_hit;
     int *counters;           // [rounds][4]
     int levels, tri_nodes;   // speculative bisection: levels per round, nodes = 2^levels - 1
+    float tau;               // coarse pass: error bound of a coarse sample (0: coarse pass off)
+    int cap;                 //              most samples of one ray refined individually
     RayState s;
 };
 
 // ---- work-list append: block-aggregated ------------------------------------------------------
-// each thread contributes n_single (0..2) single queries and n_dense (0..1) dense rays.
-__device__ __forceinline__ void append_queries(const Params &P, int round, bool qs, bool qe, bool qt, bool qd,
-                                               unsigned ray, unsigned dense_which, int consumed) {
-    __shared__ int wtot[4][4];
-    __shared__ int base[3];
+// each thread contributes up to 2 single queries, one dense ray (split precision or coarse), one bisecting ray and
+// n_ref coarse samples to refine (bit set `cmask`).
+__device__ __forceinline__ void append_queries(const Params &P, int round, bool qs, bool qe, bool qt, bool qd, bool qc,
+                                               unsigned ray, unsigned dense_which, int consumed, int n_alg, int n_ref,
+                                               const unsigned (&cmask)[4]) {
+    __shared__ int wtot[7][4];
+    __shared__ int base[5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long bs = __ballot(qs), be = __ballot(qe), bt = __ballot(qt), bd = __ballot(qd);
+    const unsigned long long bs = __ballot(qs), be = __ballot(qe), bt = __ballot(qt), bd = __ballot(qd), bc = __ballot(qc);
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int cons = consumed;
+    int cons = consumed, alg = n_alg;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cons += __shfl_xor(cons, o);
+    for (int o = 32; o > 0; o >>= 1) cons += __shfl_xor(cons, o), alg += __shfl_xor(alg, o);
+    int incl = n_ref;               // inclusive prefix sum of the refine counts over the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    const int wref = __shfl(incl, 63);
     if (lane == 0) {
         wtot[0][wave] = __popcll(bs) + __popcll(be);
         wtot[1][wave] = __popcll(bd);
         wtot[2][wave] = __popcll(bt);
         wtot[3][wave] = cons;
+        wtot[4][wave] = wref;
+        wtot[5][wave] = __popcll(bc);
+        wtot[6][wave] = alg;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int t[4];
-        for (int i = 0; i < 4; ++i) t[i] = wtot[i][0] + wtot[i][1] + wtot[i][2] + wtot[i][3];
-        for (int i = 0; i < 3; ++i) base[i] = t[i] ? atomicAdd(&P.counters[round * 4 + i], t[i]) : 0;
-        if (t[3]) atomicAdd(&P.counters[round * 4 + 3], t[3]);
+        int t[7];
+        for (int i = 0; i < 7; ++i) t[i] = wtot[i][0] + wtot[i][1] + wtot[i][2] + wtot[i][3];
+        int *cnt = P.counters + round * NCNT;
+        for (int i = 0; i < 3; ++i) base[i] = t[i] ? atomicAdd(&cnt[i], t[i]) : 0;
+        if (t[3]) atomicAdd(&cnt[3], t[3]);
+        base[3] = t[4] ? atomicAdd(&cnt[4], t[4]) : 0;
+        base[4] = t[5] ? atomicAdd(&cnt[5], t[5]) : 0;
+        if (t[6]) atomicAdd(&cnt[6], t[6]);
     }
     __syncthreads();
-    int off_s = base[0], off_d = base[1], off_t = base[2];
+    int off_s = base[0], off_d = base[1], off_t = base[2], off_r = base[3], off_c = base[4];
     for (int w = 0; w < wave; ++w) {
         off_s += wtot[0][w];
         off_d += wtot[1][w];
         off_t += wtot[2][w];
+        off_r += wtot[4][w];
+        off_c += wtot[5][w];
     }
     if (qs) P.s.singles[off_s + __popcll(bs & lt)] = (ray << 2) | Q_START;
     if (qe) P.s.singles[off_s + __popcll(bs) + __popcll(be & lt)] = (ray << 2) | Q_END;
     if (qd) P.s.dense[off_d + __popcll(bd & lt)] = (ray << 1) | dense_which;
     if (qt) P.s.tri[off_t + __popcll(bt & lt)] = ray;
+    if (qc) P.s.cdense[off_c + __popcll(bc & lt)] = (ray << 1) | dense_which;
+    if (n_ref > 0) {
+        size_t o = (size_t)off_r + incl - n_ref;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned mbits = cmask[w];
+            while (mbits) {
+                const int bit = __ffs(mbits) - 1;
+                mbits &= mbits - 1;
+                P.s.refine[o++] = (ray << 7) | (unsigned)(32 * w + bit);
+            }
+        }
+    }
     __syncthreads();
 }
 
@@ -131,9 +170,13 @@ __device__ __forceinline__ void finish(const Params &P, int64_t r, float dist, b
 __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < P.n;
-    bool qs = false, qe = false, qt = false, qd = false;
+    bool qs = false, qe = false, qt = false, qd = false, qc = false;
     unsigned dense_which = 0;
     int consumed = 0;          // bisection evaluations actually used this round (of the 7 speculated per ray)
+    int n_alg = 0;             // dense searches entered this round (the reference evaluates n_steps samples for each)
+    int n_ref = 0;             // coarse samples of this ray to re-evaluate in split precision (bits of cmask)
+    unsigned cmask[4] = {0u, 0u, 0u, 0u};
+    const bool coarse = P.tau > 0.f;
     const nefii_tracer_params &tp = P.p;
     const float thr = tp.sdf_threshold;
     int fl = 0;
@@ -222,14 +265,16 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                 P.s.t_s[r] = t_s;
                 P.s.t_e[r] = t_e;
                 if (live_s) {
-                    fl |= PH_SAMPLER;
-                    qd = true;
+                    fl |= coarse ? PH_SAMPLER_C : PH_SAMPLER;
+                    qd = !coarse;
+                    qc = coarse;
+                    n_alg = 1;
                     dense_which = 0;
                     P.s.flags[r] = fl;
                     ph = -1;
                 } else {
                     P.s.mid[r] = t_s;      // dist so far
-                    ph = PH_MINSDF + 1;    // falls through to the post-sampler stage below
+                    ph = PH_POST;          // falls through to the post-sampler stage below
                 }
             } else {
                 ++it;
@@ -260,6 +305,59 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             P.s.cur_e[r] = cur_e;
             P.s.nxt_s[r] = nxt_s;
             P.s.nxt_e[r] = nxt_e;
+            P.s.flags[r] = fl;
+            ph = -1;
+        }
+    }
+
+    if (valid && ph == PH_SAMPLER_C) {
+        // The n_steps samples hold COARSE values v16 with |v16 - v| < tau.  What the exact stage below decides from them:
+        // the first negative sample `ind`, the signs at ind and ind-1 (bracket), and - unless the ray surely has a
+        // negative sample and lies inside the object mask - the argmin.  Samples that cannot decide from their coarse
+        // value are re-evaluated in split precision (refine list; next round's exact stage then sees exact values
+        // exactly where it matters); with none, the exact stage runs right away on the coarse values.
+        const int ns = tp.n_steps;
+        const float tau = P.tau;
+        const float *v = P.s.big + (size_t)r * ns;
+        int i0 = -1, i1 = -1;           // first sample that may be negative / that surely is
+        float vmin = v[0];
+        for (int i = 0; i < ns; ++i) {
+            const float x = v[i];
+            if (x < tau && i0 < 0) i0 = i;
+            if (x < -tau && i1 < 0) i1 = i;
+            vmin = x < vmin ? x : vmin;
+        }
+        const bool obj = P.obj[r] != 0;
+        const bool need_argmin = !(obj && i1 >= 0);
+        int n_sign = 0, n_min = 0;
+        if (i0 >= 0) {
+            const int end = i1 >= 0 ? i1 : ns;
+            for (int i = i0; i < end; ++i)
+                if (v[i] < tau) {
+                    cmask[i >> 5] |= 1u << (i & 31);
+                    ++n_sign;
+                }
+            // bracket quirk: ind = 0 pairs with sample ns-1 (ray_tracing.py:245-246)
+            if (i0 == 0 && fabsf(v[ns - 1]) < tau && !((cmask[(ns - 1) >> 5] >> ((ns - 1) & 31)) & 1u)) {
+                cmask[(ns - 1) >> 5] |= 1u << ((ns - 1) & 31);
+                ++n_sign;
+            }
+        }
+        if (need_argmin) {
+            const float lim = vmin + 2.f * tau;
+            for (int i = 0; i < ns; ++i)
+                if (v[i] <= lim) {
+                    cmask[i >> 5] |= 1u << (i & 31);
+                    ++n_min;
+                }
+        }
+        if (n_sign == 0 && n_min <= 1) {
+            ph = PH_SAMPLER;            // every decision is certain from the coarse values
+        } else {
+            const int k = __popc(cmask[0]) + __popc(cmask[1]) + __popc(cmask[2]) + __popc(cmask[3]);
+            if (k <= P.cap) n_ref = k; else qd = true;      // too many: all n_steps samples in split precision
+            dense_which = 0;
+            fl = (fl & ~F_PHASE) | PH_SAMPLER;
             P.s.flags[r] = fl;
             ph = -1;
         }
@@ -310,7 +408,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             ph = -1;
         } else {
             P.s.mid[r] = dist;
-            ph = PH_MINSDF + 1;
+            ph = PH_POST;
         }
     }
 
@@ -341,11 +439,11 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             qt = true;
             ph = -1;
         } else {
-            ph = PH_MINSDF + 1;
+            ph = PH_POST;
         }
     }
 
-    if (valid && ph == PH_MINSDF + 1) {
+    if (valid && ph == PH_POST) {
         // after tracing / sampler: eval mode returns; training mode handles rays that miss (:71-97)
         float dist = P.s.mid[r];
         const bool hit = fl & F_HIT, samp = fl & F_SAMP, sph = fl & F_SPH;
@@ -360,9 +458,11 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                     dist = -fadd(fadd(fmul(dx, ox), fmul(dy, oy)), fmul(dz, oz));
                 } else {
                     if (hit && out_m) P.s.t_min[r] = dist;
-                    fl = (fl & ~F_PHASE) | PH_MINSDF;
+                    fl = (fl & ~F_PHASE) | (coarse ? PH_MINSDF_C : PH_MINSDF);
                     P.s.flags[r] = fl;
-                    qd = true;
+                    qd = !coarse;
+                    qc = coarse;
+                    n_alg = 1;
                     dense_which = 1;
                     done = false;
                 }
@@ -373,6 +473,30 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             P.s.flags[r] = (fl & ~F_PHASE) | PH_DONE;
         }
         ph = -1;
+    }
+
+    if (valid && ph == PH_MINSDF_C) {
+        // argmin over coarse values: every sample within 2 tau of the coarse minimum could be the exact one
+        const int ns = tp.n_steps;
+        const float *v = P.s.big + (size_t)r * ns;
+        float vmin = v[0];
+        for (int i = 1; i < ns; ++i) vmin = v[i] < vmin ? v[i] : vmin;
+        const float lim = vmin + 2.f * P.tau;
+        int k = 0;
+        for (int i = 0; i < ns; ++i)
+            if (v[i] <= lim) {
+                cmask[i >> 5] |= 1u << (i & 31);
+                ++k;
+            }
+        if (k <= 1) {
+            ph = PH_MINSDF;
+        } else {
+            if (k <= P.cap) n_ref = k; else qd = true;
+            dense_which = 1;
+            fl = (fl & ~F_PHASE) | PH_MINSDF;
+            P.s.flags[r] = fl;
+            ph = -1;
+        }
     }
 
     if (valid && ph == PH_MINSDF) {
@@ -391,51 +515,103 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         P.s.flags[r] = (fl & ~F_PHASE) | PH_DONE;
     }
 
-    append_queries(P, round, qs, qe, qt, qd, (unsigned)r, dense_which, consumed);
+    append_queries(P, round, qs, qe, qt, qd, qc, (unsigned)r, dense_which, consumed, n_alg, n_ref, cmask);
 }
 
 // ---- SDF evaluation of one round's work list -------------------------------------------------
-// decode the 32 queries of a tile into points (raw[32][9]) and result addresses (dest[32])
+// queries of a round in split precision, in this order: singles | dense rays x n_steps | bisecting rays x tree nodes |
+// refined coarse samples
+struct RoundWork {
+    int n_single;
+    int64_t n_sd, n_sdt, total;
+};
+__device__ __forceinline__ RoundWork round_work(const Params &P, int round) {
+    const int *c = P.counters + round * NCNT;
+    RoundWork w;
+    w.n_single = c[0];
+    w.n_sd = (int64_t)c[0] + (int64_t)c[1] * P.p.n_steps;
+    w.n_sdt = w.n_sd + (int64_t)c[2] * P.tri_nodes;
+    w.total = w.n_sdt + c[4];
+    return w;
+}
+
+// depth of dense sample i of ray r: the bracket search's linspace (ray_tracing.py:205) or the min-SDF search's uniform
+// draws (:319); the one expression both the dense and the refine path use
+__device__ __forceinline__ float dense_depth(const Params &P, int64_t r, int i, bool minsdf) {
+    if (minsdf) {
+        const float tmin = P.s.t_min[r], tmax = P.s.t_max[r];
+        return fadd(fmul(P.steps[i], fsub(tmax, tmin)), tmin);
+    }
+    const float a = P.s.t_s[r];
+    return fadd(a, fmul(P.lin[i], fsub(P.s.t_e[r], a)));
+}
+
+// decode the ROWS queries of a tile into points (raw[ROWS][9]) and result addresses (dest[ROWS])
 template <int ROWS>
-__device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, int64_t total, int n_single, int64_t n_sd,
-                                            float *raw, float **dest) {
+__device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const RoundWork &W, float *raw, float **dest) {
     const int tid = threadIdx.x;
     if (tid >= ROWS) return;
     const int ns = P.p.n_steps;
     int64_t q = tile * ROWS + tid;
     float *dst = nullptr;
     float px = 0.f, py = 0.f, pz = 0.f;
-    if (q < total) {
+    if (q < W.total) {
         int64_t r;
         float t;
-        if (q < n_single) {
+        if (q < W.n_single) {
             const unsigned e = P.s.singles[q];
             r = e >> 2;
             const int kind = e & 3;
             t = kind == Q_START ? P.s.t_s[r] : (kind == Q_END ? P.s.t_e[r] : P.s.mid[r]);
             dst = kind == Q_END ? &P.s.res_e[r] : &P.s.res_s[r];
-        } else if (q >= n_sd) {
-            const int64_t qq = q - n_sd;
+        } else if (q >= W.n_sdt) {
+            const unsigned e = P.s.refine[q - W.n_sdt];
+            r = e >> 7;
+            const int i = e & 127;
+            t = dense_depth(P, r, i, (P.s.flags[r] & F_PHASE) == PH_MINSDF);
+            dst = &P.s.big[(size_t)r * ns + i];
+        } else if (q >= W.n_sd) {
+            const int64_t qq = q - W.n_sd;
             const int64_t ti = qq / P.tri_nodes;
             const int j = (int)(qq - ti * P.tri_nodes);
             r = P.s.tri[ti];
             t = tri_depth(P.s.lo[r], P.s.hi[r], j);
             dst = &P.s.big[(size_t)r * ns + j];
         } else {
-            const int64_t qq = q - n_single;
+            const int64_t qq = q - W.n_single;
             const int64_t di = qq / ns;
             const int i = (int)(qq - di * ns);
             const unsigned e = P.s.dense[di];
             r = e >> 1;
-            if (e & 1) {   // min-SDF search depths: steps * (max - min) + min   (ray_tracing.py:319)
-                const float tmin = P.s.t_min[r], tmax = P.s.t_max[r];
-                t = fadd(fmul(P.steps[i], fsub(tmax, tmin)), tmin);
-            } else {       // sampler depths: min + lin * (max - min)            (ray_tracing.py:205)
-                const float a = P.s.t_s[r];
-                t = fadd(a, fmul(P.lin[i], fsub(P.s.t_e[r], a)));
-            }
+            t = dense_depth(P, r, i, e & 1);
             dst = &P.s.big[(size_t)r * ns + i];
         }
+        px = fadd(P.o[r * 3], fmul(t, P.d[r * 3]));
+        py = fadd(P.o[r * 3 + 1], fmul(t, P.d[r * 3 + 1]));
+        pz = fadd(P.o[r * 3 + 2], fmul(t, P.d[r * 3 + 2]));
+    }
+    dest[tid] = dst;
+    float *rw = raw + tid * 9;
+    rw[0] = px, rw[1] = py, rw[2] = pz;
+    rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
+}
+
+// the same for the coarse evaluator's list: rays x n_steps samples
+template <int ROWS>
+__device__ __forceinline__ void decode_tile_coarse(const Params &P, int64_t tile, int64_t total, float *raw, float **dest) {
+    const int tid = threadIdx.x;
+    if (tid >= ROWS) return;
+    const int ns = P.p.n_steps;
+    const int64_t q = tile * ROWS + tid;
+    float *dst = nullptr;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (q < total) {
+        const int64_t di = q / ns;
+        const int i = (int)(q - di * ns);
+        const unsigned e = P.s.cdense[di];
+        const int64_t r = e >> 1;
+        const float t = dense_depth(P, r, i, e & 1);
+        dst = &P.s.big[(size_t)r * ns + i];
         px = fadd(P.o[r * 3], fmul(t, P.d[r * 3]));
         py = fadd(P.o[r * 3 + 1], fmul(t, P.d[r * 3 + 1]));
         pz = fadd(P.o[r * 3 + 2], fmul(t, P.d[r * 3 + 2]));
@@ -450,17 +626,14 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int
     __shared__ Lds lds;
     __shared__ float raw[TILE * 9];
     __shared__ float *dest[TILE];
-    const int n_single = P.counters[round * 4 + 0];
-    const int n_dense = P.counters[round * 4 + 1];
-    const int n_tri = P.counters[round * 4 + 2];
-    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
-    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
+    const RoundWork W = round_work(P, round);
+    const int64_t total = W.total;
     const int64_t n_tiles = (total + TILE - 1) / TILE;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
     const int Lm1 = m.n_layers - 1;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile<TILE>(P, tile, total, n_single, n_sd, raw, dest);
+        decode_tile<TILE>(P, tile, W, raw, dest);
         __syncthreads();
         encode_tile(m, raw, lds.E, ke);
         __syncthreads();
@@ -487,18 +660,15 @@ __global__ __launch_bounds__(256, 1) void eval_kernel16(Params P, nefii_mlp m, i
     __shared__ Lds16 lds;
     __shared__ float raw[TILE * 9];
     __shared__ float *dest[TILE];
-    const int n_single = P.counters[round * 4 + 0];
-    const int n_dense = P.counters[round * 4 + 1];
-    const int n_tri = P.counters[round * 4 + 2];
-    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
-    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
+    const RoundWork W = round_work(P, round);
+    const int64_t total = W.total;
     const int64_t n_tiles = (total + TILE - 1) / TILE;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
     const int Lm1 = m.n_layers - 1;
     const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile<TILE>(P, tile, total, n_single, n_sd, raw, dest);
+        decode_tile<TILE>(P, tile, W, raw, dest);
         __syncthreads();
         encode_tile16(m, raw, lds, ke);
         __syncthreads();
@@ -569,16 +739,13 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, 
     __shared__ Lds16w lds;
     __shared__ float raw[TILE_W * 9];
     __shared__ float *dest[TILE_W];
-    const int n_single = P.counters[round * 4 + 0];
-    const int n_dense = P.counters[round * 4 + 1];
-    const int n_tri = P.counters[round * 4 + 2];
-    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
-    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
+    const RoundWork W = round_work(P, round);
+    const int64_t total = W.total;
     const int64_t n_tiles = (total + TILE_W - 1) / TILE_W;
     int ke = 0;
     for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile<TILE_W>(P, tile, total, n_single, n_sd, raw, dest);
+        decode_tile<TILE_W>(P, tile, W, raw, dest);
         __syncthreads();
         sdf_tile16w(m, lds, raw, dest, ke);
     }
@@ -596,11 +763,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Param
     __shared__ Lds16p lds;
     __shared__ float raw[TILE_W * 9];
     __shared__ float *dest[TILE_W];
-    const int n_single = P.counters[round * 4 + 0];
-    const int n_dense = P.counters[round * 4 + 1];
-    const int n_tri = P.counters[round * 4 + 2];
-    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
-    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
+    const RoundWork W = round_work(P, round);
+    const int64_t total = W.total;
     if ((total <= SMALL_ROUND) != (RT == 1)) return;
     constexpr int ROWS = 32 * RT;
     const int64_t n_tiles = (total + ROWS - 1) / ROWS;
@@ -612,7 +776,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Param
     int ph = 0;
     prime16p<NW>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile<ROWS>(P, tile, total, n_single, n_sd, raw, dest);
+        decode_tile<ROWS>(P, tile, W, raw, dest);
         __syncthreads();
         sdf_tile16p<NW, RT>(m, lds, raw, dest, b, cur, ph, ke);
     }
@@ -635,11 +799,8 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
     __shared__ LdsQ<FT> lds;
     __shared__ float raw[RMAX * 9];
     __shared__ float *dest[RMAX];
-    const int n_single = P.counters[round * 4 + 0];
-    const int n_dense = P.counters[round * 4 + 1];
-    const int n_tri = P.counters[round * 4 + 2];
-    const int64_t n_sd = (int64_t)n_single + (int64_t)n_dense * P.p.n_steps;
-    const int64_t total = n_sd + (int64_t)n_tri * P.tri_nodes;
+    const RoundWork W = round_work(P, round);
+    const int64_t total = W.total;
     // Which instance takes which queries.  Rounds up to SMALL_ROUND: all in 32-query tiles.  Larger rounds: big tiles
     // (64 / 96 queries); when the big tiles form whole waves of one tile per CU plus a remainder that fits one wave of
     // 32-query tiles, that remainder goes to the 32-query instance (a wave of those is done in ~110 instead of ~160 us).
@@ -669,9 +830,65 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
     PCursor cur;
     prime16q<FT, NB>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile<ROWS>(P, first + tile, total, n_single, n_sd, raw, dest);
+        decode_tile<ROWS>(P, first + tile, W, raw, dest);
         __syncthreads();
         sdf_tile16q<QT, FT, NB>(m, lds, raw, dest, b, cur);
+    }
+}
+
+// the coarse evaluator (mlp_tile.h "16s") over the round's coarse list: one fp16 pass, 16 * QT queries per tile
+template <int FT>
+__device__ __forceinline__ void zero_lds_s(LdsS<FT> &lds) {
+    uint32_t *p = reinterpret_cast<uint32_t *>(&lds);
+    for (int i = threadIdx.x; i < (int)(sizeof(LdsS<FT>) / 4); i += blockDim.x) p[i] = 0u;
+    __syncthreads();
+}
+
+template <int QT, int FT>
+__global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, int round) {
+    constexpr int RMAX = QGeo<FT>::ROWS, ROWS = 16 * QT;
+    static_assert(ROWS <= RMAX, "tile rows");
+    __shared__ LdsS<FT> lds;
+    __shared__ float raw[RMAX * 9];
+    __shared__ float *dest[RMAX];
+    const int64_t total = (int64_t)P.counters[round * NCNT + 5] * P.p.n_steps;
+    const int64_t n_tiles = (total + ROWS - 1) / ROWS;
+    if (blockIdx.x >= n_tiles) return;
+    zero_lds_s(lds);        // the K-padded stream multiplies what follows a layer's own columns by zero weights: keep it finite
+    SStage<FT> b[4];
+    PCursor cur;
+    prime16s<FT>(m, b, cur);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        decode_tile_coarse<ROWS>(P, tile, total, raw, dest);
+        __syncthreads();
+        sdf_tile16s<QT, FT>(m, lds, raw, dest, b, cur);
+    }
+}
+
+template <int QT, int FT>
+__global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, const float *__restrict__ x, int64_t n,
+                                                              float *__restrict__ out) {
+    constexpr int RMAX = QGeo<FT>::ROWS, ROWS = 16 * QT;
+    __shared__ LdsS<FT> lds;
+    __shared__ float raw[RMAX * 9];
+    __shared__ float *dest[RMAX];
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
+    zero_lds_s(lds);
+    SStage<FT> b[4];
+    PCursor cur;
+    prime16s<FT>(m, b, cur);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tid = threadIdx.x;
+        if (tid < ROWS) {
+            const int64_t q = tile * ROWS + tid;
+            float *rw = raw + tid * 9;
+            const bool live = q < n;
+            rw[0] = live ? x[q * 3] : 0.f, rw[1] = live ? x[q * 3 + 1] : 0.f, rw[2] = live ? x[q * 3 + 2] : 0.f;
+            rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
+            dest[tid] = live ? out + q : nullptr;
+        }
+        __syncthreads();
+        sdf_tile16s<QT, FT>(m, lds, raw, dest, b, cur);
     }
 }
 
@@ -818,6 +1035,33 @@ __global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int
     dst[((size_t)wave * G + g) * 256 + threadIdx.x] = v;
 }
 
+// third copy (nefii_mlp.reserved == 1 only): the single-pass evaluator's stream.  Unit g of a wave = one 32-deep k-step
+// of the layer sequence with every layer's K padded to a multiple of 128, hi fragments of the wave's FT feature tiles:
+// dst[((wave*G + g)*FT + f)*64 + lane][j] = hi(W[n = 16 FT wave + 16 f + (lane&15)][k = 32 s + 8 (lane>>4) + j]),
+// zeros past the layer's own K.  blockDim.x = 64 FT.
+__global__ void pack_sdf_stream_sp_kernel(nefii_mlp m, half8 *__restrict__ dst, int G, int ft) {
+    const int g = blockIdx.x, wave = blockIdx.y;
+    int l = 0, s = g;
+    while (s >= s_units(m.layer[l])) s -= s_units(m.layer[l]), ++l;
+    const half8 *w = reinterpret_cast<const half8 *>(m.layer[l].w_f16x3);
+    const int f = threadIdx.x >> 6, lane = threadIdx.x & 63, kg = lane >> 4;
+    const int n = 16 * ft * wave + 16 * f + (lane & 15);
+    const int s16 = 2 * s + (kg >> 1), t = n >> 5, lane_src = (n & 31) + 32 * (kg & 1);
+    const int NT = m.layer[l].n_pad >> 5;
+    half8 v;
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+    if (s16 < ((m.layer[l].k_x + m.layer[l].k_e) >> 4)) v = w[(((size_t)s16 * NT + t) * 2) * 64 + lane_src];
+    dst[((size_t)wave * G + g) * ft * 64 + threadIdx.x] = v;
+}
+
+// units of the single-pass copy (0: the net has none)
+int stream_steps_sp(const nefii_mlp *m) {
+    if (!shape16p(m) || m->reserved != 1) return 0;
+    int G = 0;
+    for (int l = 0; l < m->n_layers - 1; ++l) G += s_units(m->layer[l]);
+    return G;
+}
+
 // the same tile evaluator over an explicit point list (nefii_sdf_eval)
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16w(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
@@ -844,7 +1088,7 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16w(nefii_mlp m, cons
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-size_t carve(RayState &s, char *base, int64_t n, int ns) {
+size_t carve(RayState &s, char *base, int64_t n, int ns, int cap) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char *p = base ? base + off : nullptr;
@@ -859,6 +1103,8 @@ size_t carve(RayState &s, char *base, int64_t n, int ns) {
     s.singles = (unsigned *)take(sizeof(unsigned) * 2 * n);
     s.dense = (unsigned *)take(sizeof(unsigned) * n);
     s.tri = (unsigned *)take(sizeof(unsigned) * n);
+    s.cdense = (unsigned *)take(sizeof(unsigned) * n);
+    s.refine = (unsigned *)take(sizeof(unsigned) * (size_t)n * (cap > 0 ? cap : 0));
     return off;
 }
 
@@ -932,7 +1178,13 @@ extern "C" int nefii_trace_profile_launches(float *h_ms, int cap) {
 
 extern "C" size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf) {
     if (!h_sdf || h_sdf->n_layers < 2 || h_sdf->n_layers > NEFII_MAX_LAYERS || !shape16p(h_sdf)) return 0;
-    return (size_t)8 * (stream_steps(h_sdf) + stream_steps8(h_sdf)) * 256 * sizeof(half8);
+    return (size_t)8 * (stream_steps(h_sdf) + stream_steps8(h_sdf)) * 256 * sizeof(half8) +
+           (size_t)8 * stream_steps_sp(h_sdf) * shape16p(h_sdf) * 64 * sizeof(half8);
+}
+
+extern "C" int nefii_sdf_coarse_supported(const nefii_mlp *h_sdf) {
+    return h_sdf && h_sdf->w_stream && h_sdf->n_layers >= 2 && h_sdf->n_layers <= NEFII_MAX_LAYERS &&
+           stream_steps_sp(h_sdf) > 0;
 }
 
 extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, void *stream) {
@@ -950,6 +1202,33 @@ extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, voi
                            (half8 *)w_stream + (size_t)8 * G * 256, G8, 4, 1);
         HIP_CHECK_LAUNCH();
     }
+    const int Gs = stream_steps_sp(h_sdf);
+    if (Gs > 0) {
+        const int ft = shape16p(h_sdf);
+        hipLaunchKernelGGL(pack_sdf_stream_sp_kernel, dim3(Gs, 8), dim3(64 * ft), 0, (hipStream_t)stream, *h_sdf,
+                           (half8 *)w_stream + (size_t)8 * (G + G8) * 256, Gs, ft);
+        HIP_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
+extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream) {
+    if (!h_sdf || h_sdf->n_layers < 1 || h_sdf->n_layers > NEFII_MAX_LAYERS) return NEFII_E_ARG;
+    if (!nefii_sdf_coarse_supported(h_sdf)) return NEFII_E_UNSUPPORTED;
+    if (n <= 0) return 0;
+    if (!x || !sdf_out) return NEFII_E_ARG;
+    if (h_sdf->enc_freqs[0] < 0 || h_sdf->enc_freqs[1] >= 0 || h_sdf->enc_freqs[2] >= 0 || h_sdf->feat_width != 0 ||
+        h_sdf->layer[0].k_x != 0)
+        return NEFII_E_UNSUPPORTED;
+    const int ft = shape16p(h_sdf);
+    const int rows = ft == 2 ? 96 : 64;
+    const int64_t n_tiles = (n + rows - 1) / rows;
+    const dim3 grid((int)(n_tiles < 512 ? n_tiles : 512));
+    if (ft == 2)
+        hipLaunchKernelGGL((sdf_points_kernel16s<6, 2>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    else
+        hipLaunchKernelGGL((sdf_points_kernel16s<4, 4>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    HIP_CHECK_LAUNCH();
     return 0;
 }
 
@@ -980,18 +1259,27 @@ extern "C" int nefii_sdf_eval(const nefii_mlp *h_sdf, const float *x, int64_t n,
     return 0;
 }
 
+// samples of one ray the coarse pass refines individually (0: coarse pass off)
+static int coarse_cap(const nefii_tracer_params *p) {
+    if (!(p->coarse_tau > 0.f)) return 0;
+    const int c = p->coarse_cap <= 0 ? 24 : p->coarse_cap;
+    return c > 100 ? 100 : c;
+}
+
 extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     if (!p) return 0;
     // initial eval + iters*(step + back-offs) -> sampler -> bisection (L levels per round) -> min-SDF -> bookkeeping
+    // with the coarse pass each of the two dense searches takes one round more (coarse samples -> refined samples)
     const int L = p->bisect_levels >= 1 && p->bisect_levels <= 5 ? p->bisect_levels : 3;
-    return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + (p->n_rootfind_steps + L - 1) / L + 1 + 2;
+    return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + (p->n_rootfind_steps + L - 1) / L + 1 + 2 +
+           (p->coarse_tau > 0.f ? 2 : 0);
 }
 
 extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *p) {
     if (!p || n_rays <= 0) return 0;
     RayState s;
-    size_t bytes = carve(s, nullptr, n_rays, p->n_steps);
-    bytes += align256(sizeof(int) * 4 * (size_t)nefii_trace_max_rounds(p));
+    size_t bytes = carve(s, nullptr, n_rays, p->n_steps, coarse_cap(p));
+    bytes += align256(sizeof(int) * NCNT * (size_t)nefii_trace_max_rounds(p));
     return bytes;
 }
 
@@ -1002,6 +1290,7 @@ struct TraceJob {
     const nefii_mlp *sdf;
     int precision, rounds, adv_blocks, eval_blocks, eval_blocks_w;
     int pipelined;      // feature tiles per wave of the pipelined evaluator (4 / 2), 0: generic kernels
+    int coarse;         // the coarse pass runs (its kernel is launched every round)
     hipStream_t st;
     int32_t *counters;
 };
@@ -1044,12 +1333,20 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     P.out_pts = out_points;
     P.out_dist = out_dists;
     P.out_hit = out_hit;
-    size_t off = carve(P.s, (char *)workspace, n_rays, h_params->n_steps);
+    // coarse pass: needs the single-pass stream (pipelined shapes, 16x16x32 layout), sample ids in 7 bits and ray ids in
+    // the other 25 of a refine entry
+    J.pipelined = h_params->precision == 2 ? fits16p(h_sdf) : 0;
+    J.coarse = h_params->coarse_tau > 0.f && J.pipelined && nefii_sdf_coarse_supported(h_sdf) &&
+               n_rays < (1ll << 25) && h_params->n_steps <= 128;
+    if (h_params->coarse_tau < 0.f || h_params->coarse_tau > 1.f) return NEFII_E_ARG;
+    P.tau = J.coarse ? h_params->coarse_tau : 0.f;
+    P.cap = coarse_cap(h_params);
+    size_t off = carve(P.s, (char *)workspace, n_rays, h_params->n_steps, P.cap);
     P.counters = (int *)((char *)workspace + off);
     P.levels = levels;
     P.tri_nodes = (1 << levels) - 1;
     if (reset) {      // a continuation keeps the ray state and counters in the workspace
-        hipError_t e = hipMemsetAsync(P.counters, 0, sizeof(int) * 4 * J.rounds, J.st);
+        hipError_t e = hipMemsetAsync(P.counters, 0, sizeof(int) * NCNT * J.rounds, J.st);
         if (e != hipSuccess) return (int)e;
         e = hipMemsetAsync(P.s.flags, 0, sizeof(int) * n_rays, J.st);
         if (e != hipSuccess) return (int)e;
@@ -1059,7 +1356,6 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     const int64_t max_q = n_rays * (int64_t)h_params->n_steps;   // n_steps >= 2^levels > bisection tree nodes > 2 ends
     const int64_t max_tiles = (max_q + TILE - 1) / TILE;
     J.eval_blocks = (int)(max_tiles < 1024 ? max_tiles : 1024);
-    J.pipelined = h_params->precision == 2 ? fits16p(h_sdf) : 0;
     const int64_t max_tiles_w = (max_q + TILE_W - 1) / TILE_W;
     // tile evaluators: up to 2048 workgroups (one resident per CU: LDS), i.e. one or two tiles each for the rounds of the
     // headline workloads - the hardware dispatcher then balances tiles over CUs, also between the kernels of two traces in
@@ -1114,6 +1410,16 @@ int launch_round(const TraceJob &J, int r, bool profile) {
         else
             hipLaunchKernelGGL(eval_kernel, dim3(J.eval_blocks), dim3(WG), 0, st, J.P, *J.sdf, r);
         HIP_CHECK_LAUNCH();
+        if (J.coarse) {
+            if (J.pipelined == 2) {
+                const int64_t t = (J.P.n * (int64_t)J.P.p.n_steps + 95) / 96;
+                hipLaunchKernelGGL((eval_kernel16s<6, 2>), dim3((int)(t < J.eval_blocks_w ? t : J.eval_blocks_w)), dim3(512), 0,
+                                   st, J.P, *J.sdf, r);
+            } else {
+                hipLaunchKernelGGL((eval_kernel16s<4, 4>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
+            }
+            HIP_CHECK_LAUNCH();
+        }
         if (profile) (void)hipEventRecord(e1, st);
     }
     return 0;
@@ -1121,7 +1427,7 @@ int launch_round(const TraceJob &J, int r, bool profile) {
 
 int finish_job(const TraceJob &J) {
     if (J.counters) {
-        hipError_t e = hipMemcpyAsync(J.counters, J.P.counters, sizeof(int) * 4 * J.rounds, hipMemcpyDeviceToDevice, J.st);
+        hipError_t e = hipMemcpyAsync(J.counters, J.P.counters, sizeof(int) * NCNT * J.rounds, hipMemcpyDeviceToDevice, J.st);
         if (e != hipSuccess) return (int)e;
     }
     return 0;
@@ -1175,7 +1481,7 @@ extern "C" int nefii_trace_rays_groups(const nefii_mlp *h_sdf, const nefii_trace
         if (lo < 0 || n <= 0) return NEFII_E_ARG;
         int rc = prepare_job(J[g], h_sdf, h_params, origins + 3 * lo, dirs + 3 * lo, object_mask + lo, n, lin_steps,
                              minsdf_steps, out_points + 3 * lo, out_hit + lo, out_dists + lo, workspaces[g],
-                             workspace_bytes[g], counters ? counters + (size_t)g * rounds * 4 : nullptr,
+                             workspace_bytes[g], counters ? counters + (size_t)g * rounds * NCNT : nullptr,
                              round_begin == 0, streams[g]);
         if (rc) return rc;
     }

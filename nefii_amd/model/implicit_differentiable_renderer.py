@@ -70,6 +70,15 @@ class ImplicitNetwork(nn.Module):
         self._pm = None
         self._pm_version = None
         self._pm_fit = None
+        self._tau = None          # (packed version, error bound of the tracer's coarse pass for these weights)
+
+    def coarse_tau(self, radius=1.0):
+        """Error bound of the tracer's single-pass evaluator for the current weights (ops.calibrate_coarse_tau), measured
+        once per packed version - i.e. once, with frozen geometry.  0.0 if the net has no single-pass stream."""
+        pm = self.packed(f16x3=True)
+        if self._tau is None or self._tau[0] != self._pm_version or self._tau[1] != radius:
+            self._tau = (self._pm_version, radius, ops.calibrate_coarse_tau(pm, radius))
+        return self._tau[2]
 
     def effective_weights(self):
         ws, bs = [], []
@@ -340,6 +349,7 @@ class IDRNetwork(nn.Module):
         points, network_object_mask, object_mask = ctx['points'], ctx['network_object_mask'], ctx['object_mask']
         sdf_output, pre, ray_dirs = ctx['sdf_output'], ctx['pre'], ctx['ray_dirs']
         surface_mask = network_object_mask
+        self.last_ray_hit = network_object_mask     # per-RAY mask of this forward (the output dict's is per pixel); diagnostics
         n_all = points.shape[0]
         rows = n_all + (1 if dst is not None else 0)
         dev = points.device

@@ -43,6 +43,14 @@ class RayTracing(nn.Module):
         self.skip_min_sdf_search = False
         # a list: traces append their deferred round-prefix checks instead of syncing (ops.trace_rays `deferred`)
         self.deferred_checks = None
+        # Coarse pass (nefii_tracer_params.coarse_tau): the 100 samples of the bracket search and of the min-SDF search are
+        # evaluated in ONE fp16 pass first, and only the samples that decide a sign change / the argmin are re-evaluated
+        # in split precision - same decisions and outputs as without it, ~2.5x less matrix work on ~85 % of the
+        # evaluations.  The error bound is measured per network (ImplicitNetwork.coarse_tau); coarse_tau_override pins
+        # it (tests), NEFII_TRACER_COARSE=0 turns the pass off.
+        self.coarse = os.environ.get('NEFII_TRACER_COARSE', '1') != '0'
+        self.coarse_tau_override = None
+        self.coarse_cap = int(os.environ.get('NEFII_TRACER_COARSE_CAP', '0'))
 
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
@@ -85,7 +93,12 @@ class RayTracing(nn.Module):
                 steps = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
         n_rays = dirs.shape[0]
         levels = self.bisect_levels or (5 if n_rays <= 16384 else 3)
-        params = ops.make_tracer_params(self._cfg(), training, self.precision, levels)
+        tau = 0.0
+        if self.coarse and self.precision == 'f16x3w':
+            tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
+                net.coarse_tau(self.object_bounding_sphere)
+        params = ops.make_tracer_params(self._cfg(), training, self.precision, levels, coarse_tau=tau,
+                                        coarse_cap=self.coarse_cap)
         state = None
         if self.adaptive_rounds:      # one guess per (mode, batch size): primary and secondary traces differ
             import math

@@ -269,24 +269,61 @@ def sdf_value_grad(pm, x, want_feat=False):
     return out, feat, grad
 
 
-def sdf_eval(pm, x):
-    """implicit_network(x)[:, 0] with the tracer's split-precision tile evaluator (needs PackedMLP(f16x3=True))."""
+def sdf_eval(pm, x, coarse=False):
+    """implicit_network(x)[:, 0] with the tracer's split-precision tile evaluator (needs PackedMLP(f16x3=True));
+    coarse=True: with its single-pass (one fp16 MFMA per product) evaluator instead."""
     lib = _lib.lib()
     x = x.contiguous()
     n = x.shape[0]
     out = torch.empty(n, device=x.device, dtype=torch.float32)
     if n > 0:
-        _lib.check(lib.nefii_sdf_eval(ctypes.byref(pm.struct), _ptr(x), n, _ptr(out), _stream()), 'nefii_sdf_eval')
+        fn, name = (lib.nefii_sdf_eval_coarse, 'nefii_sdf_eval_coarse') if coarse else (lib.nefii_sdf_eval, 'nefii_sdf_eval')
+        _lib.check(fn(ctypes.byref(pm.struct), _ptr(x), n, _ptr(out), _stream()), name)
     return out
+
+
+def coarse_supported(pm):
+    return bool(pm.f16x3 and pm.w_stream is not None and _lib.lib().nefii_sdf_coarse_supported(ctypes.byref(pm.struct)))
+
+
+def calibrate_coarse_tau(pm, radius=1.0, n=32768, safety=4.0, seed=0):
+    """Error bound of the tracer's coarse pass for THIS network: `safety` x the largest |single-pass - split| SDF value
+    over n points drawn uniformly in the bounding sphere (where the tracer samples), at least 1e-4.  0.0 when the net
+    has no single-pass stream.  One host sync; callers cache it per packed weight version (geometry is frozen)."""
+    if not coarse_supported(pm):
+        return 0.0
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, generator=g)
+    x = x / x.norm(dim=1, keepdim=True) * (torch.rand(n, 1, generator=g) ** (1.0 / 3.0)) * (radius * 1.02)
+    x = x.to(pm.device)
+    err = (sdf_eval(pm, x, coarse=True) - sdf_eval(pm, x)).abs().max().item()
+    if not math.isfinite(err):
+        return 0.0
+    return max(1e-4, safety * err)
+
+
+def algorithmic_evals(counters, n_steps):
+    """SDF evaluations the reference's recurrences need for the rounds in `counters` [..., rounds, 8] (what the
+    roofline credits): singles + n_steps per dense search entered + bisection steps consumed."""
+    c = counters.long()
+    return c[..., 0] + c[..., 6] * n_steps + c[..., 3]
+
+
+def executed_evals(counters, n_steps, tri_nodes):
+    """(split-precision evaluations, coarse single-pass evaluations) actually executed."""
+    c = counters.long()
+    return c[..., 0] + c[..., 1] * n_steps + c[..., 2] * tri_nodes + c[..., 4], c[..., 5] * n_steps
 
 
 PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}
 
 
-def make_tracer_params(cfg, training, precision='f32', bisect_levels=3):
+def make_tracer_params(cfg, training, precision='f32', bisect_levels=3, coarse_tau=0.0, coarse_cap=0):
     p = TracerParams()
     p.precision = PRECISIONS[precision]
     p.bisect_levels = bisect_levels
+    p.coarse_tau = float(coarse_tau)
+    p.coarse_cap = int(coarse_cap)
     p.object_bounding_sphere = cfg.get('object_bounding_sphere', 1.0)
     p.sdf_threshold = cfg.get('sdf_threshold', 5.0e-5)
     p.line_search_step = cfg.get('line_search_step', 0.5)
@@ -309,6 +346,7 @@ class TraceRounds:
 
 
 _TRACE_STREAMS = {}
+_WORK = [0, 1, 2, 4, 5]      # counter columns that mean "a ray still waits for an evaluation"
 
 
 def _trace_streams(dev, n):
@@ -341,7 +379,7 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
     rounds = lib.nefii_trace_max_rounds(ctypes.byref(params))
     need_cnt = want_counters or rounds_state is not None
     groups = max(1, min(int(groups), n // 64)) if n > 0 else 1
-    counters = torch.zeros(groups, rounds, 4, device=dev, dtype=torch.int32) if need_cnt else None
+    counters = torch.zeros(groups, rounds, _lib.TRACE_COUNTERS, device=dev, dtype=torch.int32) if need_cnt else None
     if n > 0:
         om = object_mask.to(torch.uint8).contiguous()
         per = -(-n // groups)
@@ -401,13 +439,13 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
                     """call once the enqueued prefix has completed: None if it was the whole trace, else the remaining
                     rounds are run (same streams, same workspaces) and the refreshed (points, hit, dists) returned"""
                     host = counters.cpu()
-                    again = [g for g in everyone if guess < rounds and int(host[g, guess - 1, :3].sum()) > 0]
+                    again = [g for g in everyone if guess < rounds and int(host[g, guess - 1, _WORK].sum()) > 0]
                     if again:
                         run(again, guess, 0)
                         for st in streams:
                             st.synchronize()
                         host = counters.cpu()
-                    busy = torch.nonzero(host[:, :, :3].sum(dim=(0, 2))).flatten()
+                    busy = torch.nonzero(host[:, :, _WORK].sum(dim=(0, 2))).flatten()
                     rounds_state.guess = (int(busy[-1]) if busy.numel() else 0) + 3
                     return (pts, hit.bool(), dist) if again else None
                 deferred.append(check)
@@ -416,12 +454,12 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
                 return pts, hit.bool(), dist
             host = counters.cpu()                            # the one host sync (the caller syncs next anyway)
             if guess < rounds:
-                again = [g for g in everyone if int(host[g, guess - 1, :3].sum()) > 0]
+                again = [g for g in everyone if int(host[g, guess - 1, _WORK].sum()) > 0]
                 if again:
                     run(again, guess, 0)
                     join()
                     host = counters.cpu()
-            busy = torch.nonzero(host[:, :, :3].sum(dim=(0, 2))).flatten()
+            busy = torch.nonzero(host[:, :, _WORK].sum(dim=(0, 2))).flatten()
             last = int(busy[-1]) if busy.numel() else 0
             rounds_state.guess = last + 3                    # last emitting round + its consumer + one spare
     if want_counters:

@@ -133,6 +133,8 @@ class Renderer:
 
     # -- forward_with_uv ------------------------------------------------------------------------
     def forward(self, inp, minsdf_steps=None, uniforms=None, minsdf_steps2=None):
+        """uniforms: the sampler's 7 draws per HIT ray [N_hit, 7] as the reference makes them, or per ray [N_ray, 7]
+        (rows of rays that miss are ignored) for callers that fix the draws before knowing which rays hit."""
         uv = inp['uv']
         object_mask = inp['object_mask'].reshape(-1)
         multi = uv.dim() == 4
@@ -157,6 +159,8 @@ class Renderer:
         ret = {}
         if hit.any():
             idx = torch.nonzero(hit).flatten()
+            if uniforms is not None and uniforms.shape[0] == hit.shape[0]:
+                uniforms = uniforms[hit]
             ret = self.shade(pts[hit], -d[hit], uniforms, minsdf_steps2)
             put = lambda dst, src: dst.index_put((idx,), src.expand(idx.shape[0], dst.shape[1]))
             out['idr_rgb_values'] = put(out['idr_rgb_values'], ret['idr_rgb'])
@@ -177,6 +181,7 @@ class Renderer:
                     'secondary_points': ret.get('secondary_points'), 'secondary_mask': ret.get('secondary_mask'),
                     'secondary_dir': ret.get('secondary_dir')})
         out['_minsdf_steps'] = tr['minsdf_steps']
+        out['_ray_hit'] = hit            # per-RAY mask (network_object_mask becomes the per-pixel `all` below)
         out['_uniforms'] = ret.get('_uniforms')
         out['_minsdf_steps2'] = ret.get('_minsdf_steps2')
         if multi:

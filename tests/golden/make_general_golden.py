@@ -42,6 +42,28 @@ def main():
             out['%s_order_w%d' % (tag, world)] = np.array(order)
             for rank in range(world):
                 out['%s_scatter_w%d_r%d' % (tag, world, rank)] = np.array(ref.scatter_list(order, len(order), rank, world))
+    # BASELINE config 5 (robot/render.sh: 800 x 800 frame, num_rays 256, memory_capacity_level 18) at W = 1, 2, 8 ranks:
+    # chunk sizes of split_input at level 18 - floor(log2 W) (render.py:284-286), the round-robin order and every rank's
+    # slice of it (:289-295).  The uv tensor carries no ray dimension here (split_input only indexes pixels; the chunk
+    # size comes from its n_rays argument) - 640 000 x 256 x 2 floats would be 1.3 GB.
+    total, num_rays, level = 800 * 800, 256, 18
+    uv = torch.zeros(1, total, 2)
+    uv[0, :, 0] = torch.arange(total)
+    inp = {'uv': uv, 'object_mask': torch.ones(1, total, dtype=torch.bool)}
+    for world in (1, 2, 8):
+        lv = level - int(np.floor(np.log2(world)))
+        split = ref.split_input(inp, total, num_rays, lv)
+        sizes = np.array([s['uv'].shape[1] for s in split])
+        first = np.array([int(s['uv'][0, 0, 0]) for s in split])
+        out['cfg5_w%d_sizes' % world] = sizes.astype(np.int32)
+        out['cfg5_w%d_first_pixel' % world] = first.astype(np.int32)
+        order = []
+        for i in range(world):
+            order += list(range(len(split)))[i:len(split):world]
+        out['cfg5_w%d_order' % world] = np.array(order, dtype=np.int32)
+        parts = [ref.scatter_list(order, len(order), rank, world) for rank in range(world)]
+        out['cfg5_w%d_scatter_lens' % world] = np.array([len(p) for p in parts], dtype=np.int32)
+        out['cfg5_w%d_scatter' % world] = np.concatenate([np.array(p, dtype=np.int32) for p in parts])
     np.savez_compressed(os.path.join(HERE, 'general_ref.npz'), **out)
     print(len(out), 'arrays')
 

@@ -217,9 +217,15 @@ def golden_tracer():
 def run_forward(m, inp, train, seed):
     m.train(train)
     ctx = contextlib.nullcontext() if train else torch.no_grad()
-    with ctx, Capture() as cap:
-        torch.manual_seed(seed)
-        out = m(inp)
+    traces = []      # (points, hit mask, dists) of every RayTracing.forward call: [0] primary rays, [1] secondary rays
+    hook = m.ray_tracer.register_forward_hook(lambda mod, args, res: traces.append([t.detach().clone() for t in res]))
+    try:
+        with ctx, Capture() as cap:
+            torch.manual_seed(seed)
+            out = m(inp)
+    finally:
+        hook.remove()
+    cap.ray_hit = traces[0][1] if traces else None      # per-RAY hit mask (the output dict only has the per-pixel `all`)
     return out, cap
 
 
@@ -235,6 +241,7 @@ def golden_forward_and_step():
         for mode in ('train', 'eval'):
             out, cap = run_forward(m, inp, mode == 'train', 31)
             rec = {k: v for k, v in out.items() if v is not None}
+            rec['ray_hit'] = cap.ray_hit
             if mode == 'train':
                 assert len(cap.unif_pre) <= 1 and len(cap.unif_post) <= 1
                 if cap.unif_pre:
@@ -274,10 +281,55 @@ def golden_forward_and_step():
                  minsdf_steps2=(cap.unif[0] if cap.unif else torch.zeros(0)))
 
 
+def golden_forward_full_width():
+    """IDRNetwork.forward + IDRLoss + backward at the confs' FULL network widths (conf.conf: 8x512 SDF with the 512-wide
+    feature vector, 8x512 material, 4x512 radiance; conf_neus.conf: 8x256, d_out 257) on the non-convex stand-in scene of
+    configs 3-5 (synthetic.make_state_dict(scene='bowl')), multi-ray pixels through the workload's own camera: pins the
+    512-/256-wide path to the reference directly (the hidden-64 fixtures above pin the logic)."""
+    for tag, wl, npx, nr in [('conf512', 'cfg3', 32, 4), ('neus256', 'cfg4', 32, 4)]:
+        w = syn.WORKLOADS[wl]
+        mc, sd = syn.workload_state_dict(wl, seed=0)
+        lc = syn.loss_conf(w['model'])
+        m = build_ref(mc, sd)
+        inp, gt = syn.make_inputs(npx, w['image_hw'], w['focal'], w['cam_pos'], nr, seed=9)
+        out, cap = run_forward(m, inp, True, 41)
+        rec = {k: v for k, v in out.items() if v is not None}
+        rec['ray_hit'] = cap.ray_hit
+        assert len(cap.unif_pre) <= 1 and len(cap.unif_post) <= 1 and len(cap.rand) == 7
+        if cap.unif_pre:
+            rec['minsdf_steps'] = cap.unif_pre[0]
+        if cap.unif_post:
+            rec['minsdf_steps2'] = cap.unif_post[0]
+        rec['uniforms'] = torch.cat([r.reshape(-1, 1) for r in cap.rand], dim=1)
+        with contextlib.redirect_stdout(io.StringIO()):
+            lossf = IDRLoss(**lc)
+        lo = lossf(out, {'rgb': gt})
+        m.zero_grad()
+        lo['loss'].backward()
+        for k, v in lo.items():
+            rec['loss.' + k] = v
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                rec['gnorm.' + k] = p.grad.norm()
+                if p.numel() <= 4096:
+                    rec['grad.' + k] = p.grad.clone()
+        assert rec['secondary_mask'].float().mean() > 0.2          # the indirect branch is exercised
+        save('forward_%s_train' % tag, uv=inp['uv'], pose=inp['pose'], intrinsics=inp['intrinsics'],
+             in_object_mask=inp['object_mask'], rgb_gt=gt, **rec)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['full_width']:
+        golden_forward_full_width()
+        sys.exit(0)
+    if sys.argv[1:] == ['forward']:
+        golden_forward_and_step()
+        golden_forward_full_width()
+        sys.exit(0)
     golden_sg_math()
     golden_sg_render()
     golden_camera()
     golden_nets()
     golden_tracer()
     golden_forward_and_step()
+    golden_forward_full_width()

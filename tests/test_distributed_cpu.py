@@ -323,3 +323,34 @@ def test_train_step_collectives_do_not_depend_on_the_data(tmp_path):
     for k, v in model.state_dict().items():
         assert torch.allclose(got[k], v, atol=1e-6), k
     assert torch.equal(got['unused'], ref0['unused'])         # no gradient on any rank: untouched
+
+
+@pytest.mark.parametrize('world', [1, 2, 8])
+def test_config5_frame_plan_matches_the_reference(world):
+    """BASELINE config 5 at its real size (800 x 800 pixels, 256 rays per pixel, memory_capacity_level 18): the chunk
+    sizes, the round-robin order and every rank's slice equal what the reference's split_input / scatter_list produce
+    (tests/golden/make_general_golden.py ran them for W = 1, 2, 8)."""
+    import math
+    import numpy as np
+    w = syn.WORKLOADS['cfg5']
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'general_ref.npz')))
+    total = w['image_hw'][0] * w['image_hw'][1]
+    assert total == w['num_pixels']
+    level = w['memory_capacity_level'] - int(math.floor(math.log2(world)))
+    uv = torch.zeros(1, total, 2)
+    uv[0, :, 0] = torch.arange(total)
+    split = utils.split_input({'uv': uv, 'object_mask': torch.ones(1, total, dtype=torch.bool)}, total, w['num_rays'], level)
+    assert [s['uv'].shape[1] for s in split] == g['cfg5_w%d_sizes' % world].tolist()
+    assert [int(s['uv'][0, 0, 0]) for s in split] == g['cfg5_w%d_first_pixel' % world].tolist()
+    order, slices = R.plan_chunks(len(split), world)
+    assert order == g['cfg5_w%d_order' % world].tolist()
+    lens = g['cfg5_w%d_scatter_lens' % world].tolist()
+    assert [b - a for a, b in slices] == lens
+    flat = g['cfg5_w%d_scatter' % world].tolist()
+    off = 0
+    for rank, (a, b) in enumerate(slices):
+        assert order[a:b] == flat[off:off + lens[rank]]
+        off += lens[rank]
+    # every rank renders the same number of pixels of the frame (xGMI gather of equal-sized packed buffers)
+    px = [sum(split[c]['uv'].shape[1] for c in order[a:b]) for a, b in slices]
+    assert len(set(px)) == 1 and sum(px) == total

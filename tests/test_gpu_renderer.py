@@ -7,20 +7,13 @@ import numpy as np
 import pytest
 import torch
 
-from nefii_amd import conf, synthetic as syn
+from nefii_amd import conf, ops, synthetic as syn
 from oracle import nets, renderer as orr
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
-FLOAT_KEYS = ['points', 'idr_rgb_values', 'sg_rgb_values', 'normal_values', 'sdf_output', 'sg_diffuse_rgb_values',
-              'sg_diffuse_albedo_values', 'sg_specular_rgb_values', 'sg_roughness_values',
-              'sg_specular_reflection_values']
-
-
-def rel_l2(a, b):
-    a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+from parity import FLOAT_KEYS, compare_outputs, rel_l2  # noqa: E402  (tests/parity.py)
 
 
 def build_model(mc, sd, training=True):
@@ -35,43 +28,6 @@ def build_model(mc, sd, training=True):
 
 def to_dev(inp):
     return {k: v.to(DEV) for k, v in inp.items()}
-
-
-def trimmed_rel_l2(a, b, drop_frac):
-    """relative L2 after dropping the `drop_frac` pixels with the largest error (MC shading: a sampled direction is
-    a discontinuous function of the hit point - a lobe pick flipping at a CDF boundary changes one pixel by O(1))."""
-    a, b = a.detach().float().cpu(), b.detach().float().cpu()
-    err = (a - b).reshape(a.shape[0], -1).norm(dim=1)
-    k = int(drop_frac * err.numel())
-    keep = torch.argsort(err)[:err.numel() - k] if k > 0 else torch.arange(err.numel())
-    return ((a[keep] - b[keep]).norm() / (b[keep].norm() + 1e-12)).item()
-
-
-def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', mc_outlier_frac=0.0):
-    net, rnet = out['network_object_mask'].cpu(), ref['network_object_mask']
-    flips = (net != rnet).sum().item()
-    assert flips <= max_flips, (what, 'mask flips', flips)
-    assert torch.equal(out['object_mask'].cpu(), ref['object_mask'])
-    agree = net == rnet
-    for k in FLOAT_KEYS:
-        a, b = out[k].detach().cpu()[agree], ref[k][agree]
-        if k in ('points', 'sdf_output'):
-            # rays that miss take the argmin of 100 samples (flat minimum: the winner flips on rounding noise);
-            # compare them on hit rays only, misses through sdf_output (the value reached) with a loose bound
-            h = rnet[agree]
-            if k == 'points':
-                assert rel_l2(a[h], b[h]) < 1e-4, (what, k, rel_l2(a[h], b[h]))
-            else:      # |sdf| <= 5e-5 on the surface: absolute comparison
-                assert (a[h] - b[h]).abs().max().item() < 2e-4, (what, k)
-                assert (a[h] - b[h]).abs().median().item() < 2e-6, (what, k)
-            if k == 'sdf_output' and (~h).any():
-                assert (a[~h] - b[~h]).abs().max().item() < 5e-3, (what, k)
-                assert ((a[~h] - b[~h]).abs() < 2e-5).float().mean().item() > 0.9, (what, k)
-            continue
-        if mc_outlier_frac > 0 and k in ('sg_rgb_values', 'sg_diffuse_rgb_values', 'sg_specular_rgb_values'):
-            assert trimmed_rel_l2(a, b, mc_outlier_frac) < tol_rgb, (what, k, trimmed_rel_l2(a, b, mc_outlier_frac))
-        else:
-            assert rel_l2(a, b) < tol_rgb, (what, k, rel_l2(a, b))
 
 
 @pytest.mark.parametrize('mode', ['train', 'eval'])
@@ -138,7 +94,7 @@ def test_train_step_full_size_vs_oracle(wl):
             assert rel_l2(p.grad, sdo[name].grad) < 2e-2, (name, rel_l2(p.grad, sdo[name].grad))
     # the tracer's query counters equal the oracle's SDF evaluation counts (exact algorithmic work, no padding)
     cnt = m.ray_tracer.last_counters.cpu().long()
-    gpu_evals = (cnt[:, 0] + cnt[:, 1] * 100 + cnt[:, 3]).sum().item()     # algorithmic (header: counters)
+    gpu_evals = ops.algorithmic_evals(cnt, 100).sum().item()     # algorithmic (header: counters)
     c = R.counters
     cpu_evals = sum(c.get(k, 0) for k in ('sphere_trace', 'sampler', 'bisect', 'min_sdf'))
     assert abs(gpu_evals - cpu_evals) <= 0.01 * cpu_evals, (gpu_evals, cpu_evals)
@@ -206,14 +162,22 @@ def test_trainable_geometry_is_refused():
         m(to_dev(inp))
 
 
-@pytest.mark.parametrize('name', ['conf', 'neus'])
-@pytest.mark.parametrize('mode', ['train', 'eval'])
+@pytest.mark.parametrize('name,mode', [('conf', 'train'), ('conf', 'eval'), ('neus', 'train'), ('neus', 'eval'),
+                                       ('conf512', 'train'), ('neus256', 'train')])
 def test_forward_indirect_golden(golden, name, mode):
     """conf.conf / conf_neus.conf models: MIS sampling + secondary trace + indirect radiance + MC shading,
-    replaying the reference's captured random draws."""
+    replaying the reference's captured random draws.  conf512 / neus256: the confs' FULL network widths on the
+    non-convex stand-in scene of configs 3-5 through the workload's camera (59 % of the secondary rays re-hit) - the
+    512- / 256-wide kernels against the reference itself, not only against the oracle."""
     g = golden('forward_%s_%s' % (name, mode))
-    mc = syn.model_conf(name, hidden=64)
-    sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+    if name in ('conf512', 'neus256'):
+        wl = {'conf512': 'cfg3', 'neus256': 'cfg4'}[name]
+        mc, sd = syn.workload_state_dict(wl, seed=0)
+        lc = syn.loss_conf(syn.WORKLOADS[wl]['model'])
+    else:
+        mc = syn.model_conf(name, hidden=64)
+        sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+        lc = syn.loss_conf(name)
     m = build_model(mc, sd, mode == 'train')
     d = torch.rand(100)
     m.ray_tracer.minsdf_steps_override = [g.get('minsdf_steps', d), g.get('minsdf_steps2', d)]
@@ -222,12 +186,14 @@ def test_forward_indirect_golden(golden, name, mode):
     ctx = torch.enable_grad() if mode == 'train' else torch.no_grad()
     with ctx:
         out = m(inp)
-    compare_outputs(out, g, what=(name, mode), mc_outlier_frac=0.03)
+    nr = g['uv'].shape[2] if g['uv'].dim() == 4 else 1
+    compare_outputs(out, g, what='%s-%s golden' % (name, mode), rays_per_pixel=nr, ray_hit=m.last_ray_hit,
+                    ref_ray_hit=g['ray_hit'], max_explained_frac=0.10)
     sm, rsm = out['secondary_mask'].cpu(), g['secondary_mask']
     assert (sm != rsm).float().mean().item() < 0.01
     if mode == 'train':
         from nefii_amd.model.loss import IDRLoss
-        lo = IDRLoss(**syn.loss_conf(name))(out, {'rgb': g['rgb_gt'].to(DEV)})
+        lo = IDRLoss(**lc)(out, {'rgb': g['rgb_gt'].to(DEV)})
         for k in ('loss', 'idr_rgb_loss', 'sg_rgb_loss', 'mask_loss', 'normalsmooth_loss', 'background_rgb_loss'):
             assert abs(lo[k].item() - g['loss.' + k].item()) <= 3e-3 * abs(g['loss.' + k].item()) + 1e-6, k
         lo['loss'].backward()
@@ -274,7 +240,8 @@ def test_forward_full_size_conf_vs_oracle():
     m.uniforms_override = uniforms
     with torch.no_grad():
         out = m(to_dev(inp))
-    compare_outputs(out, ref, max_flips=2, what='conf512', mc_outlier_frac=0.03)
+    compare_outputs(out, ref, max_flips=2, what='conf512 bumpy', rays_per_pixel=4, ray_hit=m.last_ray_hit,
+                    ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.10)
     assert (out['secondary_mask'].cpu() != ref['secondary_mask']).float().mean().item() < 0.01
     assert ref['secondary_mask'].float().mean().item() > 0.01      # the indirect branch is exercised
 

@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     # nefii_layer: 4 x int32 + 4 pointers; nefii_mlp: 8 x int32 + 12 layers
     assert ctypes.sizeof(_lib.Layer) == 16 + 5 * 8
     assert ctypes.sizeof(_lib.Mlp) == 40 + 12 * ctypes.sizeof(_lib.Layer)
-    assert ctypes.sizeof(_lib.TracerParams) == 40
+    assert ctypes.sizeof(_lib.TracerParams) == 48         # 3 floats + 7 int32 + coarse_tau + coarse_cap
 
 
 def test_host_side_argument_checks_need_no_gpu():
@@ -43,6 +43,11 @@ def test_host_side_argument_checks_need_no_gpu():
     assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 11 + 1 + 2    # bisection: 3 levels per round
     p.bisect_levels = 5
     assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2
+    w0 = lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p))
+    p.coarse_tau = 2e-3          # coarse pass: one more round per dense search, a refine list of coarse_cap entries per ray
+    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2 + 2
+    assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) >= w0 + 4096 * 24 * 4
+    p.coarse_tau = 0.0
     assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) > 4096 * 100 * 4
     assert lib.nefii_trace_rays(None, None, None, None, None, 0, None, None, None, None, None, None, 0, None, None) == -1
     assert lib.nefii_trace_rays_rounds(None, None, None, None, None, 0, None, None, None, None, None, None, 0, None, 0, 0,
@@ -71,9 +76,13 @@ def test_sdf_stream_size():
     # 512-wide: 16-deep k-steps (either layout); 256-wide: 32-deep k-steps of K padded to 128, 16x16x32 layout only
     for name, hidden, layout, want in [('physg', 512, 0, 8 * (4 + 32 * 3 + 36 + 32 * 3) * 4096),
                                        # 16x16x32 layout: + the K-padded copy of the deep-prefetch 32-query instance
-                                       ('physg', 512, 1, 8 * ((4 + 32 * 3 + 36 + 32 * 3) + (8 + 32 * 3 + 40 + 32 * 3)) * 4096),
+                                       # + the single-pass (coarse) copy: hi fragments only, one 32-deep k-step of the
+                                       # wave's 4 (2) feature tiles per 4 KiB (2 KiB) unit, K padded to 128
+                                       ('physg', 512, 1, 8 * ((4 + 32 * 3 + 36 + 32 * 3) + (8 + 32 * 3 + 40 + 32 * 3)) * 4096
+                                        + 8 * (4 + 16 * 3 + 20 + 16 * 3) * 4096),
                                        ('physg', 64, 1, 0),
-                                       ('neus', None, 0, 0), ('neus', None, 1, 8 * (4 + 8 * 3 + 12 + 8 * 3) * 4096)]:
+                                       ('neus', None, 0, 0),
+                                       ('neus', None, 1, 8 * (4 + 8 * 3 + 12 + 8 * 3) * 4096 + 8 * (4 + 8 * 3 + 12 + 8 * 3) * 2048)]:
         mc = syn.model_conf(name, hidden=hidden)
         specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
         m = _lib.Mlp()

@@ -119,12 +119,21 @@ FWD_KEYS = ['points', 'idr_rgb_values', 'sg_rgb_values', 'normal_values', 'sdf_o
             'sg_specular_reflection_values']
 
 
-@pytest.mark.parametrize('name', ['physg', 'conf', 'neus'])
-@pytest.mark.parametrize('mode', ['train', 'eval'])
+def forward_case(tag):
+    """(fixture name, model conf, state dict, loss conf) of a forward_* fixture (tests/golden/make_golden.py)."""
+    if tag in ('conf512', 'neus256'):       # the confs' full widths on the non-convex stand-in scene of configs 3-5
+        wl = {'conf512': 'cfg3', 'neus256': 'cfg4'}[tag]
+        mc, sd = syn.workload_state_dict(wl, seed=0)
+        return mc, sd, syn.loss_conf(syn.WORKLOADS[wl]['model'])
+    mc = syn.model_conf(tag, hidden=64)
+    return mc, syn.make_state_dict(mc, seed=0, bumpy=0.02), syn.loss_conf(tag)
+
+
+@pytest.mark.parametrize('name,mode', [('physg', 'train'), ('physg', 'eval'), ('conf', 'train'), ('conf', 'eval'),
+                                       ('neus', 'train'), ('neus', 'eval'), ('conf512', 'train'), ('neus256', 'train')])
 def test_forward_and_step(golden, name, mode):
     g = golden('forward_%s_%s' % (name, mode))
-    mc = syn.model_conf(name, hidden=64)
-    sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+    mc, sd, lc = forward_case(name)
     trainable = [k for k in sd if not k.startswith('implicit') and not (
         k.endswith('specular_reflectance') and mc['envmap_material_network'].get('fix_specular_albedo'))]
     for k in trainable:
@@ -136,6 +145,7 @@ def test_forward_and_step(golden, name, mode):
         out = R.forward(inp, g.get('minsdf_steps'), g.get('uniforms'), g.get('minsdf_steps2'))
     assert torch.equal(out['network_object_mask'], g['network_object_mask'])
     assert torch.equal(out['object_mask'], g['object_mask'])
+    assert torch.equal(out['_ray_hit'], g['ray_hit'])
     for k in FWD_KEYS:
         tol = 2e-3 if k in ('points', 'sdf_output') else 2e-3
         assert rel_l2(out[k], g[k]) < tol, (k, rel_l2(out[k], g[k]))
@@ -146,7 +156,7 @@ def test_forward_and_step(golden, name, mode):
         assert torch.equal(out['secondary_mask'], g['secondary_mask'])
         assert (out['secondary_points'] - g['secondary_points']).abs().max() < 1e-4
     if mode == 'train':
-        lo = renderer.idr_loss(out, g['rgb_gt'], syn.loss_conf(name))
+        lo = renderer.idr_loss(out, g['rgb_gt'], lc)
         for k in ('loss', 'idr_rgb_loss', 'sg_rgb_loss', 'mask_loss', 'normalsmooth_loss', 'background_rgb_loss'):
             assert abs(lo[k].item() - g['loss.' + k].item()) <= 1e-3 * abs(g['loss.' + k].item()) + 1e-6, k
         lo['loss'].backward()
