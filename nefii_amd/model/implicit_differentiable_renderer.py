@@ -13,7 +13,8 @@ fallback; ops raise without the library).  torch is used for parameter storage, 
 reparameterisation (tiny [out,in] tensors), masking/scatter glue and autograd bookkeeping.
 
 Scope: Step-2 with frozen geometry (``freeze_geometry()``; every shipped Step-2 script passes
---freeze_geometry).  The trainable-geometry branch (:357-393, SampleNetwork) raises NotImplementedError.
+--freeze_geometry) on the kernels.  The trainable-geometry branch (:357-393, SampleNetwork) exists as a torch slow path
+for the closed-form ``sg`` render type (model/trainable_geometry.py).
 """
 import math
 
@@ -285,6 +286,10 @@ class IDRNetwork(nn.Module):
 
     # ---- forward_with_uv (:312-501) ------------------------------------------------------------------
     def forward_with_uv(self, input):
+        if self.training and not self.state_freeze_geo:
+            # trainable geometry (:357-393, SampleNetwork): torch slow path, closed-form shading only
+            from . import trainable_geometry
+            return trainable_geometry.forward_with_uv(self, input)
         ctx = self.trace_head(input)
         idx = torch.nonzero(ctx['network_object_mask']).flatten()          # one host sync per call (compaction size)
         return self.shade_tail(ctx, idx)
@@ -297,8 +302,8 @@ class IDRNetwork(nn.Module):
     def trace_points(self, input):
         """trace_head without the SDF value / feature / gradient pass at the traced points (attach_surface)."""
         if self.training and not self.state_freeze_geo:
-            raise NotImplementedError('training with trainable geometry is outside the Step-2 hot path; '
-                                      'call freeze_geometry()')
+            raise NotImplementedError('the kernel path needs frozen geometry (freeze_geometry()); forward() routes '
+                                      'trainable geometry to model/trainable_geometry.py')
         intrinsics = input['intrinsics']
         uv = input['uv']
         pose = input['pose']

@@ -1,8 +1,8 @@
-"""SampleNetwork placeholder (reference code/model/sample_network.py:10-24).
+"""SampleNetwork (reference code/model/sample_network.py:10-24): the ray / surface intersection as a differentiable
+function of the implicit geometry (IDR, equation 3):  x(theta) = c + (t - (f(x; theta) - f0) / (grad f . d)) d.
 
-IDR's differentiable hit-point reparameterisation is only used when geometry is trainable, which no shipped
-Step-2 script does (--freeze_geometry); SURVEY.md section 8a row S1 marks it inactive.  Kept as a tiny torch module so
-the attribute exists; it is never on the hot path."""
+Used by the trainable-geometry branch only (model/trainable_geometry.py) - a torch slow path:
+every shipped Step-2 script freezes the geometry, where the hit point is a constant."""
 import torch
 import torch.nn as nn
 

@@ -59,11 +59,12 @@ class Capture:
         torch.rand, torch.Tensor.uniform_ = self._rand, self._unif
 
 
-def build_ref(model_cfg, sd):
+def build_ref(model_cfg, sd, freeze=True):
     with contextlib.redirect_stdout(io.StringIO()):
         m = IDRNetwork(ref_shim.Conf(model_cfg))
     m.load_state_dict(sd, strict=True)
-    m.freeze_geometry()
+    if freeze:
+        m.freeze_geometry()
     return m
 
 
@@ -318,7 +319,43 @@ def golden_forward_full_width():
              in_object_mask=inp['object_mask'], rgb_gt=gt, **rec)
 
 
+def golden_trainable_geometry():
+    """forward_with_uv with geometry NOT frozen (implicit_differentiable_renderer.py:357-393: SampleNetwork, eikonal
+    points, grad_theta) + IDRLoss (eikonal term included) + backward into every parameter, the SDF network's too."""
+    for tag, nr in [('physg', -1), ('physg_multi', 2)]:
+        mc = syn.model_conf('physg', hidden=64)
+        sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+        lc = syn.loss_conf('physg')
+        lc['idr_rgb_weight'] = 1.0
+        m = build_ref(mc, sd, freeze=False)
+        inp, gt = syn.make_inputs(128 if nr < 0 else 64, image_hw=(64, 64), focal=100.0, cam_pos=(0.2, 0.1, 2.0),
+                                  num_rays=nr, seed=6, mask_all=False)
+        out, cap = run_forward(m, inp, True, 43)
+        assert out['grad_theta'] is not None and len(cap.unif) == 2        # min-SDF steps, eikonal points
+        rec = {k: v for k, v in out.items() if v is not None}
+        rec['ray_hit'] = cap.ray_hit
+        rec['minsdf_steps'], rec['eikonal_points'] = cap.unif[0], cap.unif[1]
+        with contextlib.redirect_stdout(io.StringIO()):
+            lossf = IDRLoss(**lc)
+        lo = lossf(out, {'rgb': gt})
+        m.zero_grad()
+        lo['loss'].backward()
+        for k, v in lo.items():
+            rec['loss.' + k] = v
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                rec['gnorm.' + k] = p.grad.norm()
+                if p.numel() <= 4096:
+                    rec['grad.' + k] = p.grad.clone()
+        assert any(k.startswith('gnorm.implicit_network') and v > 0 for k, v in rec.items())
+        save('forward_trainable_%s' % tag, uv=inp['uv'], pose=inp['pose'], intrinsics=inp['intrinsics'],
+             in_object_mask=inp['object_mask'], rgb_gt=gt, **rec)
+
+
 if __name__ == '__main__':
+    if sys.argv[1:] == ['trainable']:
+        golden_trainable_geometry()
+        sys.exit(0)
     if sys.argv[1:] == ['full_width']:
         golden_forward_full_width()
         sys.exit(0)
@@ -333,3 +370,4 @@ if __name__ == '__main__':
     golden_tracer()
     golden_forward_and_step()
     golden_forward_full_width()
+    golden_trainable_geometry()

@@ -151,15 +151,65 @@ def test_state_dict_roundtrip_and_eval_mode():
         assert torch.equal(o1[k], o2[k]), k      # deterministic (no atomics on the forward path)
 
 
-def test_trainable_geometry_is_refused():
+@pytest.mark.parametrize('tag', ['physg', 'physg_multi'])
+def test_trainable_geometry_golden(golden, tag):
+    """geometry NOT frozen (implicit_differentiable_renderer.py:357-393, SampleNetwork,
+    eikonal points, grad_theta) - HIP camera rays and tracer in front of the torch slow path
+    (model/trainable_geometry.py) - against the reference-generated fixture: outputs, every loss term incl. the eikonal
+    one, and the gradient of every parameter, the SDF network's included; then one TrainStep moves the SDF weights."""
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from nefii_amd.model.loss import IDRLoss
+    from nefii_amd.training.step import TrainStep
+    g = golden('forward_trainable_' + tag)
     mc = syn.model_conf('physg', hidden=64)
-    sd = syn.make_state_dict(mc, seed=5)
-    m = build_model(mc, sd, True)
-    m.unfreeze_geometry()
-    m.train()
-    inp, _ = syn.make_inputs(16, (64, 64), 100.0, (0.2, 0.1, 2.0), -1, seed=2)
+    sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+    m = IDRNetwork(conf.from_dict(mc))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).train()
+    m.ray_tracer.minsdf_steps_override = g['minsdf_steps']
+    m.eikonal_points_override = g['eikonal_points']
+    inp = to_dev({'uv': g['uv'], 'pose': g['pose'], 'intrinsics': g['intrinsics'], 'object_mask': g['in_object_mask']})
+    out = m(inp)
+    flips = (out['network_object_mask'].cpu() != g['network_object_mask']).sum().item()
+    assert flips <= 1, flips
+    agree = out['network_object_mask'].cpu() == g['network_object_mask']
+    hit = g['network_object_mask'] & agree
+    for k in FLOAT_KEYS:
+        a, b = out[k].detach().cpu(), g[k]
+        sel = hit if k in ('points', 'sdf_output') else agree
+        tol = 2e-4 if k == 'points' else (5e-2 if k == 'sdf_output' else 1e-3)
+        if k == 'sdf_output':
+            assert (a[sel] - b[sel]).abs().max().item() < 2e-4
+        else:
+            assert rel_l2(a[sel], b[sel]) < tol, (tag, k, rel_l2(a[sel], b[sel]))
+    n_eik = g['eikonal_points'].shape[0]
+    assert rel_l2(out['grad_theta'][:n_eik], g['grad_theta'][:n_eik]) < 1e-4
+    lc = syn.loss_conf('physg')
+    lc['idr_rgb_weight'] = 1.0
+    lo = IDRLoss(**lc)(out, {'rgb': g['rgb_gt'].to(DEV)})
+    for k in ('loss', 'idr_rgb_loss', 'sg_rgb_loss', 'eikonal_loss', 'mask_loss', 'normalsmooth_loss'):
+        assert abs(lo[k].item() - g['loss.' + k].item()) <= 5e-3 * abs(g['loss.' + k].item()) + 1e-6, k
+    lo['loss'].backward()
+    sdf_grads = 0
+    for name, p in m.named_parameters():
+        key = 'gnorm.' + name
+        if key in g and g[key].item() > 0:
+            assert p.grad is not None, name
+            assert abs(p.grad.norm().item() - g[key].item()) <= 3e-2 * g[key].item() + 1e-7, name
+            if 'grad.' + name in g:
+                assert rel_l2(p.grad, g['grad.' + name]) < 3e-2, (name, rel_l2(p.grad, g['grad.' + name]))
+            sdf_grads += name.startswith('implicit_network')
+    assert sdf_grads >= 20
+    # the whole step with trainable geometry: the SDF network is in the idr optimizer (idr_train.py:188-191) and moves
+    before = {k: v.detach().clone() for k, v in m.implicit_network.state_dict().items()}
+    st = TrainStep(m, lc)
+    _, lo2 = st(inp, {'rgb': g['rgb_gt'].to(DEV)})
+    assert all(torch.isfinite(v).all() for v in m.state_dict().values() if v.dtype.is_floating_point)
+    assert any(not torch.equal(before[k], v) for k, v in m.implicit_network.state_dict().items())
+    # Monte-Carlo shading has no input-differentiable form here: refused, loudly
+    m2 = IDRNetwork(conf.from_dict(syn.model_conf('conf', hidden=64))).to(DEV).train()
     with pytest.raises(NotImplementedError):
-        m(to_dev(inp))
+        m2(inp)
 
 
 @pytest.mark.parametrize('name,mode', [('conf', 'train'), ('conf', 'eval'), ('neus', 'train'), ('neus', 'eval'),

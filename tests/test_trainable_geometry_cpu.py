@@ -1,0 +1,73 @@
+"""the trainable-geometry branch (torch slow path, nefii_amd/model/trainable_geometry.py)
+against the reference-generated fixture - on the CPU, with the two HIP stages in front of it (camera rays, sphere
+tracer) replaced by the fixture's own rays and hit depths, so that every torch piece is checked here: SDF network,
+input gradient with create_graph, SampleNetwork, radiance / material MLPs, closed-form SG shading, IDRLoss incl. the
+eikonal term, and the gradient of every parameter (the SDF network's included).  The GPU suite runs the same fixtures
+through the real tracer (tests/test_gpu_renderer.py::test_trainable_geometry_golden)."""
+import pytest
+import torch
+
+from nefii_amd import conf, synthetic as syn
+from oracle import renderer as orr
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float(), b.detach().float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def test_trainable_geometry_branch_matches_the_reference(golden, monkeypatch):
+    from nefii_amd.model import trainable_geometry as tg
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from nefii_amd.model.loss import IDRLoss
+    from nefii_amd.utils import rend_util
+    g = golden('forward_trainable_physg')
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+    m = IDRNetwork(conf.from_dict(mc))
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    assert not m.state_freeze_geo
+    inp = {'uv': g['uv'], 'pose': g['pose'], 'intrinsics': g['intrinsics'], 'object_mask': g['in_object_mask']}
+    dirs, cam = orr.camera_rays(inp['uv'], inp['pose'], inp['intrinsics'])
+    monkeypatch.setattr(rend_util, 'get_camera_params', lambda uv, pose, K: (dirs, cam))
+    dists = ((g['points'] - cam) * dirs.reshape(-1, 3)).sum(-1)            # the reference's traced depths
+
+    class Tracer(torch.nn.Module):
+        def forward(self, sdf, cam_loc, object_mask, ray_directions):
+            return g['points'], g['ray_hit'], dists
+    m.ray_tracer = Tracer()
+    m.eikonal_points_override = g['eikonal_points']
+    out = m(inp)
+    assert torch.equal(out['network_object_mask'], g['network_object_mask'])
+    for k in ('points', 'sdf_output', 'idr_rgb_values', 'sg_rgb_values', 'normal_values', 'sg_diffuse_rgb_values',
+              'sg_diffuse_albedo_values', 'sg_specular_rgb_values', 'sg_roughness_values',
+              'sg_specular_reflection_values', 'grad_theta'):
+        assert rel_l2(out[k], g[k]) < (2e-3 if k == 'sdf_output' else 1e-3), (k, rel_l2(out[k], g[k]))
+    lc = syn.loss_conf('physg')
+    lc['idr_rgb_weight'] = 1.0
+    lo = IDRLoss(**lc)(out, {'rgb': g['rgb_gt']})
+    for k in ('loss', 'idr_rgb_loss', 'sg_rgb_loss', 'eikonal_loss', 'mask_loss', 'normalsmooth_loss'):
+        assert abs(lo[k].item() - g['loss.' + k].item()) <= 1e-3 * abs(g['loss.' + k].item()) + 1e-6, k
+    assert g['loss.eikonal_loss'].item() > 0
+    lo['loss'].backward()
+    seen = 0
+    for name, p in m.named_parameters():
+        key = 'gnorm.' + name
+        if key in g and g[key].item() > 0:
+            assert p.grad is not None, name
+            assert abs(p.grad.norm().item() - g[key].item()) <= 1e-2 * g[key].item() + 1e-7, name
+            if 'grad.' + name in g:
+                assert rel_l2(p.grad, g['grad.' + name]) < 1e-2, (name, rel_l2(p.grad, g['grad.' + name]))
+            seen += name.startswith('implicit_network')
+    assert seen >= 20          # the SDF network's weight_v / weight_g / bias all received the reference's gradients
+
+
+def test_trainable_geometry_refuses_monte_carlo_shading():
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    mc = syn.model_conf('conf', hidden=64)
+    m = IDRNetwork(conf.from_dict(mc))
+    m.train()
+    inp, _ = syn.make_inputs(16, (64, 64), 100.0, (0.2, 0.1, 2.0), -1, seed=2)
+    with pytest.raises(NotImplementedError):
+        m(inp)
