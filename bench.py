@@ -5,20 +5,30 @@
 
 Step = one full Step-2 iteration on a synthetic batch already resident in HBM: forward (camera rays, HIP
 sphere tracer, SDF value/normal, radiance + material MLPs, SG shading) + IDRLoss + backward + both Adam
-updates (idr_train.py:750-776).  N=1 workload = BASELINE.json configs[1]: "robot"-like scene, physg.conf
+updates (idr_train.py:750-776).  N=1 workload = BASELINE.json configs[1] ("cfg2"): "robot"-like scene, physg.conf
 model, num_pixels 4096, 128 SG lobes, indirect OFF.  N>1: every rank gets its own 4096-pixel slice of a
 4096*N-pixel global batch (the dataset's contiguous patch split) and gradients are averaged by one RCCL
 all-reduce per step: weak scaling, `value` = all ranks' primary rays / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  `roofline`: the SDF-evaluation kernel of the tracer (>90 % of the step),
-achieved = algorithmic FLOPs of all its launches (queries x 2 x MACs of the unpadded SDF MLP) / their summed
-duration, measured live with HIP events on the launch stream in an extra un-timed step; peak = dense f32
-MFMA (the kernel computes in exact fp32; see DESIGN.md for why 16-bit operands cannot be used in the tracer).
+Prints ONE JSON line (rank 0).  Beside the headline it carries, under "cfg3", the same measurement of BASELINE.json
+configs[2] (conf.conf model, 64 rays per pixel, MC direct + near-field indirect on the non-convex stand-in scene - what
+robot/run_s2.sh runs; it fills the chip where config 2 is launch-shaped) at min(K, 5) steps; --workload X measures X alone.
+
+`roofline` (recomputable from the numbers in the line): the tracer's SDF-evaluation kernels (eval_kernel16q: split
+precision, 3 fp16 MFMAs per product; eval_kernel16s: the single-pass coarse evaluator) against the dense fp16 MFMA peak
+(2.5 PFLOP/s, MI355X_MICROARCH.md) in ALGORITHMIC flops:
+  frac = frac_kernel = sdf_evals_per_step x flops_per_sdf_eval / kernel_ms_per_step / peak, the evaluations being what
+         the reference's recurrences execute (the min-SDF search included: it is executed, on these kernels), the time
+         measured live with HIP events on the launch stream over one extra un-timed step;
+  frac_step = SURVEY.md section 8(d)'s A x rays/s / peak: A excludes the min-SDF search (dead work under frozen
+         geometry), the speculative bisection nodes and the reference's repeated SDF passes, and includes the MLP and
+         shading work behind the tracer; its terms are listed under roofline.step_model.
 `cpu_baseline`: the CPU oracle (kind "port": a PyTorch-CPU restatement of the reference, pinned against the
 reference's own outputs) running the same step on a bounded sample of the same workload on the host cores.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -30,9 +40,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (never the 2:1-sparse figure)
+F_SG_SHADING = 0.2e6             # closed-form SG shading fwd+bwd per hit (M = 128)
+F_MC_SHADING = 0.1e6             #                         MC shading + samplers + pdfs fwd+bwd per hit
 
 
-def sdf_flops_per_eval(specs):
+def mlp_flops(specs):
     return sum(2 * s.k_in * s.n_out for s in specs)
 
 
@@ -110,50 +122,21 @@ def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
             a, b = out[k].cpu()[mask], ref[k][mask]
             mse = ((a - b) ** 2).mean().item()
             parity[name + '_rel_l2'] = ((a - b).norm() / (b.norm() + 1e-12)).item()
-            parity[name + '_psnr_db'] = float('inf') if mse == 0 else 20.0 * __import__('math').log10(1.0 / mse ** 0.5)
+            parity[name + '_psnr_db'] = float('inf') if mse == 0 else 20.0 * math.log10(1.0 / mse ** 0.5)
         parity['tolerance_rel_l2'] = 1e-3
     return res, parity
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='cfg2')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-side-measurement', action='store_true',
-                    help='skip the untimed side loop without the min-SDF search (profiling runs: every step of the process\n'
-                         'is then the headline step, so rocprofv3 per-kernel averages compare directly)')
-    ap.add_argument('--cpu-sample-pixels', type=int, default=512)
-    args = ap.parse_args()
-
-    rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d'
-                             % (args.gpus, args.gpus))
+def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side=True):
+    """Time `steps` training steps of WORKLOADS[name] (every rank), then measure the roofline terms in un-timed extra
+    steps.  Returns the result dict on rank 0, None elsewhere."""
+    import ctypes
     import torch.distributed as dist
-    # one process per GPU; NEFII_BENCH_BACKEND=gloo lets the multi-process path be smoke-tested on a 1-GPU box
-    backend = os.environ.get('NEFII_BENCH_BACKEND', 'nccl')
-    dev_index = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device('cuda', dev_index)
-    if world > 1:
-        if backend == 'nccl':
-            dist.init_process_group(backend='nccl', device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
-
-    from nefii_amd import _lib, conf, synthetic as syn
+    from nefii_amd import conf, ops, synthetic as syn
     from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
     from nefii_amd.training.step import TrainStep
-    import ctypes
-    lib = _lib.lib()
 
-    w = dict(syn.WORKLOADS[args.workload])
+    w = dict(syn.WORKLOADS[name])
     mc = syn.model_conf(w['model'])
     sd = syn.make_state_dict(mc, seed=0, scene=w.get('scene'))
     lc = syn.loss_conf(w['model'])
@@ -180,18 +163,18 @@ def main():
     nxt = inp if os.environ.get('NEFII_BENCH_PREFETCH', '1') != '0' else None
     if nxt is not None:         # batches known ahead of time (a dataloader's prefetch queue): 2 by default
         nxt = [inp] * max(1, int(os.environ.get('NEFII_BENCH_LOOKAHEAD', '2')))
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(inp, gt, nxt)
     # the graph of the step's tail is captured once per padded hit count, after 3 eager steps: with fewer warm-up steps
     # than that, run the missing ones (still untimed) so that no capture lands in the timed region
-    priming = max(0, step.graph_after + 1 - args.warmup) if use_graph else 0     # the same count on every rank
+    priming = max(0, step.graph_after + 1 - warmup) if use_graph else 0     # the same count on every rank
     for _ in range(priming):
         step(inp, gt, nxt)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out, lo = step(inp, gt, nxt)
     torch.cuda.synchronize()
     if world > 1:
@@ -201,30 +184,34 @@ def main():
         t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
-    ms_per_step = elapsed / args.steps * 1e3
-    value = rays_per_rank * world / (elapsed / args.steps)
+    ms_per_step = elapsed / steps * 1e3
+    value = rays_per_rank * world / (elapsed / steps)
 
-    # side measurement, NOT the headline: the same step without the min-SDF search that is dead work under frozen
-    # geometry (RayTracing.skip_min_sdf_search; same gradients, different mask_loss value)
+    # ---- un-timed side measurements (every rank runs the steps: they contain the gradient all-reduce)
+    # (1) the same step without the min-SDF search that is dead work under frozen geometry
+    #     (RayTracing.skip_min_sdf_search; same gradients, different mask_loss value), and its SDF-evaluation counters:
+    #     E_tr / E_tr2 of SURVEY.md section 8(d) (sphere tracing + bracket search + bisection, primary + secondary rays)
     ms_skip = None
-    if not args.no_side_measurement:
-        model.ray_tracer.skip_min_sdf_search = True
+    model.ray_tracer.skip_min_sdf_search = True
+    if side:
         for _ in range(3):
             step(inp, gt, nxt)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        for _ in range(max(args.steps // 2, 1)):
+        for _ in range(max(steps // 2, 1)):
             step(inp, gt, nxt)
         torch.cuda.synchronize()
-        ms_skip = (time.perf_counter() - t2) / max(args.steps // 2, 1) * 1e3
-        model.ray_tracer.skip_min_sdf_search = False
-        step(inp, gt)
-
-    # ---- roofline of the dominant kernel: one extra, un-timed step with per-launch HIP events.  Every rank runs the step
-    # (it contains the gradient all-reduce); only rank 0 instruments and reports it.
+        ms_skip = (time.perf_counter() - t2) / max(steps // 2, 1) * 1e3
     torch.cuda.synchronize()
     step._prefetch.clear()                  # traces enqueued ahead by the loops above: done, not needed
     model.ray_tracer.collect_counters = True
+    model.ray_tracer.counter_sum = None
+    step(inp, gt)
+    torch.cuda.synchronize()
+    cnt_live = model.ray_tracer.counter_sum.cpu().long()
+    model.ray_tracer.skip_min_sdf_search = False
+
+    # (2) roofline of the dominant kernel: one extra step with per-launch HIP events; only rank 0 instruments it
     model.ray_tracer.counter_sum = None
     model.ray_tracer.stream_groups = 1      # the profiled step runs the rounds back to back on one stream
     if nxt is not None and not model.ray_tracer.bisect_levels:
@@ -247,79 +234,164 @@ def main():
         dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
         param_spread = float((hi - lo_).item() / max(abs(hi.item()), 1e-30))
         dist.barrier()
-        dist.destroy_process_group()        # nothing below communicates (rank 0 alone runs the CPU baseline)
+    if rank != 0:
+        return None
 
-    result = None
-    if rank == 0:
-        eval_ms, n_eval, span_ms = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
-        lib.nefii_trace_profile_read(ctypes.byref(eval_ms), ctypes.byref(n_eval), ctypes.byref(span_ms))
-        lib.nefii_trace_profile_enable(0)
-        cnt = model.ray_tracer.counter_sum.cpu().long()       # primary + secondary traces of the step
-        n_steps = model.ray_tracer.n_steps
-        # algorithmic evaluations (what the reference's recurrences need) vs executed (incl. the unused nodes of
-        # the speculative 3-level bisection tree); the roofline credits only the algorithmic ones
-        from nefii_amd import ops as _ops
-        queries = int(_ops.algorithmic_evals(cnt, n_steps).sum().item())
-        nodes = 2 ** (model.ray_tracer.bisect_levels or (5 if rays_per_rank <= 16384 else 3)) - 1
-        ex_split, ex_coarse = _ops.executed_evals(cnt, n_steps, nodes)
-        executed, executed_coarse = int(ex_split.sum().item()), int(ex_coarse.sum().item())
-        launches = int((cnt[:, [0, 1, 2, 4, 5]].sum(dim=1) > 0).sum().item())
-        f_eval = sdf_flops_per_eval(model.implicit_network.specs)
-        achieved = queries * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
-        hit_frac = out['network_object_mask'].float().mean().item()
-        prec = model.ray_tracer.precision
-        split = prec.startswith('f16x3')
-        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        # HBM traffic of the same kernel from rocprofv3 PMC passes of this command (separate FETCH_SIZE / WRITE_SIZE runs,
-        # gfx950 correction applied by tools/pmc_traffic.py); only quoted for the workload/kernel it was measured on
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01', 'pmc_traffic_%s.json' % args.workload)
-        kname = {'f32': 'eval_kernel', 'f16x3': 'eval_kernel16', 'f16x3w': 'eval_kernel16w'}[model.ray_tracer.precision]
-        if prec == 'f16x3w' and model.implicit_network.packed(f16x3=True).w_stream is not None:
-            kname = 'eval_kernel16q' if model.implicit_network.packed(f16x3=True).struct.reserved == 1 else 'eval_kernel16p'
-            # 512-wide nets: the pipelined stream kernel (mlp_tile.h "16q": 16x16x32 MFMA; "16p": 32x32x16)
+    eval_ms, n_eval, span_ms = ctypes.c_double(), ctypes.c_int(), ctypes.c_double()
+    lib.nefii_trace_profile_read(ctypes.byref(eval_ms), ctypes.byref(n_eval), ctypes.byref(span_ms))
+    lib.nefii_trace_profile_enable(0)
+    cnt = model.ray_tracer.counter_sum.cpu().long()       # primary + secondary traces of the step
+    n_steps = model.ray_tracer.n_steps
+    # algorithmic evaluations (what the reference's recurrences need) vs executed (incl. the unused nodes of the
+    # speculative bisection tree and the coarse pass's refined samples); the roofline credits only the algorithmic ones
+    queries = int(ops.algorithmic_evals(cnt, n_steps).sum().item())
+    nodes = 2 ** (model.ray_tracer.bisect_levels or (5 if rays_per_rank <= 16384 else 3)) - 1
+    ex_split, ex_coarse = ops.executed_evals(cnt, n_steps, nodes)
+    executed, executed_coarse = int(ex_split.sum().item()), int(ex_coarse.sum().item())
+    launches = int((cnt[:, [0, 1, 2, 4, 5]].sum(dim=1) > 0).sum().item())
+    f_eval = mlp_flops(model.implicit_network.specs)
+    achieved = queries * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
+    ray_hit = model.last_ray_hit
+    n_hit = int(ray_hit.sum().item())
+    hit_frac = n_hit / max(ray_hit.numel(), 1)
+    n_hit2 = int(out['secondary_mask'].sum().item()) if out.get('secondary_mask') is not None else 0
+    sec_frac = n_hit2 / max(3 * n_hit, 1) if indirect else None
+    prec = model.ray_tracer.precision
+    split = prec.startswith('f16x3')
+    peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+    pm = model.implicit_network.packed(f16x3=True) if split else None
+    kname = {'f32': 'eval_kernel', 'f16x3': 'eval_kernel16', 'f16x3w': 'eval_kernel16w'}[prec]
+    coarse_tau = 0.0
+    if prec == 'f16x3w' and pm.w_stream is not None:
+        # 512- / 256-wide nets: the pipelined stream kernels (mlp_tile.h "16q": 16x16x32 MFMA; "16p": 32x32x16)
+        kname = 'eval_kernel16q' if pm.struct.reserved == 1 else 'eval_kernel16p'
+        if model.ray_tracer.coarse:
+            coarse_tau = model.implicit_network.coarse_tau(model.ray_tracer.object_bounding_sphere)
+            if coarse_tau > 0:
+                kname += ' + eval_kernel16s'
+    # ---- algorithmic flops of the whole step per primary ray
+    f_rad = mlp_flops(model.rendering_network.specs)
+    f_mat = mlp_flops(model.envmap_material_network.specs)
+    evals_live = int(ops.algorithmic_evals(cnt_live, n_steps).sum().item())        # E_tr (+ 3 h E_tr2), whole step
+    rad_on = lc.get('idr_rgb_weight', 0.0) > 0
+    a_step = evals_live * f_eval + n_hit * (2 * f_eval + (3 * f_rad if rad_on or indirect else 0) + 3 * f_mat +
+                                            (F_MC_SHADING if indirect else F_SG_SHADING))
+    if indirect:
+        a_step += n_hit2 * (2 * f_eval + 3 * f_rad)
+    a_ray = a_step / rays_per_rank
+    frac_step = a_ray * (value / world) / (peak * 1e12)
+    # HBM traffic of the same kernels: NOT measured by this run - read from the rocprofv3 PMC passes of this command
+    # committed under profiles/ (tools/profile_round.sh; separate FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied
+    # by tools/pmc_traffic.py), and only quoted for the workload / kernels it was measured on
+    traffic, traffic_source = None, None
+    for rnd in ('r02', 'r01'):
+        tpath = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic_%s.json' % name)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get('kernel') == kname:
+            if tj.get('kernel') and tj['kernel'] in kname:
                 traffic = tj['hbm_bytes_per_launch']
-        roofline = {'bound': 'mfma',
-                    'kernel': kname + ' (fused SDF MLP over the tracer work list)',
-                    'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': traffic,
-                    'traffic_unit': 'HBM bytes per launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, averaged over all launches '
-                                    'of the kernel incl. empty rounds; profiles/r01/pmc_traffic_*.json)',
-                    'arithmetic': ('3x v_mfma_f32_{16x16x32,32x32x16}_f16 per k-step on fp16 hi/lo operand pairs, fp32 accumulate: '
-                                   'achieved counts ALGORITHMIC flops (the matrix cores issue 3x that)') if split
-                                  else 'v_mfma_f32_32x32x2_f32 (exact fp32)',
-                    'flops_per_sdf_eval': f_eval, 'sdf_evals_per_step': queries, 'sdf_evals_executed_split_precision': executed,
-                    'sdf_evals_executed_single_pass': executed_coarse,
-                    'sdf_evals_per_primary_ray': queries / rays_per_rank,
-                    'nonempty_launches_per_step': launches, 'launches_per_step': n_eval.value,
-                    'kernel_ms_per_step': eval_ms.value, 'tracer_span_ms': span_ms.value,
-                    'profiled_step_ms': prof_step_ms, 'hit_fraction': hit_frac}
-        result = {
-            'metric': 'training rays/sec (Step-2 material opt)', 'value': value, 'unit': 'rays/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'graph_priming_steps': priming,
-            'ms_per_step': ms_per_step,
-            'ms_per_step_without_dead_min_sdf_search': ms_skip,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f16x3' if model.ray_tracer.precision.startswith('f16x3') else 'f32', 'data': 'synthetic',
-            'config': {'workload': '%s: robot-like synthetic scene (geometric-init SDF), %s model, num_pixels=%d per GPU'
-                                   '%s, 128 SG lobes, %s, frozen geometry, fwd+IDRLoss+bwd+2xAdam'
-                                   % (args.workload, {'physg': 'physg.conf', 'conf': 'conf.conf', 'neus': 'conf_neus.conf'}[w['model']],
-                                      w['num_pixels'], (' x %d rays/pixel' % w['num_rays']) if w['num_rays'] > 0 else '',
-                                      'indirect OFF (closed-form SG)' if mc.get('render_type', 'sg') == 'sg'
-                                      else 'MC direct + near-field indirect ON'),
-                       'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
-                       'step_graph': bool(use_graph),
-                       'rank_param_spread': param_spread,
-                       'trace_prefetch': len(nxt) if nxt is not None else 0,   # batches traced ahead, beside the tail of batch i
+                traffic_source = ('profiles/%s/pmc_traffic_%s.json: rocprofv3 --pmc passes of this command on an earlier run '
+                                  '(2*FETCH_SIZE + WRITE_SIZE per tracer round, all dispatches of the round\'s evaluation '
+                                  'kernels, averaged over all rounds incl. empty ones); not measured by this run' % (rnd, name))
+                break
+    roofline = {'bound': 'mfma',
+                'kernel': kname + ' (fused SDF MLP over the tracer work list)',
+                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
+                'frac_kernel': achieved / peak, 'frac_step': frac_step,
+                'traffic': traffic, 'traffic_source': traffic_source,
+                'arithmetic': ('split precision: 3x v_mfma_f32_16x16x32_f16 per k-step on fp16 hi/lo operand pairs, fp32 '
+                               'accumulate; coarse pass (bracket / min-SDF searches): 1x, decisive samples re-evaluated in '
+                               'split precision.  achieved counts ALGORITHMIC flops: evaluations the reference executes x '
+                               'flops_per_sdf_eval') if split else 'v_mfma_f32_32x32x2_f32 (exact fp32)',
+                'flops_per_sdf_eval': f_eval, 'sdf_evals_per_step': queries,
+                'sdf_evals_executed_split_precision': executed, 'sdf_evals_executed_single_pass': executed_coarse,
+                'coarse_tau': coarse_tau,
+                'sdf_evals_per_primary_ray': queries / rays_per_rank,
+                'nonempty_launches_per_step': launches, 'launches_per_step': n_eval.value,
+                'kernel_ms_per_step': eval_ms.value, 'tracer_span_ms': span_ms.value,
+                'profiled_step_ms': prof_step_ms, 'hit_fraction': hit_frac, 'secondary_hit_fraction': sec_frac,
+                'step_model': {'formula': 'SURVEY.md 8(d): A = E*F_sdf + N_hit*(F_nrm + 3 F_rad[if weighted] + 3 F_mat + F_shade)'
+                                          ' + N_hit2*(F_nrm + 3 F_rad); frac_step = A/ray * rays/s/GPU / peak',
+                               'E_sdf_evals_without_min_sdf_search': evals_live, 'N_hit': n_hit, 'N_hit2': n_hit2,
+                               'F_sdf': f_eval, 'F_nrm': 2 * f_eval, 'F_rad': f_rad, 'F_mat': f_mat,
+                               'F_shade': F_MC_SHADING if indirect else F_SG_SHADING,
+                               'radiance_backward_counted': bool(rad_on or indirect),
+                               'A_flops_per_primary_ray': a_ray}}
+    return {
+        'metric': 'training rays/sec (Step-2 material opt)', 'value': value, 'unit': 'rays/s',
+        'n_gpus': world, 'steps': steps, 'warmup': warmup, 'graph_priming_steps': priming,
+        'ms_per_step': ms_per_step,
+        'ms_per_step_without_dead_min_sdf_search': ms_skip,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f16x3' if split else 'f32', 'data': 'synthetic',
+        'config': {'workload': '%s: %s, %s model, num_pixels=%d per GPU%s, 128 SG lobes, %s, frozen geometry, '
+                               'fwd+IDRLoss+bwd+2xAdam'
+                               % (name, 'robot-like synthetic scene (geometric-init SDF sphere)' if not w.get('scene') else
+                                  'non-convex synthetic scene (fitted ball-in-bowl SDF embedded at full width)',
+                                  {'physg': 'physg.conf', 'conf': 'conf.conf', 'neus': 'conf_neus.conf'}[w['model']],
+                                  w['num_pixels'], (' x %d rays/pixel' % w['num_rays']) if w['num_rays'] > 0 else '',
+                                  'indirect OFF (closed-form SG)' if not indirect else 'MC direct + near-field indirect ON'),
+                   'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
+                   'step_graph': bool(use_graph),
+                   'rank_param_spread': param_spread,
+                   'trace_prefetch': len(nxt) if nxt is not None else 0,   # batches traced ahead, beside the tail of batch i
+                   'loss': float(lo['loss'].item())},
+        'roofline': roofline,
+    }
 
-                       'loss': float(lo['loss'].item())},
-            'roofline': roofline,
-        }
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default=None, help='measure this workload alone (default: cfg2, with cfg3 nested)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-nested', action='store_true', help='skip the nested cfg3 measurement')
+    ap.add_argument('--no-side-measurement', action='store_true',
+                    help='skip the untimed side loop without the min-SDF search (profiling runs: nearly every step of the\n'
+                         'process is then the headline step, so rocprofv3 per-kernel averages compare directly)')
+    ap.add_argument('--cpu-sample-pixels', type=int, default=512)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d'
+                             % (args.gpus, args.gpus))
+    import torch.distributed as dist
+    # one process per GPU; NEFII_BENCH_BACKEND=gloo lets the multi-process path be smoke-tested on a 1-GPU box
+    backend = os.environ.get('NEFII_BENCH_BACKEND', 'nccl')
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    if world > 1:
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+
+    from nefii_amd import _lib
+    lib = _lib.lib()
+    headline = args.workload or 'cfg2'
+    result = run_workload(headline, args, args.steps, args.warmup, rank, world, dev, backend, lib,
+                          side=not args.no_side_measurement)
+    nested = None
+    if args.workload is None and not args.no_nested:
+        nested = run_workload('cfg3', args, max(1, min(args.steps, 5)), min(args.warmup, 2), rank, world, dev, backend, lib,
+                              side=False)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()        # nothing below communicates (rank 0 alone runs the CPU baseline)
+    if rank == 0:
+        if nested is not None:
+            result['cfg3'] = {k: nested[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config',
+                                                     'roofline')}
         if not args.no_cpu_baseline:
             result['cpu_baseline'], result['parity_vs_cpu_oracle'] = cpu_baseline(
-                args.workload, args.cpu_sample_pixels, steps=3, warmup=1, device=dev)
+                headline, args.cpu_sample_pixels, steps=3, warmup=1, device=dev)
         print(json.dumps(result), flush=True)
 
 

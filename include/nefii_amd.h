@@ -149,7 +149,7 @@ typedef struct nefii_tracer_params {
                                 is - are re-evaluated in split precision, so every decision (and the outputs) is the
                                 split evaluator's.  0 = off.  nefii_sdf_eval_coarse measures the bound for a net. */
     int32_t coarse_cap;      /* most samples of one ray re-evaluated individually; a ray with more takes all n_steps
-                                in split precision instead.  <= 0: 24.  At most 100. */
+                                in split precision instead.  <= 0: 64.  At most 100. */
 } nefii_tracer_params;
 #define NEFII_TRACE_COUNTERS 8   /* int32 counters per round, see nefii_trace_rays */
 

@@ -15,6 +15,8 @@
 //   * accumulators: up to 4 tiles x 16 VGPR per wave.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 #include "../../include/nefii_amd.h"
 
 namespace nefii {
@@ -1157,7 +1159,8 @@ __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, f
 // Same tile, cursor, 4 register stages and epilogue idea as "16q"; what changes:
 //   * the stream unit is one 32-deep k-step of the wave's FT feature tiles, hi fragments only (FT KiB), every layer's
 //     K zero-padded to a multiple of 128 (unit counts = multiples of the 4 stages): nefii_pack_sdf_stream's third copy;
-//   * the activation image has the hi halves only (64 or 96 rows x XP halves);
+//   * the activation image has the hi halves only (16 QT rows x XP halves): with a third of the matrix work per query the
+//     tile is bound by its fragment stream unless it holds more queries than the split evaluator's (QT = 6: 96);
 //   * FT * QT MFMAs per unit, one activation fragment read per query tile and unit.
 // ================================================================================================
 template <int FT>
@@ -1168,9 +1171,9 @@ template <int QT>
 struct SAct {
     half8 h[QT];
 };
-template <int FT>
+template <int FT, int ROWS>
 struct LdsS {
-    _Float16 Xh[QGeo<FT>::ROWS * QGeo<FT>::XP];
+    _Float16 Xh[ROWS * QGeo<FT>::XP];
     _Float16 tail[128];
 };
 // units (32-deep k-steps of the 128-padded K) of a layer in the single-pass stream
@@ -1191,38 +1194,59 @@ __device__ __forceinline__ void sload_a(SAct<QT> &st, const _Float16 *ah, int s3
     for (int qt = 0; qt < QT; ++qt) st.h[qt] = *reinterpret_cast<const half8 *>(ah + qt * 16 * XP + 32 * s32);
 }
 
-template <int QT, int FT, int J>
-__device__ __forceinline__ void sstep(SStage<FT> (&b)[4], SAct<QT> (&a)[2], PCursor &cur, const _Float16 *ah, int s32,
+// DB: the next step's activation fragments are read while this step multiplies (two register sets); !DB: one set, read
+// at the top of the step that uses it (24-32 registers less for the 96- / 128-query tiles, the SIMD partner covers the wait)
+template <int QT, int FT, int J, bool DB>
+__device__ __forceinline__ void sstep(SStage<FT> (&b)[4], SAct<QT> (&a)[DB ? 2 : 1], PCursor &cur, const _Float16 *ah, int s32,
                                       f32x4 (&acc)[FT * QT]) {
-    static_assert(QT % FT == 0, "the issue pattern below hands QT / FT activation reads to each feature tile");
     sload<FT>(b[(J + 3) % 4], cur);
-    sload_a<QT, QGeo<FT>::XP>(a[(J + 1) & 1], ah, s32 + 1);
+    if constexpr (DB)
+        sload_a<QT, QGeo<FT>::XP>(a[(J + 1) & 1], ah, s32 + 1);
+    else
+        sload_a<QT, QGeo<FT>::XP>(a[0], ah, s32);
 #pragma unroll
     for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             f32x4 &c = acc[ft * QT + qt];
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[ft], a[J & 1].h[qt], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[ft], a[DB ? (J & 1) : 0].h[qt], c, 0, 0, 0);
         }
-    // MFMAs lead; the unit's FT fragment loads and QT activation reads are spread between them (see pstep)
+    if constexpr (DB) {
+        // MFMAs lead; the unit's FT fragment loads and QT activation reads are spread between them (see pstep)
+        // (feature tile i: QT MFMAs with its fragment load and its share of the QT reads in their midst)
+#define NEFII_SGROUP(i)                                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, QT / 2, 0);                                       \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, QT - QT / 2, 0);                                  \
+    __builtin_amdgcn_sched_group_barrier(0x100, (QT * ((i) + 1)) / FT - (QT * (i)) / FT, 0);
+        NEFII_SGROUP(0)
+        NEFII_SGROUP(1)
+        if constexpr (FT == 4) {
+            NEFII_SGROUP(2)
+            NEFII_SGROUP(3)
+        }
+#undef NEFII_SGROUP
+    } else {
+        // the step's own activation reads first, then MFMAs with the fragment loads spread between them
+        __builtin_amdgcn_sched_group_barrier(0x100, QT, 0);
 #pragma unroll
-    for (int i = 0; i < FT; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, QT / 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, QT - QT / 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, QT / FT, 0);
+        for (int i = 0; i < FT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, QT / 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, QT - QT / 2, 0);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int QT, int FT>
-__device__ __forceinline__ void sgemm(int units, SStage<FT> (&b)[4], SAct<QT> (&a)[2], PCursor &cur, const _Float16 *ah,
-                                      f32x4 (&acc)[FT * QT]) {
+template <int QT, int FT, bool DB>
+__device__ __forceinline__ void sgemm(int units, SStage<FT> (&b)[4], SAct<QT> (&a)[DB ? 2 : 1], PCursor &cur,
+                                      const _Float16 *ah, f32x4 (&acc)[FT * QT]) {
     for (int s = 0; s < units; s += 4) {
-        sstep<QT, FT, 0>(b, a, cur, ah, s, acc);
-        sstep<QT, FT, 1>(b, a, cur, ah, s + 1, acc);
-        sstep<QT, FT, 2>(b, a, cur, ah, s + 2, acc);
-        sstep<QT, FT, 3>(b, a, cur, ah, s + 3, acc);
+        sstep<QT, FT, 0, DB>(b, a, cur, ah, s, acc);
+        sstep<QT, FT, 1, DB>(b, a, cur, ah, s + 1, acc);
+        sstep<QT, FT, 2, DB>(b, a, cur, ah, s + 2, acc);
+        sstep<QT, FT, 3, DB>(b, a, cur, ah, s + 3, acc);
     }
 }
 
@@ -1250,8 +1274,8 @@ __device__ __forceinline__ void sepilogue(const f32x4 (&acc)[FT * QT], float bve
     }
 }
 
-template <int FT>
-__device__ __forceinline__ void encode_tile16s(const nefii_mlp &m, const float *raw, LdsS<FT> &lds, int rows) {
+template <int FT, int ROWS>
+__device__ __forceinline__ void encode_tile16s(const nefii_mlp &m, const float *raw, LdsS<FT, ROWS> &lds, int rows) {
     constexpr int XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, EW = QGeo<FT>::EW;
     const int w0 = enc_width(m.enc_freqs[0]);
     for (int i = threadIdx.x; i < rows * EW; i += 512) {
@@ -1288,15 +1312,15 @@ __device__ __forceinline__ void prime16s(const nefii_mlp &m, SStage<FT> (&b)[4],
 }
 
 // One tile of 16 * QT queries through the whole SDF network in a single fp16 pass.
-template <int QT, int FT>
-__device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT> &lds, float *raw, float *const *dest,
+template <int QT, int FT, bool DB = true>
+__device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT> &lds, float *raw, float *const *dest,
                                             SStage<FT> (&b)[4], PCursor &cur) {
-    constexpr int NW = 8, RT = (QT + 1) / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, RMAX = QGeo<FT>::ROWS;
+    constexpr int NW = 8, RT = (QT + 1) / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, RMAX = 16 * QT;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int NH = m.n_layers - 1;
     const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
     const float k16 = inv_scale * A16_SCALE;
-    encode_tile16s<FT>(m, raw, lds, 16 * QT);
+    encode_tile16s<FT, 16 * QT>(m, raw, lds, 16 * QT);
     __syncthreads();
     const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4);
     for (int l = 0; l < NH; ++l) {
@@ -1313,24 +1337,61 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT> &lds, f
         for (int j = 0; j < FT * QT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
-        SAct<QT> a[2];
-        sload_a<QT, XP>(a[0], ah, 0);
-        sgemm<QT, FT>(units, b, a, cur, ah, acc);
-        half4 phi[FT * QT];
-        if (m.act == NEFII_ACT_SOFTPLUS100)
-            sepilogue<QT, FT, true>(acc, bvec, k16, lane, m.act, phi);
-        else
-            sepilogue<QT, FT, false>(acc, bvec, k16, lane, m.act, phi);
-        __syncthreads();
+        SAct<QT> a[DB ? 2 : 1];
+        if constexpr (DB) sload_a<QT, XP>(a[0], ah, 0);
+        sgemm<QT, FT, DB>(units, b, a, cur, ah, acc);
         _Float16 *xh = lds.Xh + (EP - L.n_pad);
+        if constexpr (DB) {
+            // epilogue arithmetic ahead of the barrier (it overlaps the SIMD partner's k-loop), packed results parked in
+            // registers until every wave is done reading the activation image
+            half4 phi[FT * QT];
+            if (m.act == NEFII_ACT_SOFTPLUS100)
+                sepilogue<QT, FT, true>(acc, bvec, k16, lane, m.act, phi);
+            else
+                sepilogue<QT, FT, false>(acc, bvec, k16, lane, m.act, phi);
+            __syncthreads();
 #pragma unroll
-        for (int ft = 0; ft < FT; ++ft) {
-            const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
+            for (int ft = 0; ft < FT; ++ft) {
+                const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const int query = 16 * qt + (lane & 15);
-                *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int query = 16 * qt + (lane & 15);
+                    *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                }
             }
+        } else {
+            // big tiles: no registers to park the packed results in - the whole epilogue runs behind the barrier, each
+            // feature tile's values stored as they are produced
+            __syncthreads();
+            const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
+            auto body = [&](auto fast) {        // the activation id resolved once per layer, not per value (see pepilogue)
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) {
+                    const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
+                    float4v bs;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        bs[k] = __builtin_bit_cast(float,
+                                                   __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const f32x4 &av = acc[ft * QT + qt];
+                        float4v hs;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float zs = __builtin_fmaf(av[k], k16, bs[k]);
+                            hs[k] = decltype(fast)::value ? softplus100_s16(zs)
+                                                          : act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
+                        }
+                        const int query = 16 * qt + (lane & 15);
+                        *reinterpret_cast<half4 *>(xh + query * XP + f0) = __builtin_convertvector(hs, half4);
+                    }
+                }
+            };
+            if (m.act == NEFII_ACT_SOFTPLUS100)
+                body(std::true_type{});
+            else
+                body(std::false_type{});
         }
         __syncthreads();
     }

@@ -265,9 +265,14 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                 P.s.t_s[r] = t_s;
                 P.s.t_e[r] = t_e;
                 if (live_s) {
-                    fl |= coarse ? PH_SAMPLER_C : PH_SAMPLER;
-                    qd = !coarse;
-                    qc = coarse;
+                    // what is left between the two fronts is often a short stretch hugging the surface (a grazing ray):
+                    // the SDF is ~1-Lipschitz, so |sdf| <= (sdf_s + sdf_e + length) / 2 on it - when that is within the
+                    // coarse pass's error bound nearly every sample would have to be refined, and the samples go to the
+                    // split evaluator directly (a performance choice only: either way decides from exact values)
+                    const bool go_coarse = coarse && 0.5f * (cur_s + cur_e + (t_e - t_s)) > 3.f * P.tau;
+                    fl |= go_coarse ? PH_SAMPLER_C : PH_SAMPLER;
+                    qd = !go_coarse;
+                    qc = go_coarse;
                     n_alg = 1;
                     dense_which = 0;
                     P.s.flags[r] = fl;
@@ -837,18 +842,17 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
 }
 
 // the coarse evaluator (mlp_tile.h "16s") over the round's coarse list: one fp16 pass, 16 * QT queries per tile
-template <int FT>
-__device__ __forceinline__ void zero_lds_s(LdsS<FT> &lds) {
+template <int FT, int ROWS>
+__device__ __forceinline__ void zero_lds_s(LdsS<FT, ROWS> &lds) {
     uint32_t *p = reinterpret_cast<uint32_t *>(&lds);
-    for (int i = threadIdx.x; i < (int)(sizeof(LdsS<FT>) / 4); i += blockDim.x) p[i] = 0u;
+    for (int i = threadIdx.x; i < (int)(sizeof(LdsS<FT, ROWS>) / 4); i += blockDim.x) p[i] = 0u;
     __syncthreads();
 }
 
-template <int QT, int FT>
+template <int QT, int FT, bool DB = true>
 __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, int round) {
-    constexpr int RMAX = QGeo<FT>::ROWS, ROWS = 16 * QT;
-    static_assert(ROWS <= RMAX, "tile rows");
-    __shared__ LdsS<FT> lds;
+    constexpr int ROWS = 16 * QT, RMAX = ROWS;
+    __shared__ LdsS<FT, ROWS> lds;
     __shared__ float raw[RMAX * 9];
     __shared__ float *dest[RMAX];
     const int64_t total = (int64_t)P.counters[round * NCNT + 5] * P.p.n_steps;
@@ -861,15 +865,15 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         decode_tile_coarse<ROWS>(P, tile, total, raw, dest);
         __syncthreads();
-        sdf_tile16s<QT, FT>(m, lds, raw, dest, b, cur);
+        sdf_tile16s<QT, FT, DB>(m, lds, raw, dest, b, cur);
     }
 }
 
-template <int QT, int FT>
+template <int QT, int FT, bool DB = true>
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
-    constexpr int RMAX = QGeo<FT>::ROWS, ROWS = 16 * QT;
-    __shared__ LdsS<FT> lds;
+    constexpr int ROWS = 16 * QT, RMAX = ROWS;
+    __shared__ LdsS<FT, ROWS> lds;
     __shared__ float raw[RMAX * 9];
     __shared__ float *dest[RMAX];
     const int64_t n_tiles = (n + ROWS - 1) / ROWS;
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, cons
             dest[tid] = live ? out + q : nullptr;
         }
         __syncthreads();
-        sdf_tile16s<QT, FT>(m, lds, raw, dest, b, cur);
+        sdf_tile16s<QT, FT, DB>(m, lds, raw, dest, b, cur);
     }
 }
 
@@ -1212,6 +1216,21 @@ extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, voi
     return 0;
 }
 
+// queries per tile of the single-pass evaluator, 16 * QT.  512-wide nets: QT 4 (default) / 6 / 8 (NEFII_COARSE_QT; the big
+// tiles read activation fragments single-buffered and run their epilogue behind the barrier to fit 256 registers).
+// Measured per 64 queries at 12 tiles per CU: 62.0 / 58.9 / 58.3 us, at one tile per CU 77 / 100 / 123 us - the tile is
+// bound by its matrix work plus the epilogue's VALU work, not by the fragment stream, so bigger tiles buy ~5 % on
+// full rounds and cost latency on small ones
+static int coarse_qt() {
+    static const int v = [] {
+        const char *e = getenv("NEFII_COARSE_QT");
+        const int q = e ? atoi(e) : 0;
+        return q == 4 || q == 6 || q == 8 ? q : 4;
+    }();
+    return v;
+}
+
+
 extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream) {
     if (!h_sdf || h_sdf->n_layers < 1 || h_sdf->n_layers > NEFII_MAX_LAYERS) return NEFII_E_ARG;
     if (!nefii_sdf_coarse_supported(h_sdf)) return NEFII_E_UNSUPPORTED;
@@ -1221,13 +1240,17 @@ extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int
         h_sdf->layer[0].k_x != 0)
         return NEFII_E_UNSUPPORTED;
     const int ft = shape16p(h_sdf);
-    const int rows = ft == 2 ? 96 : 64;
-    const int64_t n_tiles = (n + rows - 1) / rows;
+    const int qt = ft == 2 ? 6 : coarse_qt();
+    const int64_t n_tiles = (n + 16 * qt - 1) / (16 * qt);
     const dim3 grid((int)(n_tiles < 512 ? n_tiles : 512));
     if (ft == 2)
         hipLaunchKernelGGL((sdf_points_kernel16s<6, 2>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
-    else
+    else if (qt == 4)
         hipLaunchKernelGGL((sdf_points_kernel16s<4, 4>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    else if (qt == 8)
+        hipLaunchKernelGGL((sdf_points_kernel16s<8, 4, false>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    else
+        hipLaunchKernelGGL((sdf_points_kernel16s<6, 4, false>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
     HIP_CHECK_LAUNCH();
     return 0;
 }
@@ -1262,7 +1285,9 @@ extern "C" int nefii_sdf_eval(const nefii_mlp *h_sdf, const float *x, int64_t n,
 // samples of one ray the coarse pass refines individually (0: coarse pass off)
 static int coarse_cap(const nefii_tracer_params *p) {
     if (!(p->coarse_tau > 0.f)) return 0;
-    const int c = p->coarse_cap <= 0 ? 24 : p->coarse_cap;
+    // break-even of refining k samples of a ray (k split evaluations on top of the coarse pass, 1/3 each) against
+    // re-evaluating all 100 in split precision is k ~ 67
+    const int c = p->coarse_cap <= 0 ? 64 : p->coarse_cap;
     return c > 100 ? 100 : c;
 }
 
@@ -1415,8 +1440,12 @@ int launch_round(const TraceJob &J, int r, bool profile) {
                 const int64_t t = (J.P.n * (int64_t)J.P.p.n_steps + 95) / 96;
                 hipLaunchKernelGGL((eval_kernel16s<6, 2>), dim3((int)(t < J.eval_blocks_w ? t : J.eval_blocks_w)), dim3(512), 0,
                                    st, J.P, *J.sdf, r);
-            } else {
+            } else if (coarse_qt() == 4) {
                 hipLaunchKernelGGL((eval_kernel16s<4, 4>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
+            } else if (coarse_qt() == 8) {
+                hipLaunchKernelGGL((eval_kernel16s<8, 4, false>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
+            } else {
+                hipLaunchKernelGGL((eval_kernel16s<6, 4, false>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
             }
             HIP_CHECK_LAUNCH();
         }

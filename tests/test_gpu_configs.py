@@ -189,13 +189,13 @@ def test_config_full_size_properties(wl):
 
 def test_config5_render_strip_vs_oracle():
     """Config 5 (render.py: eval mode, conf.conf model, 256 rays per pixel, frame in raster order): 16 pixels of row 400
-    of the 800 x 800 frame.  Per ray against the oracle (eval mode: no min-SDF search), then through render_frame in
+    of the 800 x 800 frame, straddling the object's silhouette (the bowl's rim leaves the row at column 712).  Per ray against the oracle (eval mode: no min-SDF search), then through render_frame in
     chunks (memory_capacity_level 10 = 4 pixels per chunk at 256 rays) against the un-chunked forward."""
     from nefii_amd.training import render as RR
     w = syn.WORKLOADS['cfg5']
     mc, sd = syn.workload_state_dict('cfg5', seed=0)
     full = syn.frame_inputs(w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], rows=(400, 1))
-    cols = slice(392, 408)
+    cols = slice(704, 720)
     inp = {'uv': full['uv'][:, cols].contiguous(), 'object_mask': full['object_mask'][:, cols].contiguous(),
            'pose': full['pose'], 'intrinsics': full['intrinsics']}
     assert inp['uv'].shape == (1, 16, 256, 2) and inp['uv'][0, 0, :, 1].round().eq(400).all()
@@ -212,7 +212,7 @@ def test_config5_render_strip_vs_oracle():
         out = gpu_forward_with_per_ray_draws(m, to_dev(flat), uniforms)
     compare_outputs(out, ref, max_flips=4, what='cfg5 strip', rays_per_pixel=1, ray_hit=m.last_ray_hit,
                     ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02)
-    assert 0.2 < ref['_ray_hit'].float().mean().item() < 0.95 and ref['secondary_mask'].float().mean().item() > 0.2
+    assert 0.2 < ref['_ray_hit'].float().mean().item() < 0.95 and ref['secondary_mask'].float().mean().item() > 0.0
     # chunked frame path on the same pixels (fresh sampler draws per chunk: compare what does not pass through them)
     merged = RR.render_frame(m, to_dev(inp), 16, num_rays=256, memory_capacity_level=10)
     assert merged['points'].shape == (16, 3)

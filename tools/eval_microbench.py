@@ -1,5 +1,6 @@
-"""Per-tile cost of the tracer's SDF tile evaluator (nefii_sdf_eval): n points = tiles_per_cu x 256 CUs x 64 rows.
-Usage: python tools/eval_microbench.py [tiles_per_cu ...]   (NEFII_LIB_PATH selects an A/B build)"""
+"""Per-tile cost of the tracer's SDF tile evaluators - split precision (nefii_sdf_eval) and single pass
+(nefii_sdf_eval_coarse) interleaved in one process: n points = tiles_per_cu x 256 CUs x 64 rows.
+Usage: python tools/eval_microbench.py [tiles_per_cu ...]   (NEFII_LIB_PATH selects an A/B build; MODEL=neus: 8x256 net)"""
 import os
 import sys
 
@@ -8,7 +9,7 @@ import torch
 from nefii_amd import ops, synthetic as syn
 from oracle import nets
 
-mc = syn.model_conf('physg')
+mc = syn.model_conf(os.environ.get('MODEL', 'physg'))
 sd = syn.make_state_dict(mc, seed=0, bumpy=0.004)
 specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
 pm = ops.PackedMLP(specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, enc, 0, 'cuda', f16x3=True)
@@ -18,18 +19,25 @@ g = torch.Generator().manual_seed(1)
 for tpc in [int(a) for a in sys.argv[1:]] or [1, 2, 8]:
     n = tpc * 256 * 64
     x = (torch.randn(n, 3, generator=g) * 0.4).cuda()
-    for _ in range(3):
-        out = ops.sdf_eval(pm, x)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 10
-    e0.record()
-    for _ in range(reps):
-        out = ops.sdf_eval(pm, x)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    flops = sum(2 * sp.k_in * sp.n_out for sp in specs)
     ref = nets.sdf_forward({k: v.double() for k, v in sd.items()}, mc['implicit_network'], x[:2000].cpu().double())[:, 0]
-    err = (out[:2000].cpu().double() - ref).abs().max().item()
-    print('tiles/CU %3d  n %8d  %.3f ms  %.1f us per tile-slot  %.1f TFLOP/s algorithmic   max|err| vs fp64 %.2e'
-          % (tpc, n, ms, ms * 1e3 / tpc, n * 3.67104e6 / ms / 1e9, err))
+    best = {}
+    for rnd in range(3):                   # interleaved rounds in one process (compare A/B within it only)
+        for coarse in (False, True):
+            for _ in range(2):
+                out = ops.sdf_eval(pm, x, coarse=coarse)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            e0.record()
+            for _ in range(reps):
+                out = ops.sdf_eval(pm, x, coarse=coarse)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            err = (out[:2000].cpu().double() - ref).abs().max().item()
+            best[coarse] = min(best.get(coarse, (1e9, 0))[0], ms), err
+    for coarse in (False, True):
+        ms, err = best[coarse]
+        print('%-12s tiles/CU %3d  n %8d  %.3f ms  %.1f us per 64-query tile-slot  %.1f TFLOP/s algorithmic   max|err| vs fp64 %.2e'
+              % ('single pass' if coarse else 'split', tpc, n, ms, ms * 1e3 / tpc, n * flops / ms / 1e9, err))

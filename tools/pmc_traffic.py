@@ -18,7 +18,9 @@ def per_launch(path, counter, kern):
         if kern in r['Kernel_Name'] and r['Counter_Name'] == counter:
             tot += float(r['Counter_Value'])
             name = r['Kernel_Name']
-            if ', 1>(' not in name and '<2>(' not in name and 'eval_kernel16q<2, ' not in name:
+            # one launch per tracer round: the round's big-tile split-precision dispatch stands for it (the 32-query
+            # instance `<2, FT>` and the coarse evaluator eval_kernel16s are further dispatches of the same round)
+            if ', 1>(' not in name and '<2>(' not in name and 'eval_kernel16q<2, ' not in name and 'eval_kernel16s' not in name:
                 disp.add(r['Dispatch_Id'])
     return tot, len(disp)
 
