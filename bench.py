@@ -161,8 +161,8 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
 
     # NEFII_BENCH_PREFETCH=1 (default): every step also enqueues the trace of the next batch (TrainStep.prefetch_trace)
     nxt = inp if os.environ.get('NEFII_BENCH_PREFETCH', '1') != '0' else None
-    if nxt is not None:         # batches known ahead of time (a dataloader's prefetch queue): 2 by default
-        nxt = [inp] * max(1, int(os.environ.get('NEFII_BENCH_LOOKAHEAD', '2')))
+    if nxt is not None:         # batches known ahead of time (a dataloader's prefetch queue): 3 by default
+        nxt = [inp] * max(1, int(os.environ.get('NEFII_BENCH_LOOKAHEAD', '3')))
     for _ in range(warmup):
         step(inp, gt, nxt)
     # the graph of the step's tail is captured once per padded hit count, after 3 eager steps: with fewer warm-up steps
@@ -334,6 +334,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                    'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
                    'step_graph': bool(use_graph),
                    'rank_param_spread': param_spread,
+                   'nonfinite_steps': int(step.nonfinite_steps.item()),     # steps cancelled by TrainStep's NaN guard
                    'trace_prefetch': len(nxt) if nxt is not None else 0,   # batches traced ahead, beside the tail of batch i
                    'loss': float(lo['loss'].item())},
         'roofline': roofline,

@@ -116,6 +116,25 @@ int nefii_mlp_backward(const nefii_mlp *h_mlp, const float *d_out, int out_strid
 int nefii_mlp_wgrad(const float *dz, int dz_stride, const float *x, int x_stride, int64_t n, int n_out, int k_in,
                     float scale, float *dW, float *db, void *stream);
 
+/* fp16-MFMA variants of the three entry points above for the radiance and material MLPs (the north star's "fused MLP
+ * forward/backward with MFMA fp16 tiles"; every layer must carry w_f16x3 / w_bwd_f16x3); stash, dz, dW and db stay
+ * fp32; not for the SDF network.
+ *   forward: single_pass = 0 - split precision (fp16 hi/lo operand pairs, 3 MFMAs per k-step, fp32-class accuracy: the
+ *     default, its outputs are held to the north-star tolerance); 1 - operands rounded to fp16 once (measured 1.3e-3
+ *     relative L2 on rendered RGB on config 3 - above the 1e-3 bar, kept for measurement only);
+ *   backward / wgrad: one fp16 pass, fp32 accumulation.  Gradients sit far below fp16's normal range, so the GEMMs
+ *     carry dz x *scale, a power of two that nefii_mlp_grad_scale derives on the device from max |d_out|; `scale` is a
+ *     device pointer to one float.  Parameter gradients come out within ~1e-3 (2e-2 through weight-norm's projection). */
+int nefii_mlp_forward_f16(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
+                          const float *feat, int64_t n, float *out, int out_stride,
+                          float *hidden_out, int hid_stride, float *stash, int stash_stride, int single_pass,
+                          void *stream);
+int nefii_mlp_grad_scale(const float *d_out, int64_t count, float *scale, void *stream);
+int nefii_mlp_backward_f16(const nefii_mlp *h_mlp, const float *d_out, int out_stride, const float *stash,
+                           int stash_stride, int64_t n, float *dz, int dz_stride, const float *scale, void *stream);
+int nefii_mlp_wgrad_f16(const float *dz, int dz_stride, const float *x, int x_stride, int64_t n, int n_out, int k_in,
+                        float scale, const float *gscale, float *dW, float *db, void *stream);
+
 /* The reference's layer-0 concatenation [PE(a) | PE(b) | PE(c) | feat] as a dense [n, width] matrix. */
 int nefii_encode_inputs(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
                         const float *feat, int64_t n, float *out, int width, void *stream);

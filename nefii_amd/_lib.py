@@ -65,6 +65,10 @@ SIGNATURES = {
     'nefii_mlp_forward': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P]),
     'nefii_mlp_backward': (I, [ctypes.POINTER(Mlp), P, I, P, I, I64, P, I, P]),
     'nefii_mlp_wgrad': (I, [P, I, P, I, I64, I, I, F, P, P, P]),
+    'nefii_mlp_forward_f16': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, I, P]),
+    'nefii_mlp_grad_scale': (I, [P, I64, P, P]),
+    'nefii_mlp_backward_f16': (I, [ctypes.POINTER(Mlp), P, I, P, I, I64, P, I, P, P]),
+    'nefii_mlp_wgrad_f16': (I, [P, I, P, I, I64, I, I, F, P, P, P, P]),
     'nefii_encode_inputs': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P]),
     'nefii_sdf_value_grad': (I, [ctypes.POINTER(Mlp), P, I64, P, I, P, I, P, P, P]),
     'nefii_sdf_value_grad_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp), I64]),

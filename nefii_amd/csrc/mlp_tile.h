@@ -287,27 +287,28 @@ __device__ __forceinline__ void encode_tile16(const nefii_mlp &m, const float *r
 #ifndef NEFII_HD
 #define NEFII_HD 4       /* measured on sdf_value_grad16: 4 / 6 / 8 stages -> 0.551 / 0.550 / 0.663 ms (8 spills) */
 #endif
-template <int NTW>
+// SP: single pass - hi fragments only, one MFMA per k-step and tile (the radiance / material MLPs' fp16 kernels; `al` unused)
+template <int NTW, bool SP = false>
 __device__ __forceinline__ void gemm_block16_t(const _Float16 *ah, const _Float16 *al, int ksteps,
                                                const half8 *__restrict__ wp, int NT, int wave, int lane,
                                                f32x16 (&acc)[4]) {
     constexpr int NB = NEFII_HD;
     static_assert(NB >= 2 && NB % 2 == 0, "NB must be even");
-    half8 bh[NB][NTW], bl[NB][NTW];
-    half8 a_hi[2], a_lo[2];
+    half8 bh[NB][NTW], bl[SP ? 1 : NB][SP ? 1 : NTW];
+    half8 a_hi[2], a_lo[SP ? 1 : 2];
     auto load_b = [&](int u, int s) {
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
             const size_t t = (size_t)s * NT + wave + 4 * j;
             bh[u][j] = wp[(t * 2) * 64 + lane];
-            bl[u][j] = wp[(t * 2 + 1) * 64 + lane];
+            if constexpr (!SP) bl[u][j] = wp[(t * 2 + 1) * 64 + lane];
         }
     };
 #pragma unroll
     for (int u = 0; u < NB - 1; ++u)
         if (u < ksteps) load_b(u, u);
     a_hi[0] = *reinterpret_cast<const half8 *>(ah);
-    a_lo[0] = *reinterpret_cast<const half8 *>(al);
+    if constexpr (!SP) a_lo[0] = *reinterpret_cast<const half8 *>(al);
     for (int s0 = 0; s0 < ksteps; s0 += NB) {
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -316,19 +317,22 @@ __device__ __forceinline__ void gemm_block16_t(const _Float16 *ah, const _Float1
                 if (s + NB - 1 < ksteps) load_b((u + NB - 1) % NB, s + NB - 1);
                 if (s + 1 < ksteps) {
                     a_hi[(u + 1) % 2] = *reinterpret_cast<const half8 *>(ah + 16 * (s + 1));
-                    a_lo[(u + 1) % 2] = *reinterpret_cast<const half8 *>(al + 16 * (s + 1));
+                    if constexpr (!SP) a_lo[(u + 1) % 2] = *reinterpret_cast<const half8 *>(al + 16 * (s + 1));
                 }
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[u % 2], bh[u][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[u % 2], bl[u][j], acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[u % 2], bh[u][j], acc[j], 0, 0, 0);
+                    if constexpr (!SP) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi[u % 2], bl[u][j], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo[u % 2], bh[u][j], acc[j], 0, 0, 0);
+                    }
                 }
             }
         }
     }
 }
 
+template <bool SP = false>
 __device__ __forceinline__ void gemm_block16(const _Float16 *Ah, const _Float16 *Al, int a_stride, int ksteps,
                                              const half8 *__restrict__ wp, int NT, int wave, int lane, int ntw,
                                              f32x16 (&acc)[4]) {
@@ -337,11 +341,29 @@ __device__ __forceinline__ void gemm_block16(const _Float16 *Ah, const _Float16 
     const _Float16 *ah = Ah + r * a_stride + 8 * h;
     const _Float16 *al = Al + r * a_stride + 8 * h;
     switch (ntw) {          // ntw is wave-uniform; each case has fully static register indexing
-        case 1: gemm_block16_t<1>(ah, al, ksteps, wp, NT, wave, lane, acc); break;
-        case 2: gemm_block16_t<2>(ah, al, ksteps, wp, NT, wave, lane, acc); break;
-        case 3: gemm_block16_t<3>(ah, al, ksteps, wp, NT, wave, lane, acc); break;
-        default: gemm_block16_t<4>(ah, al, ksteps, wp, NT, wave, lane, acc); break;   // callers pass ntw <= 4
+        case 1: gemm_block16_t<1, SP>(ah, al, ksteps, wp, NT, wave, lane, acc); break;
+        case 2: gemm_block16_t<2, SP>(ah, al, ksteps, wp, NT, wave, lane, acc); break;
+        case 3: gemm_block16_t<3, SP>(ah, al, ksteps, wp, NT, wave, lane, acc); break;
+        default: gemm_block16_t<4, SP>(ah, al, ksteps, wp, NT, wave, lane, acc); break;   // callers pass ntw <= 4
     }
+}
+
+// single-pass tile of the radiance / material kernels: hi halves of activations and encoded inputs only
+struct Lds16h {
+    _Float16 Xh[TILE * XS16];
+    _Float16 Eh[TILE * ES16];
+};
+
+__device__ __forceinline__ void layer_gemm16h(const nefii_layer &L, const Lds16h &lds, int n_tiles, f32x16 (&acc)[4],
+                                              int &ntw) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    ntw = (n_tiles - wave + 3) >> 2;
+    if (ntw < 0) ntw = 0;
+    zero_acc(acc);
+    const half8 *wp = reinterpret_cast<const half8 *>(L.w_f16x3);
+    gemm_block16<true>(lds.Xh, lds.Xh, XS16, L.k_x >> 4, wp, n_tiles, wave, lane, ntw, acc);
+    gemm_block16<true>(lds.Eh, lds.Eh, ES16, L.k_e >> 4, wp + (size_t)(L.k_x >> 4) * n_tiles * 2 * 64, n_tiles, wave, lane,
+                       ntw, acc);
 }
 
 __device__ __forceinline__ void layer_gemm16(const nefii_layer &L, const Lds16 &lds, int n_tiles, f32x16 (&acc)[4],
@@ -509,6 +531,35 @@ __device__ __forceinline__ float softplus100_s16(float zs) {
     const float t = __builtin_fabsf(zs) * C_T;
     const float u = 1.f + __builtin_amdgcn_exp2f(t);
     return __builtin_fmaf(__builtin_amdgcn_logf(u), C_L, __builtin_fmaxf(zs, 0.f));
+}
+
+// The same for the single-pass (coarse) evaluator, two values per instruction in packed fp16: its results are rounded to
+// fp16 anyway, and what the coarse pass may get wrong is measured per network (nefii_tracer_params.coarse_tau), so the
+// epilogue - half of that evaluator's tile time at 52 VALU cycles per value - can afford fp16 arithmetic behind the
+// fp32 bias add: |z| (v_and), x C_T (v_pk_mul), 2 x v_exp_f16, + 1 (v_pk_add), 2 x v_log_f16, max(z, 0) (v_pk_max),
+// fma (v_pk_fma): 32 cycles per value.
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2v softplus100_s16_pk(half2v zs) {
+    const _Float16 C_T = (_Float16)(-1.44269504088896340736f * 100.f / A16_SCALE);
+    const _Float16 C_L = (_Float16)(0.69314718055994530942f * A16_SCALE / 100.f);
+    const half2v t = __builtin_elementwise_abs(zs) * C_T;
+    half2v e;
+    e[0] = __builtin_exp2f16(t[0]);
+    e[1] = __builtin_exp2f16(t[1]);
+    const half2v u = e + (_Float16)1.f;
+    half2v l;
+    l[0] = __builtin_log2f16(u[0]);
+    l[1] = __builtin_log2f16(u[1]);
+    return __builtin_elementwise_fma(l, half2v{C_L, C_L}, __builtin_elementwise_max(zs, half2v{(_Float16)0.f, (_Float16)0.f}));
+}
+// four accumulator values -> bias, activation, packed halves
+__device__ __forceinline__ half4 softplus100_s16_pk4(const float4v &av, float k16, const float4v &bs) {
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    const float2v z01 = {__builtin_fmaf(av[0], k16, bs[0]), __builtin_fmaf(av[1], k16, bs[1])};
+    const float2v z23 = {__builtin_fmaf(av[2], k16, bs[2]), __builtin_fmaf(av[3], k16, bs[3])};
+    const half2v r01 = softplus100_s16_pk(__builtin_convertvector(z01, half2v));
+    const half2v r23 = softplus100_s16_pk(__builtin_convertvector(z23, half2v));
+    return half4{r01[0], r01[1], r23[0], r23[1]};
 }
 
 // transposed accumulator walk of the wide kernel: BODY sees `query` (row of the tile), `f0` (first of 4 consecutive
@@ -1263,13 +1314,17 @@ __device__ __forceinline__ void sepilogue(const f32x4 (&acc)[FT * QT], float bve
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const f32x4 &av = acc[ft * QT + qt];
-            float4v hs;
+            if constexpr (FAST) {
+                phi[ft * QT + qt] = softplus100_s16_pk4(av, k16, bs);
+            } else {
+                float4v hs;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float zs = __builtin_fmaf(av[k], k16, bs[k]);
-                hs[k] = FAST ? softplus100_s16(zs) : act_fwd(zs * (1.f / A16_SCALE), act) * A16_SCALE;
+                for (int k = 0; k < 4; ++k) {
+                    const float zs = __builtin_fmaf(av[k], k16, bs[k]);
+                    hs[k] = act_fwd(zs * (1.f / A16_SCALE), act) * A16_SCALE;
+                }
+                phi[ft * QT + qt] = __builtin_convertvector(hs, half4);
             }
-            phi[ft * QT + qt] = __builtin_convertvector(hs, half4);
         }
     }
 }
@@ -1376,15 +1431,20 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
                         const f32x4 &av = acc[ft * QT + qt];
-                        float4v hs;
+                        half4 packed;
+                        if constexpr (decltype(fast)::value) {
+                            packed = softplus100_s16_pk4(av, k16, bs);
+                        } else {
+                            float4v hs;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const float zs = __builtin_fmaf(av[k], k16, bs[k]);
-                            hs[k] = decltype(fast)::value ? softplus100_s16(zs)
-                                                          : act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
+                            for (int k = 0; k < 4; ++k) {
+                                const float zs = __builtin_fmaf(av[k], k16, bs[k]);
+                                hs[k] = act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
+                            }
+                            packed = __builtin_convertvector(hs, half4);
                         }
                         const int query = 16 * qt + (lane & 15);
-                        *reinterpret_cast<half4 *>(xh + query * XP + f0) = __builtin_convertvector(hs, half4);
+                        *reinterpret_cast<half4 *>(xh + query * XP + f0) = packed;
                     }
                 }
             };

@@ -466,6 +466,364 @@ extern "C" int nefii_mlp_wgrad(const float *dz, int dz_stride, const float *x, i
     return 0;
 }
 
+// ================================================================================================
+// Single-pass fp16 variants for the radiance and material MLPs (RenderingNetwork :196-241, EnvmapMaterialNetwork's
+// diffuse_albedo_layers sg_envmap_material.py:369): operands rounded to fp16 once, one v_mfma_f32_32x32x16_f16 per
+// 16-deep k-step, fp32 accumulation, fp32 bias / activation / head - 16x the f32-input MFMA rate of the kernels above,
+// at which these became 14 % of a config-3 step.  SURVEY.md section 7 measured fp16 on exactly these two nets at
+// 1.9e-4 relative L2 on rendered RGB (north-star tolerance 1e-3); the SDF network never takes this path.  Weights are
+// the hi blocks of nefii_pack_linear_f16x3 / _bwd (x 64), activations carry A16_SCALE.  Gradients are far below fp16's
+// normal range (d loss / d rgb ~ 1e-6 per ray), so the backward GEMMs carry dz x S, S a power of two chosen per call
+// from max |d_out| (nefii_mlp_grad_scale); everything leaves the kernels in fp32, unscaled.
+// ================================================================================================
+// LDS image of a 32-row tile: hi halves (single pass) or hi + lo halves (split precision) of activations / encoded inputs
+template <bool SP>
+struct LdsF16 {
+    _Float16 Xh[TILE * XS16], Eh[TILE * ES16];
+    _Float16 Xl[SP ? 8 : TILE * XS16], El[SP ? 8 : TILE * ES16];
+    __device__ __forceinline__ void put_x(int idx, float v) {
+        const _Float16 hi = (_Float16)(v * A16_SCALE);
+        Xh[idx] = hi;
+        if constexpr (!SP) Xl[idx] = (_Float16)(v * A16_SCALE - (float)hi);
+    }
+    __device__ __forceinline__ void put_e(int idx, float v) {
+        const _Float16 hi = (_Float16)(v * A16_SCALE);
+        Eh[idx] = hi;
+        if constexpr (!SP) El[idx] = (_Float16)(v * A16_SCALE - (float)hi);
+    }
+};
+
+template <bool SP>
+__device__ __forceinline__ void load_tile_inputs16h(const nefii_mlp &m, const float *in_a, const float *in_b,
+                                                    const float *in_c, const float *feat, int64_t base, int64_t n,
+                                                    float *raw, LdsF16<SP> &lds) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TILE * 9; i += WG) {
+        const int p = i / 9, c = i - 9 * p, which = c / 3;
+        const float *src = which == 0 ? in_a : (which == 1 ? in_b : in_c);
+        int64_t idx = base + p;
+        if (idx >= n) idx = n - 1;
+        raw[i] = (src && m.enc_freqs[which] >= 0) ? src[idx * 3 + (c - 3 * which)] : 0.f;
+    }
+    const int F = m.feat_width;
+    const int kx0 = m.layer[0].k_x;
+    if (kx0 > 0) {
+        for (int i = tid; i < TILE * kx0; i += WG) {
+            const int p = i / kx0, f = i - p * kx0;
+            int64_t idx = base + p;
+            if (idx >= n) idx = n - 1;
+            lds.put_x(p * XS16 + f, (feat && f < F) ? feat[idx * F + f] : 0.f);
+        }
+    }
+    __syncthreads();
+    int ke = 0;
+    for (int l = 0; l < m.n_layers; ++l) ke = m.layer[l].k_e > ke ? m.layer[l].k_e : ke;
+    const int pp = tid & 31, part = tid >> 5;
+    const int w0 = enc_width(m.enc_freqs[0]), w1 = enc_width(m.enc_freqs[1]), w2 = enc_width(m.enc_freqs[2]);
+    for (int c = part; c < ke; c += 8) {
+        float val = 0.f;
+        if (c < w0) val = enc_value(raw + pp * 9, c);
+        else if (c < w0 + w1) val = enc_value(raw + pp * 9 + 3, c - w0);
+        else if (c < w0 + w1 + w2) val = enc_value(raw + pp * 9 + 6, c - w0 - w1);
+        lds.put_e(pp * ES16 + c, val);
+    }
+    __syncthreads();
+}
+
+// SP = false: split precision (fp16 hi/lo pairs, 3 MFMAs per k-step: fp32-class accuracy - the default for the forward
+// pass, whose outputs are held to the north-star tolerance); SP = true: one fp16 pass.
+template <bool SP>
+__global__ __launch_bounds__(256, 1) void mlp_forward16_kernel(nefii_mlp m, const float *__restrict__ in_a,
+                                                               const float *__restrict__ in_b,
+                                                               const float *__restrict__ in_c,
+                                                               const float *__restrict__ feat, int64_t n,
+                                                               float *__restrict__ out, int out_stride,
+                                                               float *__restrict__ hidden_out, int hid_stride,
+                                                               float *__restrict__ stash, int stash_stride) {
+    __shared__ LdsF16<SP> lds;
+    __shared__ float raw[TILE * 9];
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * TILE;
+        load_tile_inputs16h<SP>(m, in_a, in_b, in_c, feat, base, n, raw, lds);
+        for (int l = 0; l < m.n_layers; ++l) {
+            const nefii_layer &L = m.layer[l];
+            f32x16 acc[4];
+            const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+            const int n_tiles_l = L.n_pad >> 5;
+            int ntw = (n_tiles_l - wave + 3) >> 2;
+            if (ntw < 0) ntw = 0;
+            zero_acc(acc);
+            const half8 *wp = reinterpret_cast<const half8 *>(L.w_f16x3);
+            gemm_block16<SP>(lds.Xh, lds.Xl, XS16, L.k_x >> 4, wp, n_tiles_l, wave, lane, ntw, acc);
+            gemm_block16<SP>(lds.Eh, lds.El, ES16, L.k_e >> 4, wp + (size_t)(L.k_x >> 4) * n_tiles_l * 2 * 64, n_tiles_l,
+                             wave, lane, ntw, acc);
+            __syncthreads();
+            const bool last = (l == m.n_layers - 1);
+            const bool pre_last = (l == m.n_layers - 2);
+            NEFII_ACT_SWITCH(m.act, {
+                NEFII_FOR_ACC(acc, ntw, {
+                    const float z = val * inv_scale + L.bias[col];
+                    const bool live = (base + row) < n;
+                    if (!last) {
+                        const float hval = act_fwd(z, ACT);
+                        lds.put_x(row * XS16 + col, hval);
+                        if (stash && live) stash[((size_t)l * n + base + row) * stash_stride + col] = hval;
+                        if (pre_last && hidden_out && live && col < L.n_out)
+                            hidden_out[(size_t)(base + row) * hid_stride + col] = hval;
+                    } else {
+                        if (stash && live) stash[((size_t)l * n + base + row) * stash_stride + col] = z;
+                        if (live && col < L.n_out) out[(size_t)(base + row) * out_stride + col] = head_fwd(z, m.head);
+                    }
+                })
+            })
+            __syncthreads();
+        }
+    }
+}
+
+static int check_mlp16(const nefii_mlp *m, bool bwd) {
+    int rc = check_mlp(m);
+    if (rc) return rc;
+    for (int l = 0; l < m->n_layers; ++l) {
+        if (!m->layer[l].w_f16x3) return NEFII_E_ARG;
+        if (bwd && l > 0 && !m->layer[l].w_bwd_f16x3) return NEFII_E_ARG;
+        if ((m->layer[l].k_x | m->layer[l].k_e | m->layer[l].n_pad) & 15) return NEFII_E_SHAPE;
+    }
+    return 0;
+}
+
+extern "C" int nefii_mlp_forward_f16(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
+                                     const float *feat, int64_t n, float *out, int out_stride, float *hidden_out,
+                                     int hid_stride, float *stash, int stash_stride, int single_pass, void *stream) {
+    int rc = check_mlp16(h_mlp, false);
+    if (rc) return rc;
+    if (n <= 0) return 0;
+    if (!out) return NEFII_E_ARG;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    if (single_pass)
+        hipLaunchKernelGGL(mlp_forward16_kernel<true>, dim3(grid_for(n_tiles, 1)), dim3(WG), 0, (hipStream_t)stream, *h_mlp,
+                           in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash, stash_stride);
+    else
+        hipLaunchKernelGGL(mlp_forward16_kernel<false>, dim3(grid_for(n_tiles, 1)), dim3(WG), 0, (hipStream_t)stream, *h_mlp,
+                           in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash, stash_stride);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// S = 2^(8 - ceil(log2(max |d_out|))): the largest gradient entering the backward GEMMs becomes ~256 in fp16, with a
+// factor ~256 of headroom for the layers to amplify it and ~2^-32 of range below (1 when d_out is all zero).
+__global__ void grad_scale_kernel(const float *__restrict__ d, int64_t count, float *__restrict__ scale) {
+    __shared__ float wmax[16];
+    float mx = 0.f;
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) {
+        const float v = fabsf(d[i]);
+        mx = (v < 3.0e38f && v > mx) ? v : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, wmax[w]);
+        float s = 1.f;
+        if (mx > 0.f) {
+            int e;
+            frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
+            e = 8 - e;
+            e = e < -40 ? -40 : (e > 60 ? 60 : e);
+            s = ldexpf(1.f, e);
+        }
+        scale[0] = s;
+    }
+}
+
+extern "C" int nefii_mlp_grad_scale(const float *d_out, int64_t count, float *scale, void *stream) {
+    if (!d_out || !scale || count < 0) return NEFII_E_ARG;
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_out, count, scale);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_backward16_kernel(nefii_mlp m, const float *__restrict__ d_out,
+                                                                int out_stride, const float *__restrict__ stash,
+                                                                int stash_stride, int64_t n, float *__restrict__ dz,
+                                                                int dz_stride, const float *__restrict__ scale) {
+    __shared__ _Float16 Xh[TILE * XS16];
+    const int tid = threadIdx.x;
+    const int Lm1 = m.n_layers - 1;
+    const float S = scale[0];
+    const float inv = 1.f / (W16_SCALE * S);
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * TILE;
+        {   // seed: dz_{L-1} = d_out * head'(pre)
+            const nefii_layer &L = m.layer[Lm1];
+            for (int i = tid; i < TILE * L.n_pad; i += WG) {
+                const int p = i / L.n_pad, c = i - p * L.n_pad;
+                float v = 0.f;
+                if (base + p < n && c < L.n_out) {
+                    const float pre = stash[((size_t)Lm1 * n + base + p) * stash_stride + c];
+                    const float y = head_fwd(pre, m.head);
+                    v = d_out[(size_t)(base + p) * out_stride + c] * head_bwd_from_out(y, pre, m.head);
+                }
+                Xh[p * XS16 + c] = (_Float16)(v * S);
+                if (base + p < n) dz[((size_t)Lm1 * n + base + p) * dz_stride + c] = v;
+            }
+        }
+        __syncthreads();
+        for (int l = Lm1; l >= 1; --l) {
+            const nefii_layer &L = m.layer[l];
+            // dH_{l-1}[32 x k_x] = dZ_l[32 x n_pad] * W_l   (only the hidden block of the inputs)
+            f32x16 acc[4];
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+            const int NTs = (L.k_x + L.k_e) >> 5, ntc = L.k_x >> 5;
+            int ntw = (ntc - wave + 3) >> 2;
+            if (ntw < 0) ntw = 0;
+            zero_acc(acc);
+            gemm_block16<true>(Xh, Xh, XS16, L.n_pad >> 4, reinterpret_cast<const half8 *>(L.w_bwd_f16x3), NTs, wave, lane,
+                               ntw, acc);
+            __syncthreads();
+            NEFII_ACT_SWITCH(m.act, {
+                NEFII_FOR_ACC(acc, ntw, {
+                    const bool live = (base + row) < n;
+                    float v = 0.f;
+                    if (live) {
+                        const float hprev = stash[((size_t)(l - 1) * n + base + row) * stash_stride + col];
+                        v = val * inv * act_bwd_from_out(hprev, ACT);
+                        dz[((size_t)(l - 1) * n + base + row) * dz_stride + col] = v;
+                    }
+                    Xh[row * XS16 + col] = (_Float16)(v * S);
+                })
+            })
+            __syncthreads();
+        }
+    }
+}
+
+extern "C" int nefii_mlp_backward_f16(const nefii_mlp *h_mlp, const float *d_out, int out_stride, const float *stash,
+                                      int stash_stride, int64_t n, float *dz, int dz_stride, const float *scale,
+                                      void *stream) {
+    int rc = check_mlp16(h_mlp, true);
+    if (rc) return rc;
+    if (n <= 0) return 0;
+    if (!d_out || !stash || !dz || !scale) return NEFII_E_ARG;
+    const int64_t n_tiles = (n + TILE - 1) / TILE;
+    hipLaunchKernelGGL(mlp_backward16_kernel, dim3(grid_for(n_tiles, 2)), dim3(WG), 0, (hipStream_t)stream, *h_mlp, d_out,
+                       out_stride, stash, stash_stride, n, dz, dz_stride, scale);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// dW[n][k] = scale * sum_p dz[p][n] * x[p][k] on v_mfma_f32_32x32x16_f16: 16 points per instruction.  A = (S dz)^T
+// fragment (lane (n, p-group): 8 consecutive points), B = x fragment (lane (k, p-group)); fp32 loads (coalesced over the
+// 32 lanes of a point row), converted on the fly.  Same block shape / point split / atomics as mlp_wgrad_kernel.
+__global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const float *__restrict__ dz, int dz_stride,
+                                                          const float *__restrict__ x, int x_stride, int64_t P, int n_out,
+                                                          int k_in, float scale, const float *__restrict__ gscale,
+                                                          float *__restrict__ dW, float *__restrict__ db, int atomic) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 64 + (wave & 1) * 32;
+    const int k0 = blockIdx.y * 256 + (wave >> 1) * 128;
+    const int64_t chunk = ((P + gridDim.z - 1) / gridDim.z + 15) & ~(int64_t)15;
+    const int64_t p_begin = (int64_t)blockIdx.z * chunk;
+    const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;
+    const float S = gscale[0];
+    f32x16 acc[4];
+    zero_acc(acc);
+    const bool n_ok = (n0 + i) < n_out;
+    bool k_ok[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) k_ok[t] = (k0 + 32 * t + i) < k_in;
+    float bsum = 0.f;
+    if (n0 < n_out && k0 < k_in) {
+        // every load is unconditional (clamped address, value selected afterwards): a load behind a runtime condition
+        // makes hipcc branch around it and wait vmcnt(0) per element - 40 dependent round trips per batch
+        const int nc = n_ok ? n0 + i : n_out - 1;
+        int kc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) kc[t] = k_ok[t] ? k0 + 32 * t + i : k_in - 1;
+        const int64_t p_last = p_end - 1;
+        constexpr int U = 2;                       // 16-point batches in flight: all loads of U batches, then their MFMAs
+        for (int64_t pb = p_begin; pb < p_end; pb += 16 * U) {
+            float a[U][8], b[U][4][8];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int64_t p = pb + 16 * u + 8 * h + j;
+                    const int64_t pc = p < p_last ? p : p_last;
+                    a[u][j] = dz[pc * dz_stride + nc];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) b[u][t][j] = x[pc * x_stride + kc[t]];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                half8 af;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool ok = (pb + 16 * u + 8 * h + j) < p_end && n_ok;
+                    const float av = ok ? a[u][j] : 0.f;
+                    bsum += av;
+                    af[j] = (_Float16)(av * S);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    half8 bf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bf[j] = (_Float16)(k_ok[t] ? b[u][t][j] : 0.f);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        const float os = scale / S;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * h, k = k0 + 32 * t + i;
+                if (nn < n_out && k < k_in) {
+                    const float v = acc[t][r] * os;
+                    if (atomic) atomicAdd(&dW[(size_t)nn * k_in + k], v);
+                    else dW[(size_t)nn * k_in + k] = v;
+                }
+            }
+    }
+    if (db && blockIdx.y == 0 && (wave >> 1) == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0 && n_ok) {
+            if (atomic) atomicAdd(&db[n0 + i], bsum);
+            else db[n0 + i] = bsum;
+        }
+    }
+}
+
+extern "C" int nefii_mlp_wgrad_f16(const float *dz, int dz_stride, const float *x, int x_stride, int64_t n, int n_out,
+                                   int k_in, float scale, const float *gscale, float *dW, float *db, void *stream) {
+    if (!dz || !x || !dW || !gscale || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int split = (int)((n + 255) / 256);       // <= 256 points per workgroup
+    if (split < 1) split = 1;
+    if (split > 64) split = 64;
+    if (split > 1 || n <= 0) {
+        const size_t nw = (size_t)n_out * k_in;
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, dW, nw);
+        HIP_CHECK_LAUNCH();
+        if (db) {
+            hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, db, (size_t)n_out);
+            HIP_CHECK_LAUNCH();
+        }
+    }
+    if (n <= 0) return 0;
+    dim3 grid((n_out + 63) / 64, (k_in + 255) / 256, split);
+    hipLaunchKernelGGL(mlp_wgrad16_kernel, grid, dim3(256), 0, st, dz, dz_stride, x, x_stride, n, n_out, k_in, scale, gscale,
+                       dW, db, split > 1 ? 1 : 0);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // SDF value + d sdf / d x  (forward keeps the hidden activations in a workspace; the backward
 // sweep runs in the same workgroup right after, so the workspace lines are still in L2)

@@ -189,8 +189,10 @@ class RenderingNetwork(nn.Module):
         self._pm = None
 
     def packed(self, device):
-        if self._pm is None or self._pm.device != device:
-            self._pm = ops.PackedMLP(self.specs, ops.ACT_RELU, self.head, self.enc, self.feature_vector_size, device)
+        half = ops.mlp_precision() if ops.mlp_precision() in ('f16', 'f16x3') else False
+        if self._pm is None or self._pm.device != device or self._pm.half != half:
+            self._pm = ops.PackedMLP(self.specs, ops.ACT_RELU, self.head, self.enc, self.feature_vector_size, device,
+                                     half=half)
         return self._pm
 
     def forward(self, points, normals, view_dirs, feature_vectors=None):

@@ -165,9 +165,10 @@ class EnvmapMaterialNetwork(nn.Module):
         return (s / 0.16) ** 0.5
 
     def packed(self, device):
-        if self._pm is None or self._pm.device != device:
+        half = ops.mlp_precision() if ops.mlp_precision() in ('f16', 'f16x3') else False
+        if self._pm is None or self._pm.device != device or self._pm.half != half:
             self._pm = ops.PackedMLP(self.specs, ops.ACT_ELU, ops.HEAD_SIGMOID, self.enc, self.feature_vector_size,
-                                     device)
+                                     device, half=half)
         return self._pm
 
     def forward(self, points, feature_vector=None, normal=None):

@@ -56,8 +56,13 @@ class LayerSpec:
 class PackedMLP:
     """Device-resident packed weights + the nefii_mlp descriptor of one fused MLP."""
 
-    def __init__(self, specs, act, head, enc_freqs, feat_width, device, need_bwd=True, f16x3=False):
+    def __init__(self, specs, act, head, enc_freqs, feat_width, device, need_bwd=True, f16x3=False, half=False):
+        """half: the MLP runs on the fp16-MFMA kernels (nefii_mlp_forward_f16 / _backward_f16 / _wgrad_f16; radiance and
+        material networks, never the SDF network) - implies the fp16 fragment sets.  True / 'f16x3': split-precision
+        forward, single-pass backward and weight gradients; 'f16': everything in one fp16 pass."""
         assert 1 <= len(specs) <= _lib.MAX_LAYERS
+        self.half = half if half in ('f16', 'f16x3') else ('f16x3' if half else False)
+        f16x3 = f16x3 or bool(self.half)
         self.specs = specs
         self.act, self.head = act, head
         self.enc_freqs = list(enc_freqs)
@@ -89,7 +94,7 @@ class PackedMLP:
         # SDF nets of the qualifying shape also keep their hidden layers as one fragment stream per wave (the
         # pipelined tile evaluator of the tracer); other nets leave w_stream NULL and run on the generic kernel
         self.w_stream = None
-        if f16x3 and torch.device(device).type == 'cuda':
+        if f16x3 and not self.half and torch.device(device).type == 'cuda':
             # stream layout / matrix instruction of the pipelined evaluator: 0 = 32x32x16 (512-wide nets only),
             # 1 = 16x16x32 (512- and 256-wide nets)
             m.reserved = int(os.environ.get('NEFII_STREAM_LAYOUT', '1'))
@@ -134,6 +139,14 @@ class PackedMLP:
                        'nefii_pack_sdf_stream')
 
 
+def mlp_precision():
+    """Arithmetic of the radiance / material MLPs (NEFII_MLP_PRECISION): 'f16x3' (default) - fp16 MFMA tiles: forward in
+    split precision (hi/lo pairs, fp32-class accuracy), backward and weight gradients in one fp16 pass with a
+    power-of-two gradient scale; 'f16' - the forward in one fp16 pass too (measured 1.3e-3 relative L2 on config 3's RGB:
+    above the north-star bar, for measurement only); 'f32' - the f32-input MFMA kernels (bit-exact fp32 fma chains)."""
+    return os.environ.get('NEFII_MLP_PRECISION', 'f16x3')
+
+
 def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False):
     lib = _lib.lib()
     n = in_a.shape[0]
@@ -147,21 +160,37 @@ def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False)
     if want_stash:
         stash = torch.empty(pm.n_layers, n, pm.hidden_stride, device=dev, dtype=torch.float32)
     if n > 0:
-        _lib.check(lib.nefii_mlp_forward(ctypes.byref(pm.struct), _ptr(in_a), _ptr(in_b), _ptr(in_c), _ptr(feat), n,
-                                         _ptr(out), n_out, _ptr(hidden), hidden.shape[1] if hidden is not None else 0,
-                                         _ptr(stash), pm.hidden_stride, _stream()), 'nefii_mlp_forward')
+        args = (ctypes.byref(pm.struct), _ptr(in_a), _ptr(in_b), _ptr(in_c), _ptr(feat), n, _ptr(out), n_out, _ptr(hidden),
+                hidden.shape[1] if hidden is not None else 0, _ptr(stash), pm.hidden_stride)
+        if pm.half:
+            _lib.check(lib.nefii_mlp_forward_f16(*args, 1 if pm.half == 'f16' else 0, _stream()), 'nefii_mlp_forward_f16')
+        else:
+            _lib.check(lib.nefii_mlp_forward(*args, _stream()), 'nefii_mlp_forward')
     return out, hidden, stash
 
 
-def mlp_backward(pm, d_out, stash):
+def mlp_backward(pm, d_out, stash, gscale=None):
+    """gscale (pm.half): device scalar from mlp_grad_scale(d_out)"""
     lib = _lib.lib()
     n = d_out.shape[0]
     dz = torch.empty(pm.n_layers, n, pm.hidden_stride, device=d_out.device, dtype=torch.float32)
     if n > 0:
-        _lib.check(lib.nefii_mlp_backward(ctypes.byref(pm.struct), _ptr(d_out), d_out.shape[1], _ptr(stash),
-                                          pm.hidden_stride, n, _ptr(dz), pm.hidden_stride, _stream()),
-                   'nefii_mlp_backward')
+        if pm.half:
+            _lib.check(lib.nefii_mlp_backward_f16(ctypes.byref(pm.struct), _ptr(d_out), d_out.shape[1], _ptr(stash),
+                                                  pm.hidden_stride, n, _ptr(dz), pm.hidden_stride, _ptr(gscale), _stream()),
+                       'nefii_mlp_backward_f16')
+        else:
+            _lib.check(lib.nefii_mlp_backward(ctypes.byref(pm.struct), _ptr(d_out), d_out.shape[1], _ptr(stash),
+                                              pm.hidden_stride, n, _ptr(dz), pm.hidden_stride, _stream()),
+                       'nefii_mlp_backward')
     return dz
+
+
+def mlp_grad_scale(d_out):
+    """power-of-two scale that brings max |d_out| to ~256 (device scalar; the fp16 backward GEMMs carry dz x scale)"""
+    s = torch.empty(1, device=d_out.device, dtype=torch.float32)
+    _lib.check(_lib.lib().nefii_mlp_grad_scale(_ptr(d_out), d_out.numel(), _ptr(s), _stream()), 'nefii_mlp_grad_scale')
+    return s
 
 
 def encode_inputs(pm, in_a, in_b, in_c, feat):
@@ -203,7 +232,8 @@ class FusedMLPFn(torch.autograd.Function):
         feat = feat if ctx.has[2] else None
         L = pm.n_layers
         d_out = d_out.contiguous()
-        dz = mlp_backward(pm, d_out, stash)
+        gscale = mlp_grad_scale(d_out) if pm.half else None
+        dz = mlp_backward(pm, d_out, stash, gscale)
         x0 = encode_inputs(pm, in_a, in_b, in_c, feat)
         lib = _lib.lib()
         n = d_out.shape[0]
@@ -221,8 +251,12 @@ class FusedMLPFn(torch.autograd.Function):
                 xin, xs = stash[l - 1], pm.hidden_stride
             g = torch.empty(s.n_out, s.k_in, device=d_out.device, dtype=torch.float32)
             b = torch.empty(s.n_out, device=d_out.device, dtype=torch.float32)
-            _lib.check(lib.nefii_mlp_wgrad(_ptr(dz[l]), pm.hidden_stride, _ptr(xin), xs, n, s.n_out, s.k_in, s.scale,
-                                           _ptr(g), _ptr(b), _stream()), 'nefii_mlp_wgrad')
+            if pm.half:
+                _lib.check(lib.nefii_mlp_wgrad_f16(_ptr(dz[l]), pm.hidden_stride, _ptr(xin), xs, n, s.n_out, s.k_in, s.scale,
+                                                   _ptr(gscale), _ptr(g), _ptr(b), _stream()), 'nefii_mlp_wgrad_f16')
+            else:
+                _lib.check(lib.nefii_mlp_wgrad(_ptr(dz[l]), pm.hidden_stride, _ptr(xin), xs, n, s.n_out, s.k_in, s.scale,
+                                               _ptr(g), _ptr(b), _stream()), 'nefii_mlp_wgrad')
             gw.append(g)
             gb.append(b)
         return (None, None, None, None, None) + tuple(gw) + tuple(gb)
@@ -286,7 +320,7 @@ def coarse_supported(pm):
     return bool(pm.f16x3 and pm.w_stream is not None and _lib.lib().nefii_sdf_coarse_supported(ctypes.byref(pm.struct)))
 
 
-def calibrate_coarse_tau(pm, radius=1.0, n=32768, safety=4.0, seed=0):
+def calibrate_coarse_tau(pm, radius=1.0, n=65536, safety=3.0, seed=0):
     """Error bound of the tracer's coarse pass for THIS network: `safety` x the largest |single-pass - split| SDF value
     over n points drawn uniformly in the bounding sphere (where the tracer samples), at least 1e-4.  0.0 when the net
     has no single-pass stream.  One host sync; callers cache it per packed weight version (geometry is frozen)."""

@@ -237,15 +237,15 @@ class IDRTrainRunner:
             self.train_sampler_generator.manual_seed(epoch)
             resample = getattr(self.loss, 'sample_each_iter', False)
 
-            def batches():       # two batches of lookahead: TrainStep traces them beside the tail of the current one
+            def batches():       # three batches of lookahead: TrainStep traces them beside the tail of the current one
                 window = []
                 for item in self.train_dataloader:
                     if resample:
                         self._resample()
                     window.append((item[0], {k: v.to(self.device) for k, v in item[1].items()},
                                    {'rgb': item[2]['rgb'].to(self.device)}))
-                    if len(window) == 3:
-                        yield window[0], (None if resample else [window[1][1], window[2][1]])
+                    if len(window) == 4:
+                        yield window[0], (None if resample else [w[1] for w in window[1:]])
                         window.pop(0)
                 while window:
                     yield window[0], (None if resample or len(window) == 1 else [w[1] for w in window[1:]])

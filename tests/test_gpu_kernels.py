@@ -113,9 +113,16 @@ def test_sdf_eval_split_precision(name, hidden, n):
         assert (out - f32).abs().max().item() < 1e-5
 
 
-@pytest.mark.parametrize('name,hidden,n', [('physg', 64, 500), ('conf', 64, 301), ('conf', 512, 200), ('physg', 512, 64)])
-def test_radiance_and_material_mlp(name, hidden, n):
+@pytest.mark.parametrize('half', [False, 'f16x3', 'f16'])
+@pytest.mark.parametrize('name,hidden,n', [('physg', 64, 500), ('conf', 64, 301), ('conf', 512, 200), ('physg', 512, 64),
+                                           ('conf', 512, 3000)])
+def test_radiance_and_material_mlp(name, hidden, n, half):
+    """half=False: the f32-input MFMA kernels (bit-exact fp32 fma chains) at fp32 tolerances.  'f16x3' (the renderer's
+    default): fp16 MFMA tiles - split-precision forward (outputs at fp32 tolerance), one-pass fp16 backward / weight
+    gradients with their tiny magnitudes carried by nefii_mlp_grad_scale (3e-2: weight-norm's projection amplifies the
+    ~1e-3 error of a one-pass GEMM).  'f16': the forward in one pass too (outputs within 1e-3)."""
     from nefii_amd import ops
+    tol_out, tol_grad = {False: (2e-5, 2e-4), 'f16x3': (2e-5, 3e-2), 'f16': (1e-3, 6e-2)}[half]
     mc = syn.model_conf(name, hidden=hidden)
     sd = syn.make_state_dict(mc, seed=1)
     F = mc['feature_vector_size']
@@ -134,19 +141,24 @@ def test_radiance_and_material_mlp(name, hidden, n):
     rgb_ref = nets.radiance_forward(sd, mc['rendering_network'], x, nrm, v, feat)
     (rgb_ref * w1).sum().backward()
     specs, enc, head = ops.radiance_specs(mc['rendering_network'], F)
-    pm = ops.PackedMLP(specs, ops.ACT_RELU, head, enc, F, DEV)
+    pm = ops.PackedMLP(specs, ops.ACT_RELU, head, enc, F, DEV, half=half)
     L = len(specs)
     gv = [sd['rendering_network.lin%d.weight_v' % l].detach().to(DEV).requires_grad_(True) for l in range(L)]
     gg = [sd['rendering_network.lin%d.weight_g' % l].detach().to(DEV).requires_grad_(True) for l in range(L)]
     gb = [sd['rendering_network.lin%d.bias' % l].detach().to(DEV).requires_grad_(True) for l in range(L)]
     ws = [torch._weight_norm(gv[l], gg[l], 0) for l in range(L)]
     rgb = ops.FusedMLPFn.apply(pm, x.to(DEV), v.to(DEV), nrm.to(DEV), feat.to(DEV) if F else None, *ws, *gb)
-    assert rel_l2(rgb, rgb_ref) < 2e-5
-    (rgb * w1.to(DEV)).sum().backward()
+    assert rel_l2(rgb, rgb_ref) < tol_out, rel_l2(rgb, rgb_ref)
+    # gradients as small as in training (d loss / d rgb ~ 1e-6 per ray): far below fp16's normal range
+    gs = 1e-6 if half else 1.0
+    half_name = half or 'f32'
+    (rgb * w1.to(DEV)).sum().mul(gs).backward()
+    worst = 0.0
     for l in range(L):
-        assert rel_l2(gv[l].grad, sd['rendering_network.lin%d.weight_v' % l].grad) < 2e-4, l
-        assert rel_l2(gg[l].grad, sd['rendering_network.lin%d.weight_g' % l].grad) < 2e-4, l
-        assert rel_l2(gb[l].grad, sd['rendering_network.lin%d.bias' % l].grad) < 2e-4, l
+        for got, key in ((gv[l], 'weight_v'), (gg[l], 'weight_g'), (gb[l], 'bias')):
+            want = sd['rendering_network.lin%d.%s' % (l, key)].grad * gs
+            worst = max(worst, rel_l2(got.grad, want))
+            assert rel_l2(got.grad, want) < tol_grad, (l, key, rel_l2(got.grad, want))
     # ---- material
     mcfg = mc['envmap_material_network']
     lp = 'envmap_material_network.diffuse_albedo_layers'
@@ -160,21 +172,24 @@ def test_radiance_and_material_mlp(name, hidden, n):
     tgt.backward()
     dim_out = 4 if mcfg.get('roughness_mlp') else 3
     specs, enc = ops.material_specs(mcfg, F, dim_out)
-    pm = ops.PackedMLP(specs, ops.ACT_ELU, ops.HEAD_SIGMOID, enc, F, DEV)
+    pm = ops.PackedMLP(specs, ops.ACT_ELU, ops.HEAD_SIGMOID, enc, F, DEV, half=half)
     L = len(specs)
     W = [sd['%s.%d.weight' % (lp, 2 * l)].detach().to(DEV).requires_grad_(True) for l in range(L)]
     Bz = [sd['%s.%d.bias' % (lp, 2 * l)].detach().to(DEV).requires_grad_(True) for l in range(L)]
     y = ops.FusedMLPFn.apply(pm, x.to(DEV), None, None, feat.to(DEV) if F else None, *W, *Bz)
-    assert rel_l2(y[:, :3], mat['sg_diffuse_albedo']) < 2e-5
+    assert rel_l2(y[:, :3], mat['sg_diffuse_albedo']) < tol_out, rel_l2(y[:, :3], mat['sg_diffuse_albedo'])
     t2 = (y[:, :3] * w1.to(DEV)).sum()
     if dim_out == 4:
         rough = (1 - 0.089) * y[:, 3:4] + 0.089
-        assert rel_l2(rough, mat['sg_roughness']) < 2e-5
+        assert rel_l2(rough, mat['sg_roughness']) < tol_out
         t2 = t2 + rough.sum()
-    t2.backward()
+    t2.mul(gs).backward()
     for l in range(L):
-        assert rel_l2(W[l].grad, sd['%s.%d.weight' % (lp, 2 * l)].grad) < 2e-4, l
-        assert rel_l2(Bz[l].grad, sd['%s.%d.bias' % (lp, 2 * l)].grad) < 2e-4, l
+        for got, key in ((W[l], 'weight'), (Bz[l], 'bias')):
+            want = sd['%s.%d.%s' % (lp, 2 * l, key)].grad * gs
+            worst = max(worst, rel_l2(got.grad, want))
+            assert rel_l2(got.grad, want) < tol_grad, (l, key, rel_l2(got.grad, want))
+    print('[mlp %s h%d n%d %s] worst parameter-gradient rel-L2 %.2e' % (name, hidden, n, half_name, worst))
 
 
 def test_camera_rays(golden):

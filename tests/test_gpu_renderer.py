@@ -519,7 +519,7 @@ def test_bench_two_processes_share_one_gpu():
     assert d['config']['primary_rays_per_step_per_gpu'] == 4096
     assert d['config']['rank_param_spread'] < 1e-9       # both ranks hold the same parameters after 8+ synchronised steps
     # the nested config-3 measurement ran on both ranks too (MC shading, secondary-consistency step, its own all-reduces)
-    assert d['cfg3']['value'] > 0 and d['cfg3']['config']['rank_param_spread'] < 1e-9
+    assert d['cfg3']['value'] > 0 and d['cfg3']['config']['rank_param_spread'] < 1e-9, (d['cfg3']['config'], d['config'])
     assert d['cfg3']['roofline']['secondary_hit_fraction'] > 0.2 and 0 < d['roofline']['frac_step'] < d['roofline']['frac_kernel']
 
 
