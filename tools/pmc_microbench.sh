@@ -16,8 +16,9 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: [0.0, 0])
 for r in csv.DictReader(open(sys.argv[1])):
     if 'sdf_points' in r['Kernel_Name']:
-        a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
-for k, (v, n) in acc.items():
-    print('%-32s %16.0f  (avg over %d launches)' % (k, v / n, n))
+        kind = 'single pass (16s)' if 'kernel16s' in r['Kernel_Name'] else 'split (16q)'
+        a = acc[(kind, r['Counter_Name'])]; a[0] += float(r['Counter_Value']); a[1] += 1
+for (kind, k), (v, n) in sorted(acc.items()):
+    print('%-18s %-32s %16.0f  (avg over %d launches)' % (kind, k, v / n, n))
 PY
 done

@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 TAG=${1:-r02}; WL=${2:-cfg2}; KERN=${3:-eval_kernel16}; STEPS=${4:-20}
-O=gpurun_out/$TAG; S=/tmp/prof_$TAG
+O=gpurun_out/$TAG; S=/tmp/prof_${TAG}_$WL; rm -rf $S
 mkdir -p $O $S
 python3 bench.py --workload $WL --steps $STEPS --warmup 3 > $O/bench_$WL.json 2> $O/bench_err.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $S/ks -- python3 bench.py --workload $WL --steps $STEPS --warmup 3 --no-cpu-baseline --no-side-measurement > $O/bench_${WL}_under_rocprof.json 2> $O/ks_err.log

@@ -40,12 +40,13 @@ for it in range(3):
 cnt = m.ray_tracer.last_counters.cpu().tolist()
 NODES = 2 ** (m.ray_tracer.bisect_levels or (5 if dirs.shape[1] <= 16384 else 3)) - 1
 tot = 0.0
-print('round  singles  dense  tri  consumed  queries   tiles   ms    us/tile')
+print('round  singles  dense  tri(consumed)  refined  coarse rays | split-precision queries  coarse samples |   ms')
 for r in range(n):
-    q = cnt[r][0] + cnt[r][1] * 100 + cnt[r][2] * NODES
-    tiles = (q + 31) // 32
+    c = cnt[r]
+    split = c[0] + c[1] * 100 + c[2] * NODES + c[4]
+    coarse = c[5] * 100
     tot += buf[r]
-    if q:
-        print('%4d %8d %6d %5d %8d %9d %7d %7.3f %8.2f' % (r, cnt[r][0], cnt[r][1], cnt[r][2], cnt[r][3], q, tiles,
-                                                          buf[r], buf[r] * 1e3 / max(tiles, 1)))
-print('total eval ms %.3f over %d launches' % (tot, n))
+    if split or coarse:
+        print('%4d %8d %6d %5d(%6d) %8d %11d | %23d %15d | %6.3f' % (r, c[0], c[1], c[2], c[3], c[4], c[5], split, coarse,
+                                                                   buf[r]))
+print('total eval ms %.3f over %d launches (a launch = the round\'s split-precision dispatches + its coarse dispatch)' % (tot, n))
