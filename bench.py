@@ -214,8 +214,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     # (2) roofline of the dominant kernel: one extra step with per-launch HIP events; only rank 0 instruments it
     model.ray_tracer.counter_sum = None
     model.ray_tracer.stream_groups = 1      # the profiled step runs the rounds back to back on one stream
-    if nxt is not None and not model.ray_tracer.bisect_levels:
-        model.ray_tracer.bisect_levels = 3  # as the timed steps' traces run (TrainStep.prefetch_trace): same rounds per step
+    model.ray_tracer.concurrent = nxt is not None   # as the timed steps' traces run (TrainStep.prefetch_trace): same rounds per step
     if rank == 0:
         lib.nefii_trace_profile_enable(1)
     torch.cuda.synchronize()
@@ -245,8 +244,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     # algorithmic evaluations (what the reference's recurrences need) vs executed (incl. the unused nodes of the
     # speculative bisection tree and the coarse pass's refined samples); the roofline credits only the algorithmic ones
     queries = int(ops.algorithmic_evals(cnt, n_steps).sum().item())
-    nodes = 2 ** (model.ray_tracer.bisect_levels or (5 if rays_per_rank <= 16384 else 3)) - 1
-    ex_split, ex_coarse = ops.executed_evals(cnt, n_steps, nodes)
+    ex_split, ex_coarse = ops.executed_evals(cnt, n_steps)
     executed, executed_coarse = int(ex_split.sum().item()), int(ex_coarse.sum().item())
     launches = int((cnt[:, [0, 1, 2, 4, 5]].sum(dim=1) > 0).sum().item())
     f_eval = mlp_flops(model.implicit_network.specs)

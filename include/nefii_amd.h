@@ -207,9 +207,10 @@ int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
  * receives per round: [r][0] single queries, [r][1] rays with n_steps dense queries in split precision, [r][2] rays in
  * bisection (2^levels - 1 speculative queries each), [r][3] bisection evaluations actually consumed, [r][4] coarse-pass
  * samples re-evaluated in split precision, [r][5] rays with n_steps dense queries in the single-pass (coarse) evaluator,
- * [r][6] rays entering a dense search (the reference evaluates n_steps samples for each), [r][7] reserved.
+ * [r][6] rays entering a dense search (the reference evaluates n_steps samples for each), [r][7] = (2^levels - 1)*[2],
+ * the speculative bisection evaluations executed.
  * Algorithmic evaluations (what the reference's recurrences need) = [0] + n_steps*[6] + [3]; executed in split
- * precision = [0] + n_steps*[1] + (2^levels - 1)*[2] + [4]; executed in the coarse evaluator = n_steps*[5]. */
+ * precision = [0] + n_steps*[1] + [7] + [4]; executed in the coarse evaluator = n_steps*[5]. */
 int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
                      const float *origins, const float *dirs, const uint8_t *object_mask, int64_t n_rays,
                      const float *lin_steps, const float *minsdf_steps,

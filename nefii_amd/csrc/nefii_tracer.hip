@@ -111,6 +111,7 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
         base[3] = t[4] ? atomicAdd(&cnt[4], t[4]) : 0;
         base[4] = t[5] ? atomicAdd(&cnt[5], t[5]) : 0;
         if (t[6]) atomicAdd(&cnt[6], t[6]);
+        if (t[2]) atomicAdd(&cnt[7], t[2] * P.tri_nodes);      // speculative bisection evaluations executed
     }
     __syncthreads();
     int off_s = base[0], off_d = base[1], off_t = base[2], off_r = base[3], off_c = base[4];

@@ -29,7 +29,9 @@ class RayTracing(nn.Module):
         self.collect_counters = False
         self.minsdf_steps_override = None     # parity tests replay the reference's captured uniforms
         self._calls = 0
-        self.bisect_levels = int(os.environ.get('NEFII_BISECT_LEVELS', '0'))   # 0 = automatic: 5 for batches up to 16 k rays (latency-bound), else 3
+        # speculative bisection levels per round, 0 = automatic (auto_levels)
+        self.bisect_levels = int(os.environ.get('NEFII_BISECT_LEVELS', '0'))
+        self.concurrent = False       # this trace runs beside other work (TrainStep.prefetch_trace): throughput-bound
         self.adaptive_rounds = True     # skip the trailing empty rounds (ops.TraceRounds)
         self._rounds_state = {}
         # concurrent ray chunks on separate streams (ops.trace_rays): measured on config 2, 1/2/3/4 chunks give
@@ -51,6 +53,19 @@ class RayTracing(nn.Module):
         self.coarse = os.environ.get('NEFII_TRACER_COARSE', '1') != '0'
         self.coarse_tau_override = None
         self.coarse_cap = int(os.environ.get('NEFII_TRACER_COARSE_CAP', '0'))
+
+    @staticmethod
+    def auto_levels(n_rays, concurrent=False):
+        """Bisection steps resolved per round (2^levels - 1 speculative evaluations per ray and round, bit-identical
+        result).  A lone small batch is latency-bound: 5 levels (32 steps in 7 rounds, 31 nodes per ray and round).  A batch
+        that fills the chip on its own is throughput-bound: every wasted node costs as much as a needed one, a round costs
+        next to nothing - 1 level, no speculation (config 3: 308 -> 289 ms per step, config 4: 293 -> 278).  In between,
+        and for traces that run beside other work, 3."""
+        if n_rays >= 131072:
+            return 1
+        if concurrent or n_rays > 16384:
+            return 3
+        return 5
 
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
@@ -92,7 +107,7 @@ class RayTracing(nn.Module):
                 # when some ray needs the search, a data-dependent host sync this build avoids)
                 steps = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
         n_rays = dirs.shape[0]
-        levels = self.bisect_levels or (5 if n_rays <= 16384 else 3)
+        levels = self.bisect_levels or self.auto_levels(n_rays, self.concurrent)
         tau = 0.0
         # (batches of up to 1024 rays are latency-bound - a handful of tiles per round: the coarse pass's extra round per
         # dense search costs them more than its cheaper samples save; config 1: 2.39 vs 2.2 ms per step)
@@ -112,5 +127,11 @@ class RayTracing(nn.Module):
                              deferred=self.deferred_checks if state is not None else None)
         if self.collect_counters:
             self.last_counters = res[3]
-            self.counter_sum = res[3].clone() if self.counter_sum is None else self.counter_sum + res[3]
+            cur = res[3]
+            if self.counter_sum is not None and self.counter_sum.shape[0] != cur.shape[0]:
+                # traces of one step differ in their round budget (bisection levels by batch size, coarse pass or not)
+                n = max(self.counter_sum.shape[0], cur.shape[0])
+                pad = lambda t: torch.cat([t, t.new_zeros(n - t.shape[0], t.shape[1])]) if t.shape[0] < n else t
+                self.counter_sum, cur = pad(self.counter_sum), pad(cur)
+            self.counter_sum = cur.clone() if self.counter_sum is None else self.counter_sum + cur
         return res[0], res[1], res[2]

@@ -287,13 +287,13 @@ class TrainStep:
             m.ray_tracer.deferred_checks = checks       # no host sync inside the trace: its round-prefix check waits
             # traces that run beside other work are throughput-bound, not latency-bound: 3 speculative bisection levels
             # (7 nodes per ray and round) instead of the 5 (31 nodes) a lone small batch prefers - fewer wasted queries,
-            # a few more rounds, bit-identical result (config 2: 4.78 vs 5.02 ms per step)
-            levels, m.ray_tracer.bisect_levels = m.ray_tracer.bisect_levels, m.ray_tracer.bisect_levels or 3
+            # a few more rounds, bit-identical result (config 2: 4.78 vs 5.02 ms per step); RayTracing.auto_levels decides
+            m.ray_tracer.concurrent = True
             try:
                 ctx = m.trace_points(model_input) if self.surface_in_tail else m.trace_head(model_input)
             finally:
                 m.ray_tracer.deferred_checks = None
-                m.ray_tracer.bisect_levels = levels
+                m.ray_tracer.concurrent = False
             ev = self._trace_stream.record_event()
         self._prefetch.append((model_input, ctx, ev, checks))
 

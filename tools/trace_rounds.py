@@ -38,12 +38,11 @@ for it in range(3):
     n = lib.nefii_trace_profile_launches(buf, 256)
     lib.nefii_trace_profile_enable(0)
 cnt = m.ray_tracer.last_counters.cpu().tolist()
-NODES = 2 ** (m.ray_tracer.bisect_levels or (5 if dirs.shape[1] <= 16384 else 3)) - 1
 tot = 0.0
 print('round  singles  dense  tri(consumed)  refined  coarse rays | split-precision queries  coarse samples |   ms')
 for r in range(n):
     c = cnt[r]
-    split = c[0] + c[1] * 100 + c[2] * NODES + c[4]
+    split = c[0] + c[1] * 100 + c[7] + c[4]
     coarse = c[5] * 100
     tot += buf[r]
     if split or coarse:
