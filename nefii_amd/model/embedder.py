@@ -1,7 +1,8 @@
 """Positional encoding (reference code/model/embedder.py:5-50).
 
-The HIP kernels encode raw 3-vectors themselves (mlp_tile.h: encode_tile); this torch version exists for API
-parity (``get_embedder(multires)`` -> (fn, out_dim)) and for host-side tools."""
+The HIP kernels encode raw 3-vectors themselves (mlp_tile.h: encode_tile); this torch version is what the
+trainable-geometry slow path (model/trainable_geometry.py) differentiates through, with the reference's
+``get_embedder(multires)`` -> (fn, out_dim) signature."""
 import torch
 
 

@@ -17,6 +17,7 @@ Scope: Step-2 with frozen geometry (``freeze_geometry()``; every shipped Step-2 
 for the closed-form ``sg`` render type (model/trainable_geometry.py).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -333,7 +334,7 @@ class IDRNetwork(nn.Module):
             # Small batches (<= one 32-point tile per CU) are latency-bound: one value+feature+gradient pass over ALL
             # rays costs the same as the pass over the hits alone and replaces the separate SDF forward.
             pre = None
-            if points.shape[0] <= 32 * 256:
+            if points.shape[0] <= int(os.environ.get('NEFII_SURFACE_ALL_MAX', str(32 * 256))):
                 pre = self.implicit_network.value_feature_gradient(points)
                 sdf_output = pre[0]
             else:

@@ -24,13 +24,11 @@ TINY_NUMBER = 1e-6
 
 
 def embed(x, n_freqs):
-    """embedder.py:21-31: x, sin(2^k x), cos(2^k x), k < L"""
+    """embedder.py:21-31: x, sin(2^k x), cos(2^k x), k < L (the torch embedder of model/embedder.py)"""
     if n_freqs <= 0:
         return x
-    parts = [x]
-    for k in range(n_freqs):
-        parts += [torch.sin(x * float(2 ** k)), torch.cos(x * float(2 ** k))]
-    return torch.cat(parts, dim=-1)
+    from .embedder import get_embedder
+    return get_embedder(n_freqs)[0](x)
 
 
 def _weights(module, n):

@@ -85,3 +85,12 @@ def test_reference_conf_files_parse():
         from nefii_amd.utils import general
         assert general.get_class(c.get_string('train.model_class')).__name__ == 'IDRNetwork'
         assert general.get_class(c.get_string('train.dataset_class')).__name__ == 'SceneDataset'
+
+
+def test_tracer_bisection_levels_follow_the_batch_size():
+    """RayTracing.auto_levels: 5 speculative bisection levels for a lone latency-bound batch, 3 for mid-size batches and
+    for traces that run beside other work, none (1 level per round) once the batch fills the chip on its own."""
+    from nefii_amd.model.ray_tracing import RayTracing
+    assert RayTracing.auto_levels(512) == 5 and RayTracing.auto_levels(16384) == 5
+    assert RayTracing.auto_levels(4096, concurrent=True) == 3 and RayTracing.auto_levels(65536) == 3
+    assert RayTracing.auto_levels(131072) == 1 and RayTracing.auto_levels(786432, concurrent=True) == 1

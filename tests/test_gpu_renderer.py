@@ -452,6 +452,17 @@ def test_runner_checkpoint_layout_and_resume(tmp_path, graph):
         if a[k].dtype.is_floating_point:
             assert rel_l2(b[k], a[k]) < tol, (k, rel_l2(b[k], a[k]))
     assert abs(float(cont.step.idr_optimizer.param_groups[0]["lr"]) - 5e-4 * 0.25) < 1e-9      # fp32 tensor in graph mode
+    if not graph:
+        # a checkpoint written by an EAGER run (python-float lr, capturable=False, CPU step counters - what a reference
+        # checkpoint looks like) continued in GRAPH mode: the captured Adam needs capturable state (TrainStep.retensor_lr)
+        g = make(expname='part', max_niters=15, is_continue=True, timestamp='t0', new_timestamp='t2', graph=True)
+        assert g.step.graph and g.step.cur_iter == 8
+        g.run()
+        assert g.step.cur_iter == 16 and len(g.step._graphs) >= 1
+        c = g.model.state_dict()
+        for k in a:
+            if a[k].dtype.is_floating_point:
+                assert torch.isfinite(c[k]).all() and rel_l2(c[k], a[k]) < 1e-2, (k, rel_l2(c[k], a[k]))
 
 
 def test_exp_runner_command_line(tmp_path):
