@@ -141,7 +141,11 @@ int nefii_encode_inputs(const nefii_mlp *h_mlp, const float *in_a, const float *
 
 /* SDF value, optional last-hidden feature, and d sdf / d x in one pass
  * (replaces implicit_network(points) + ImplicitNetwork.gradient, implicit_differentiable_renderer.py:110-123,
- * 533-540; the reference runs three SDF passes on the same points).  `ws` holds n*(n_layers-1)*512 floats. */
+ * 533-540; the reference runs three SDF passes on the same points).  `ws`: nefii_sdf_value_grad_workspace_bytes(h_mlp, n)
+ * bytes - n*(n_layers-1)*512 floats for the generic 32-row kernels; one 128 KiB slot per hidden layer and workgroup
+ * (at most 256 workgroups) for 512-wide softplus nets with a one-column last layer, a fragment stream (w_stream) and
+ * transposed fragments on every layer, which run forward AND backward on the stream (64-row tiles, the tracer's
+ * split-precision evaluator followed by the same k-loop over the transposed layers). */
 int nefii_sdf_value_grad(const nefii_mlp *h_mlp, const float *x, int64_t n, float *sdf_out, int out_stride,
                          float *feat_out, int feat_stride, float *grad_out, float *ws, void *stream);
 size_t nefii_sdf_value_grad_workspace_bytes(const nefii_mlp *h_mlp, int64_t n);
@@ -178,6 +182,9 @@ typedef struct nefii_tracer_params {
  * (hi/lo of two of the wave's four 16-feature tiles, alternating between the halves of a 32-deep k-step).
  * With reserved == 1 a third copy follows for the single-pass (coarse) evaluator: hi fragments only, one 32-deep k-step
  * of the wave's feature tiles per unit, K zero-padded to multiples of 128.
+ * When every layer also carries transposed fragments (w_bwd_f16x3) and the last layer has one column, a fourth copy
+ * follows for nefii_sdf_value_grad: per wave the forward units again, then for l = n_layers-2 .. 1 the 16-deep units of
+ * the transposed layer (the wave's 64 hidden inputs as output features) - one cursor runs forward and backward.
  * nefii_sdf_stream_bytes: size of that buffer, 0 if the net's shape does not qualify (every hidden layer 512 wide,
  * k_x in {0,512}, k_e in {0,64}, 512-deep last layer) - such nets run on the generic kernel and leave w_stream NULL.
  * nefii_pack_sdf_stream: device-side copy from the layers' w_f16x3 (call after nefii_pack_linear_f16x3). */

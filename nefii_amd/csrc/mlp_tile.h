@@ -1117,6 +1117,10 @@ __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, f
     const int NH = m.n_layers - 1;
     const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
     const float k16 = inv_scale * A16_SCALE;
+    // a layer's bias is fetched one layer ahead (behind the previous k-loop): read at the top of its own layer it would
+    // sit behind the next layer's prefetched fragments in vmcnt order and the epilogue would open with a vmcnt(0)
+    const int boff = 16 * FT * wave + (lane & (16 * FT - 1));
+    float bnext = m.layer[0].bias[boff];
     encode_tile16q<FT>(m, raw, lds, 16 * QT);
     __syncthreads();
     const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4), *ql0 = lds.Xl + (lane & 15) * XP + 8 * (lane >> 4);
@@ -1124,11 +1128,11 @@ __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, f
         const nefii_layer &L = m.layer[l];
         const int units = NB == 8 ? q_units8(L) : q_units<FT>(L);
         const _Float16 *ah = qh0 + (EP - L.k_x), *al = ql0 + (EP - L.k_x);
-        const float *bp = L.bias + 16 * FT * wave + (lane & (16 * FT - 1));
+        const float *bp = m.layer[l + 1 < NH ? l + 1 : l].bias + boff;
         asm volatile("" ::"s"(units), "v"(ah), "v"(al), "v"(bp));
         __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see 16p)
         __builtin_amdgcn_sched_barrier(0);
-        const float bvec = *bp;
+        const float bvec = bnext;
         f32x4 acc[FT * QT];
 #pragma unroll
         for (int j = 0; j < FT * QT; ++j)
@@ -1140,6 +1144,8 @@ __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, f
             qgemm8<QT>(units, b, a, cur, ah, al, acc);
         else
             qgemm<QT, FT>(units, b, a, cur, ah, al, acc);
+        bnext = *bp;
+        __builtin_amdgcn_sched_barrier(0);
         half4 phi[FT * QT], plo[FT * QT];
         if (m.act == NEFII_ACT_SOFTPLUS100)
             qepilogue<QT, FT, true>(acc, bvec, k16, lane, m.act, phi, plo);
@@ -1375,6 +1381,8 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT
     const int NH = m.n_layers - 1;
     const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
     const float k16 = inv_scale * A16_SCALE;
+    const int boff = 16 * FT * wave + (lane & (16 * FT - 1));
+    float bnext = m.layer[0].bias[boff];        // biases run one layer ahead (see sdf_tile16q)
     encode_tile16s<FT, 16 * QT>(m, raw, lds, 16 * QT);
     __syncthreads();
     const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4);
@@ -1382,19 +1390,23 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT
         const nefii_layer &L = m.layer[l];
         const int units = s_units(L);
         const _Float16 *ah = qh0 + (EP - L.k_x);
-        const float *bp = L.bias + 16 * FT * wave + (lane & (16 * FT - 1));
+        const float *bp = m.layer[l + 1 < NH ? l + 1 : l].bias + boff;
         asm volatile("" ::"s"(units), "v"(ah), "v"(bp));
         __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see 16p)
         __builtin_amdgcn_sched_barrier(0);
-        const float bvec = *bp;
+        const float bvec = bnext;
         f32x4 acc[FT * QT];
 #pragma unroll
         for (int j = 0; j < FT * QT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
         SAct<QT> a[DB ? 2 : 1];
+        NEFII_STAMP(0);
         if constexpr (DB) sload_a<QT, XP>(a[0], ah, 0);
         sgemm<QT, FT, DB>(units, b, a, cur, ah, acc);
+        bnext = *bp;
+        __builtin_amdgcn_sched_barrier(0);
+        NEFII_STAMP(1);
         _Float16 *xh = lds.Xh + (EP - L.n_pad);
         if constexpr (DB) {
             // epilogue arithmetic ahead of the barrier (it overlaps the SIMD partner's k-loop), packed results parked in
@@ -1404,7 +1416,9 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT
                 sepilogue<QT, FT, true>(acc, bvec, k16, lane, m.act, phi);
             else
                 sepilogue<QT, FT, false>(acc, bvec, k16, lane, m.act, phi);
+            NEFII_STAMP(2);
             __syncthreads();
+            NEFII_STAMP(3);
 #pragma unroll
             for (int ft = 0; ft < FT; ++ft) {
                 const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
@@ -1417,7 +1431,9 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT
         } else {
             // big tiles: no registers to park the packed results in - the whole epilogue runs behind the barrier, each
             // feature tile's values stored as they are produced
+            NEFII_STAMP(2);
             __syncthreads();
+            NEFII_STAMP(3);
             const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
             auto body = [&](auto fast) {        // the activation id resolved once per layer, not per value (see pepilogue)
 #pragma unroll
@@ -1454,6 +1470,7 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT
                 body(std::false_type{});
         }
         __syncthreads();
+        NEFII_STAMP(4);
     }
     // last layer, column 0 only: hi fragments of the layer's own w_f16x3 (32x32x16), K split over the waves
     {
@@ -1508,5 +1525,12 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT
             }                                                                             \
         }                                                                                 \
     }
+
+// nefii_sdf_value_grad on the pipelined fragment stream (defined beside the stream code in nefii_tracer.hip):
+// value_grad_stream_ws_bytes: workspace of the streamed kernel for n points, 0 when the net does not take it;
+// value_grad_stream_launch: NEFII_E_UNSUPPORTED when it does not.
+size_t value_grad_stream_ws_bytes(const nefii_mlp *m, int64_t n);
+int value_grad_stream_launch(const nefii_mlp *m, const float *x, int64_t n, float *sdf_out, int out_stride, float *feat_out,
+                             int feat_stride, float *grad_out, float *ws, hipStream_t st);
 
 }  // namespace nefii

@@ -1044,6 +1044,7 @@ static int sdf_ws_stride(const nefii_mlp *m) {
 
 extern "C" size_t nefii_sdf_value_grad_workspace_bytes(const nefii_mlp *h_mlp, int64_t n) {
     if (!h_mlp || n <= 0) return 0;
+    if (const size_t b = value_grad_stream_ws_bytes(h_mlp, n)) return b;     // the streamed kernel's per-workgroup slots
     return (size_t)(h_mlp->n_layers - 1) * (size_t)n * sdf_ws_stride(h_mlp) * sizeof(float);
 }
 
@@ -1059,6 +1060,9 @@ extern "C" int nefii_sdf_value_grad(const nefii_mlp *h_mlp, const float *x, int6
     for (int l = 0; l < h_mlp->n_layers; ++l)
         split = split && h_mlp->layer[l].w_f16x3 && h_mlp->layer[l].w_bwd_f16x3;
     const int64_t n_tiles = (n + TILE - 1) / TILE;
+    if (split && value_grad_stream_ws_bytes(h_mlp, n))      // 512-wide nets with a fragment stream: the pipelined kernel
+        return value_grad_stream_launch(h_mlp, x, n, sdf_out, out_stride, feat_out, feat_stride, grad_out, ws,
+                                        (hipStream_t)stream);
     if (split) {        // both fp16 hi/lo fragment sets present: the split-precision kernel
         hipLaunchKernelGGL(sdf_value_grad16_kernel, dim3(grid_for(n_tiles, 1)), dim3(WG), 0, (hipStream_t)stream,
                            *h_mlp, x, n, sdf_out, out_stride, feat_out, feat_stride, grad_out, ws,

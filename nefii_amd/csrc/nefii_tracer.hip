@@ -894,6 +894,10 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, cons
         }
         __syncthreads();
         sdf_tile16s<QT, FT, DB>(m, lds, raw, dest, b, cur);
+#ifdef NEFII_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamp_tile = g_stamp_tile + 1;
+        __syncthreads();
+#endif
     }
 }
 
@@ -1009,8 +1013,9 @@ int stream_steps8(const nefii_mlp *m) {
 // + f) + (lane&15)][k = 32 s32 + 8 (lane>>4) + j], gathered from the layer's 32x32x16 fragments (one source half8 per
 // destination half8).  256-wide: unit g is a whole 32-deep k-step of the layer's K padded to a multiple of 128,
 // n = 32 wave + 16 f + (lane&15); k-steps past the layer's own K hold zeros.
-__global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int G, int ft, int padded) {
-    const int g = blockIdx.x, wave = blockIdx.y;
+// Gw: units per wave of the destination copy (G, or more when other units follow in the same copy).
+__global__ void pack_sdf_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int Gw, int ft, int padded) {
+    const int g = blockIdx.x, wave = blockIdx.y, G = Gw;
     int l = 0, s = g;
     while (s >= (padded ? q_units8(m.layer[l]) : layer_units_dev(m.layer[l], ft)))
         s -= padded ? q_units8(m.layer[l]) : layer_units_dev(m.layer[l], ft), ++l;
@@ -1065,6 +1070,339 @@ int stream_steps_sp(const nefii_mlp *m) {
     int G = 0;
     for (int l = 0; l < m->n_layers - 1; ++l) G += s_units(m->layer[l]);
     return G;
+}
+
+// ---- fourth copy: the value + gradient kernel's stream (sdf_value_grad16q_kernel) ------------------------------------------
+// 512-wide softplus nets with a one-column last layer and transposed fragments on every layer.  Per wave: the forward
+// units of the plain 16x16x32 stream, then the BACKWARD units - for l = NH-1 .. 1 the half steps of the transposed layer
+// (contraction over layer l's 512 outputs, the wave's 64 of its 512 hidden inputs as output features), gathered from
+// nefii_layer.w_bwd_f16x3 - so that one cursor runs forward, backward, and wraps to the next tile's forward.
+bool vg_shape(const nefii_mlp *m) {
+    if (shape16p(m) != 4 || m->reserved != 1 || m->act != NEFII_ACT_SOFTPLUS100) return false;
+    const int NH = m->n_layers - 1;
+    if (NH < 2 || NH > 12 || m->layer[NH].n_out != 1 || m->layer[0].k_e != 64) return false;
+    if (m->enc_freqs[0] < 0 || m->enc_freqs[1] >= 0 || m->enc_freqs[2] >= 0 || m->feat_width != 0) return false;
+    for (int l = 0; l <= NH; ++l)
+        if (!m->layer[l].w_f16x3 || !m->layer[l].w_bwd_f16x3 || !m->layer[l].bias) return false;
+    return true;
+}
+int vg_units_bwd(const nefii_mlp *m) { return vg_shape(m) ? (m->n_layers - 2) * (m->layer[0].n_pad >> 4) : 0; }
+// half8 offset of the copy in w_stream
+size_t vg_stream_offset(const nefii_mlp *m) {
+    return (size_t)8 * (stream_steps(m) + stream_steps8(m)) * 256 + (size_t)8 * stream_steps_sp(m) * shape16p(m) * 64;
+}
+
+__global__ void pack_sdf_stream_bwd_kernel(nefii_mlp m, half8 *__restrict__ dst, int Gw, int g0) {
+    const int g = blockIdx.x, wave = blockIdx.y;
+    const int NH = m.n_layers - 1, U = m.layer[0].n_pad >> 4;
+    const int l = NH - 1 - g / U, s = g % U;
+    const nefii_layer &L = m.layer[l];
+    const half8 *wb = reinterpret_cast<const half8 *>(L.w_bwd_f16x3);
+    const int KT = (L.k_x + L.k_e) >> 5;
+    const int frag = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = frag >> 1, part = frag & 1, kg = lane >> 4;
+    const int half = s & 1, s32 = s >> 1;
+    const int kk = 64 * wave + 16 * (2 * half + f) + (lane & 15);       // hidden input of layer l = output feature here
+    const int s16 = 2 * s32 + (kg >> 1), t = kk >> 5, lane_src = (kk & 31) + 32 * (kg & 1);
+    dst[((size_t)wave * Gw + g0 + g) * 256 + threadIdx.x] = wb[(((size_t)s16 * KT + t) * 2 + part) * 64 + lane_src];
+}
+
+// ================================================================================================
+// SDF value + last-hidden features + input gradient (normals) of a point list on the fragment stream: get_rbg_value's
+// implicit_network(x) + gradient(x) (reference implicit_differentiable_renderer.py:85-104,533-540) for the nets
+// vg_shape() takes; the generic 32-row kernel (nefii_mlp.hip) spends ~1 ms per tile on the same work.
+// One workgroup of 8 waves per CU, 16 QT rows per tile:
+//   forward  - the "16q" evaluator (mlp_tile.h), its epilogue also stashing 16 h_l (fp32, the accumulator layout: one
+//              coalesced 16-byte store per lane and feature-tile x query-tile) in the workgroup's own workspace slot;
+//   backward - gz_{NH-1} = w_last * sigma'(h_{NH-1}); then per layer l = NH-1 .. 1 the SAME k-loop over the transposed
+//              layer's units (contraction over the layer's outputs, gz_l as the LDS image) and an epilogue that
+//              multiplies by sigma'(h_{l-1}) from the stash; the encoding columns' gradient of the skip layer and of
+//              layer 0 comes from a 32x32x16 side GEMM of waves 0-3 over the layer's own transposed fragments, kept
+//              as fp32 in the LDS image's (free by then) encoding columns; last the chain through the encoding.
+// ================================================================================================
+template <int QT>
+__device__ __forceinline__ float *vg_ge_row(LdsQ<4> &lds, int te, int row) {
+    return reinterpret_cast<float *>((te ? lds.Xl : lds.Xh) + row * QGeo<4>::XP + QGeo<4>::HW);
+}
+
+// GE[row][32 te ..] += gz_l[row][:] . W_l[:, encoding columns 32 te ..] for the layer's two encoding tiles; waves 0..3
+template <int QT>
+__device__ __forceinline__ void vg_enc_grad(const nefii_layer &L, LdsQ<4> &lds, int wave, int lane, float inv_scale) {
+    static_assert(QT == 4, "two 32-row tiles");
+    constexpr int XP = QGeo<4>::XP, EP = QGeo<4>::HW;
+    if (wave >= 4) return;
+    const int te = wave & 1, rt = wave >> 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int KT = (L.k_x + L.k_e) >> 5, t = (L.k_x >> 5) + te, S = L.n_pad >> 4;
+    const half8 *wb = reinterpret_cast<const half8 *>(L.w_bwd_f16x3) + ((size_t)t * 2) * 64 + lane;
+    const _Float16 *ah = lds.Xh + (32 * rt + r) * XP + 8 * h + (EP - L.n_pad);
+    const _Float16 *al = lds.Xl + (32 * rt + r) * XP + 8 * h + (EP - L.n_pad);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int s0 = 0; s0 < S; s0 += 4) {        // S = 32: four 16-deep steps per trip, their fragment loads issued together
+        half8 wh[4], wl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wh[u] = wb[(size_t)(s0 + u) * KT * 128], wl[u] = wb[(size_t)(s0 + u) * KT * 128 + 64];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const half8 xh = *reinterpret_cast<const half8 *>(ah + 16 * (s0 + u));
+            const half8 xl = *reinterpret_cast<const half8 *>(al + 16 * (s0 + u));
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[u], xh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], xl, acc, 0, 0, 0);
+        }
+    }
+    float *ge = vg_ge_row<QT>(lds, te, 32 * rt + r);       // this lane owns its 16 slots of the row: plain read-modify-write
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ge[(i & 3) + 8 * (i >> 2) + 4 * h] += acc[i] * inv_scale;
+}
+
+template <int QT>
+__global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, const float *__restrict__ x, int64_t n,
+                                                                  float *__restrict__ sdf_out, int out_stride,
+                                                                  float *__restrict__ feat_out, int feat_stride,
+                                                                  float *__restrict__ grad_out, float4v *__restrict__ ws,
+                                                                  size_t vg_off, int Gw) {
+    constexpr int FT = 4, ROWS = 16 * QT, NW = 8, RT = QT / 2, XP = QGeo<4>::XP, EP = QGeo<4>::HW, NJ = FT * QT;
+    __shared__ LdsQ<4> lds;
+    __shared__ float raw[ROWS * 9];
+    __shared__ float psum[NW * ROWS];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int NH = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE), k16 = inv_scale * A16_SCALE;
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
+    // stash element (layer l, accumulator j) of this lane: stash[(l * NW * NJ + j) * 64]
+    float4v *stash = ws + ((size_t)blockIdx.x * NH * NW + wave) * NJ * 64 + lane;
+    constexpr size_t SL = (size_t)NW * NJ * 64;             // float4 per layer
+    P16<8>::Stage b[4];
+    PCursor cur;
+    cur.bytes = (unsigned)Gw * 4096;
+    cur.base = reinterpret_cast<const half8 *>(m.w_stream) + vg_off + (size_t)wave * Gw * 256 + lane;
+    cur.off = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) pload<8>(b[u], cur);
+    const int boff = 64 * wave + lane;
+    const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4), *ql0 = lds.Xl + (lane & 15) * XP + 8 * (lane >> 4);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * ROWS;
+        for (int i = tid; i < ROWS * 9; i += 512) {
+            const int p = i / 9, c = i - 9 * p;
+            int64_t idx = base + p;
+            if (idx >= n) idx = n - 1;
+            raw[i] = c < 3 ? x[idx * 3 + c] : 0.f;
+        }
+        float bnext = m.layer[0].bias[boff];
+        __syncthreads();
+        encode_tile16q<4>(m, raw, lds, ROWS);
+        __syncthreads();
+        // ------------------------------------------------ forward
+        for (int l = 0; l < NH; ++l) {
+            const nefii_layer &L = m.layer[l];
+            const int units = q_units<4>(L);
+            const _Float16 *ah = qh0 + (EP - L.k_x), *al = ql0 + (EP - L.k_x);
+            const float *bp = m.layer[l + 1 < NH ? l + 1 : l].bias + boff;
+            asm volatile("" ::"s"(units), "v"(ah), "v"(al), "v"(bp));
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_sched_barrier(0);
+            const float bvec = bnext;
+            f32x4 acc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+            QAct<QT> a[2];
+            qload_a<QT, XP>(a[0], ah, al, 0);
+            qgemm<QT, 4>(units, b, a, cur, ah, al, acc);
+            bnext = *bp;
+            __builtin_amdgcn_sched_barrier(0);
+            half4 phi[NJ], plo[NJ];
+            const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
+            float4v *st = stash + (size_t)l * SL;
+            const bool feat = feat_out != nullptr && l == NH - 1;
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) {
+                float4v bs;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    bs[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int j = ft * QT + qt;
+                    float4v hs;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hs[k] = softplus100_s16(__builtin_fmaf(acc[j][k], k16, bs[k]));
+                    st[j * 64] = hs;
+                    const half4 hi = __builtin_convertvector(hs, half4);
+                    phi[j] = hi;
+                    plo[j] = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+                    if (feat) {
+                        const int64_t row = base + 16 * qt + (lane & 15);
+                        const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+                        if (row < n) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (f0 + k < L.n_out) feat_out[(size_t)row * feat_stride + f0 + k] = hs[k] * (1.f / A16_SCALE);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            _Float16 *xh = lds.Xh + (EP - L.n_pad), *xl = lds.Xl + (EP - L.n_pad);
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) {
+                const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int query = 16 * qt + (lane & 15);
+                    *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                    *reinterpret_cast<half4 *>(xl + query * XP + f0) = plo[ft * QT + qt];
+                }
+            }
+            __syncthreads();
+        }
+        // last layer, its one column: 32x32x16 fragments of the layer's own w_f16x3, K split over the waves (as in "16q")
+        {
+            const int r = lane & 31, h = lane >> 5;
+            const nefii_layer &L = m.layer[NH];
+            const int NT = L.n_pad >> 5;
+            const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
+            const _Float16 *ah = lds.Xh + r * XP + 8 * h + (EP - L.k_x), *al = lds.Xl + r * XP + 8 * h + (EP - L.k_x);
+            const int ksw = (L.k_x >> 4) / NW;
+            f32x16 acc2[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
+            for (int u = 0; u < ksw; ++u) {
+                const int s = wave * ksw + u;
+                const half8 wh = wl[(size_t)s * NT * 128], wlo = wl[(size_t)s * NT * 128 + 64];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const half8 xh8 = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP + 16 * s);
+                    const half8 xl8 = *reinterpret_cast<const half8 *>(al + rt * 32 * XP + 16 * s);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh8, acc2[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh8, acc2[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl8, acc2[rt], 0, 0, 0);
+                }
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) psum[wave * ROWS + 32 * rt + r] = acc2[rt][0];
+            }
+            __syncthreads();        // partial sums complete; every wave is done reading h_{NH-1} from the image
+            if (tid < ROWS) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) sum += psum[w * ROWS + tid];
+                if (base + tid < n) sdf_out[(size_t)(base + tid) * out_stride] = sum * inv_scale + L.bias[0];
+            }
+        }
+        // ------------------------------------------------ backward
+        // seed: gz_{NH-1}[row][f] = W_last[0][f] * sigma'(h_{NH-1}[row][f]); the encoding columns become the fp32 GE rows
+        {
+            const nefii_layer &LL = m.layer[NH];
+            const half8 *wlb = reinterpret_cast<const half8 *>(LL.w_bwd_f16x3);       // s16 = 0: outputs 0..7 of lanes 0..31
+            const float4v *st = stash + (size_t)(NH - 1) * SL;
+            for (int i = tid; i < ROWS * 32; i += 512) {
+                vg_ge_row<QT>(lds, 0, i >> 5)[i & 31] = 0.f;
+                vg_ge_row<QT>(lds, 1, i >> 5)[i & 31] = 0.f;
+            }
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) {
+                const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+                float4v wv;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = f0 + k;
+                    const half8 hi = wlb[((size_t)(f >> 5) * 2) * 64 + (f & 31)], lo = wlb[((size_t)(f >> 5) * 2 + 1) * 64 + (f & 31)];
+                    wv[k] = ((float)hi[0] + (float)lo[0]) * (1.f / W16_SCALE);
+                }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const float4v hs = st[(ft * QT + qt) * 64];
+                    const int query = 16 * qt + (lane & 15);
+                    float4v v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = wv[k] * softplus100_bwd_fast(hs[k] * (1.f / A16_SCALE)) * A16_SCALE;
+                    const half4 hi = __builtin_convertvector(v, half4);
+                    *reinterpret_cast<half4 *>(lds.Xh + query * XP + f0) = hi;
+                    *reinterpret_cast<half4 *>(lds.Xl + query * XP + f0) =
+                        __builtin_convertvector(v - __builtin_convertvector(hi, float4v), half4);
+                }
+            }
+            __syncthreads();
+        }
+        for (int l = NH - 1; l >= 1; --l) {
+            const nefii_layer &L = m.layer[l];
+            if (L.k_e) vg_enc_grad<QT>(L, lds, wave, lane, inv_scale);
+            const int units = L.n_pad >> 4;
+            const _Float16 *ah = qh0 + (EP - L.n_pad), *al = ql0 + (EP - L.n_pad);
+            asm volatile("" ::"s"(units), "v"(ah), "v"(al));
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+            QAct<QT> a[2];
+            qload_a<QT, XP>(a[0], ah, al, 0);
+            qgemm<QT, 4>(units, b, a, cur, ah, al, acc);
+            half4 phi[NJ], plo[NJ];
+            const float4v *st = stash + (size_t)(l - 1) * SL;
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) {
+                float4v hs[QT];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) hs[qt] = st[(ft * QT + qt) * 64];
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int j = ft * QT + qt;
+                    float4v v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = acc[j][k] * k16 * softplus100_bwd_fast(hs[qt][k] * (1.f / A16_SCALE));
+                    const half4 hi = __builtin_convertvector(v, half4);
+                    phi[j] = hi;
+                    plo[j] = __builtin_convertvector(v - __builtin_convertvector(hi, float4v), half4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            _Float16 *xh = lds.Xh + (EP - L.k_x), *xl = lds.Xl + (EP - L.k_x);
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) {
+                const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int query = 16 * qt + (lane & 15);
+                    *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                    *reinterpret_cast<half4 *>(xl + query * XP + f0) = plo[ft * QT + qt];
+                }
+            }
+            __syncthreads();
+        }
+        vg_enc_grad<QT>(m.layer[0], lds, wave, lane, inv_scale);
+        __syncthreads();
+        // chain through the positional encoding
+        if (tid < ROWS * 3) {
+            const int p = tid / 3, c = tid - 3 * p;
+            if (base + p < n) {
+                const float *v = raw + p * 9;
+                const int w0 = enc_width(m.enc_freqs[0]);
+                const float *g0 = vg_ge_row<QT>(lds, 0, p), *g1 = vg_ge_row<QT>(lds, 1, p);
+                float g = 0.f;
+                for (int col = 0; col < w0; ++col) {
+                    int comp;
+                    const float d = enc_deriv(v, col, comp);
+                    if (comp == c) g += (col < 32 ? g0[col] : g1[col - 32]) * d;
+                }
+                grad_out[(size_t)(base + p) * 3 + c] = g;
+            }
+        }
+        __syncthreads();
+    }
 }
 
 // the same tile evaluator over an explicit point list (nefii_sdf_eval)
@@ -1183,7 +1521,9 @@ extern "C" int nefii_trace_profile_launches(float *h_ms, int cap) {
 
 extern "C" size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf) {
     if (!h_sdf || h_sdf->n_layers < 2 || h_sdf->n_layers > NEFII_MAX_LAYERS || !shape16p(h_sdf)) return 0;
-    return (size_t)8 * (stream_steps(h_sdf) + stream_steps8(h_sdf)) * 256 * sizeof(half8) +
+    size_t units_vg = 0;
+    if (vg_shape(h_sdf)) units_vg = (size_t)stream_steps(h_sdf) + vg_units_bwd(h_sdf);
+    return (size_t)8 * (stream_steps(h_sdf) + stream_steps8(h_sdf) + units_vg) * 256 * sizeof(half8) +
            (size_t)8 * stream_steps_sp(h_sdf) * shape16p(h_sdf) * 64 * sizeof(half8);
 }
 
@@ -1214,8 +1554,44 @@ extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, voi
                            (half8 *)w_stream + (size_t)8 * (G + G8) * 256, Gs, ft);
         HIP_CHECK_LAUNCH();
     }
+    if (vg_shape(h_sdf)) {
+        const int Gb = vg_units_bwd(h_sdf), Gw = G + Gb;
+        half8 *dst = (half8 *)w_stream + vg_stream_offset(h_sdf);
+        hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, 4, 0);
+        HIP_CHECK_LAUNCH();
+        hipLaunchKernelGGL(pack_sdf_stream_bwd_kernel, dim3(Gb, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, G);
+        HIP_CHECK_LAUNCH();
+    }
     return 0;
 }
+
+namespace nefii {
+static int vg_grid(int64_t n) {
+    const int64_t n_tiles = (n + 63) / 64;
+    return (int)(n_tiles < 256 ? (n_tiles > 0 ? n_tiles : 1) : 256);     // one workgroup per CU, grid-strided
+}
+// NEFII_VG_STREAM=0: keep the generic 32-row kernel (A/B measurements)
+static bool vg_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("NEFII_VG_STREAM");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
+size_t value_grad_stream_ws_bytes(const nefii_mlp *m, int64_t n) {
+    if (!m || n <= 0 || !m->w_stream || !vg_enabled() || !vg_shape(m)) return 0;
+    return (size_t)vg_grid(n) * (m->n_layers - 1) * 8 * 16 * 64 * sizeof(float4v);
+}
+int value_grad_stream_launch(const nefii_mlp *m, const float *x, int64_t n, float *sdf_out, int out_stride, float *feat_out,
+                             int feat_stride, float *grad_out, float *ws, hipStream_t st) {
+    if (!m->w_stream || !vg_enabled() || !vg_shape(m)) return NEFII_E_UNSUPPORTED;
+    const int Gw = stream_steps(m) + vg_units_bwd(m);
+    hipLaunchKernelGGL(sdf_value_grad16q_kernel<4>, dim3(vg_grid(n)), dim3(512), 0, st, *m, x, n, sdf_out, out_stride,
+                       feat_out, feat_stride, grad_out, reinterpret_cast<float4v *>(ws), vg_stream_offset(m), Gw);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+}  // namespace nefii
 
 // queries per tile of the single-pass evaluator, 16 * QT.  512-wide nets: QT 4 (default) / 6 / 8 (NEFII_COARSE_QT; the big
 // tiles read activation fragments single-buffered and run their epilogue behind the barrier to fit 256 registers).
@@ -1226,11 +1602,29 @@ static int coarse_qt() {
     static const int v = [] {
         const char *e = getenv("NEFII_COARSE_QT");
         const int q = e ? atoi(e) : 0;
-        return q == 4 || q == 6 || q == 8 ? q : 4;
+        return q == 4 || q == 6 || q == 8 ? q : 0;
     }();
     return v;
 }
-
+// rows of a coarse tile for a net of feature-tile count ft
+static int coarse_rows(int ft) {
+    const int q = coarse_qt();
+    if (ft == 2) return 96;
+    return 16 * (q ? q : 4);
+}
+// launches KERNEL<QT, FT, DB> for the configured tile
+#define NEFII_COARSE_LAUNCH(KERNEL, ft, grid, st, ...)                                                              \
+    do {                                                                                                            \
+        const int rows_ = coarse_rows(ft);                                                                          \
+        if ((ft) == 2)                                                                                              \
+            hipLaunchKernelGGL((KERNEL<6, 2>), grid, dim3(512), 0, st, __VA_ARGS__);                                \
+        else if (rows_ == 64)                                                                                       \
+            hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(512), 0, st, __VA_ARGS__);                                \
+        else if (rows_ == 96)                                                                                       \
+            hipLaunchKernelGGL((KERNEL<6, 4, false>), grid, dim3(512), 0, st, __VA_ARGS__);                         \
+        else                                                                                                        \
+            hipLaunchKernelGGL((KERNEL<8, 4, false>), grid, dim3(512), 0, st, __VA_ARGS__);                         \
+    } while (0)
 
 extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream) {
     if (!h_sdf || h_sdf->n_layers < 1 || h_sdf->n_layers > NEFII_MAX_LAYERS) return NEFII_E_ARG;
@@ -1241,17 +1635,10 @@ extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int
         h_sdf->layer[0].k_x != 0)
         return NEFII_E_UNSUPPORTED;
     const int ft = shape16p(h_sdf);
-    const int qt = ft == 2 ? 6 : coarse_qt();
-    const int64_t n_tiles = (n + 16 * qt - 1) / (16 * qt);
+    const int rows = coarse_rows(ft);
+    const int64_t n_tiles = (n + rows - 1) / rows;
     const dim3 grid((int)(n_tiles < 512 ? n_tiles : 512));
-    if (ft == 2)
-        hipLaunchKernelGGL((sdf_points_kernel16s<6, 2>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
-    else if (qt == 4)
-        hipLaunchKernelGGL((sdf_points_kernel16s<4, 4>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
-    else if (qt == 8)
-        hipLaunchKernelGGL((sdf_points_kernel16s<8, 4, false>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
-    else
-        hipLaunchKernelGGL((sdf_points_kernel16s<6, 4, false>), grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    NEFII_COARSE_LAUNCH(sdf_points_kernel16s, ft, grid, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
     HIP_CHECK_LAUNCH();
     return 0;
 }
@@ -1437,17 +1824,10 @@ int launch_round(const TraceJob &J, int r, bool profile) {
             hipLaunchKernelGGL(eval_kernel, dim3(J.eval_blocks), dim3(WG), 0, st, J.P, *J.sdf, r);
         HIP_CHECK_LAUNCH();
         if (J.coarse) {
-            if (J.pipelined == 2) {
-                const int64_t t = (J.P.n * (int64_t)J.P.p.n_steps + 95) / 96;
-                hipLaunchKernelGGL((eval_kernel16s<6, 2>), dim3((int)(t < J.eval_blocks_w ? t : J.eval_blocks_w)), dim3(512), 0,
-                                   st, J.P, *J.sdf, r);
-            } else if (coarse_qt() == 4) {
-                hipLaunchKernelGGL((eval_kernel16s<4, 4>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
-            } else if (coarse_qt() == 8) {
-                hipLaunchKernelGGL((eval_kernel16s<8, 4, false>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
-            } else {
-                hipLaunchKernelGGL((eval_kernel16s<6, 4, false>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
-            }
+            const int ft = J.pipelined == 2 ? 2 : 4, rows = coarse_rows(ft);
+            const int64_t t = (J.P.n * (int64_t)J.P.p.n_steps + rows - 1) / rows;
+            const dim3 grid((int)(t < J.eval_blocks_w ? t : J.eval_blocks_w));
+            NEFII_COARSE_LAUNCH(eval_kernel16s, ft, grid, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();
         }
         if (profile) (void)hipEventRecord(e1, st);

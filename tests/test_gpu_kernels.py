@@ -64,6 +64,35 @@ def test_sdf_forward_and_gradient(name, hidden, n):
     assert rel_l2(feat, hid) < 1e-7
 
 
+@pytest.mark.parametrize('n', [1, 63, 64, 65, 1000, 20011])
+def test_sdf_value_grad_on_the_fragment_stream(n):
+    """nefii_sdf_value_grad of a 512-wide net with a fragment stream: forward and backward on the pipelined stream
+    (sdf_value_grad16q_kernel) - value, last-hidden features and d sdf / dx against the fp64 oracle on ragged sizes
+    (tiles of 64 rows; 20011 rows = 313 tiles on 256 workgroups: a second tile per workgroup reuses its stash slot)."""
+    import ctypes
+    from nefii_amd import ops, _lib
+    mc = syn.model_conf('physg')
+    sd = syn.make_state_dict(mc, seed=3, bumpy=0.004)
+    g = torch.Generator().manual_seed(11)
+    for l in mc['implicit_network']['skip_in']:          # live sin/cos columns at the skip layer, as after training
+        w = sd['implicit_network.lin%d.weight_v' % l]
+        w[:, -36:] = torch.randn(w.shape[0], 36, generator=g) * 0.02
+    pm = build_sdf(mc, sd, f16x3=True)
+    n_tiles = (n + 63) // 64
+    assert _lib.lib().nefii_sdf_value_grad_workspace_bytes(ctypes.byref(pm.struct), n) == \
+        min(n_tiles, 256) * (pm.n_layers - 1) * 128 * 1024, 'the streamed kernel did not take this net'
+    x = ball_points(n, 5)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref = nets.sdf_forward(sd64, mc['implicit_network'], x.double())
+    gref = nets.sdf_gradient(sd64, mc['implicit_network'], x.double())
+    out, feat, grad = ops.sdf_value_grad(pm, x.to(DEV), want_feat=True)
+    assert (out[:, 0].cpu().double() - ref[:, 0]).abs().max().item() < 3e-6
+    assert (feat.cpu().double() - ref[:, 1:]).abs().max().item() < 3e-6
+    assert (grad.cpu().double() - gref).abs().max().item() < 1e-5
+    out2, _, grad2 = ops.sdf_value_grad(pm, x.to(DEV), want_feat=False)
+    assert torch.equal(out2, out) and torch.equal(grad2, grad)
+
+
 @pytest.mark.parametrize('split', [False, True])
 @pytest.mark.parametrize('name,hidden,n', [('physg', 64, 200), ('conf', 512, 1000), ('physg', 512, 77), ('neus', None, 300)])
 def test_sdf_gradient_trained_like_skip_weights(name, hidden, n, split):
