@@ -191,6 +191,17 @@ typedef struct nefii_tracer_params {
 size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf);
 int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, void *stream);
 
+/* The same idea for the radiance / material MLPs (RenderingNetwork.forward, implicit_differentiable_renderer.py:196-241;
+ * EnvmapMaterialNetwork's MLPs, sg_envmap_material.py:357-425) on the split-precision forward nefii_mlp_forward_f16: nets
+ * whose hidden layers are all 512 wide (layer 0: up to 512 feature columns + up to 128 encoding columns; last layer: at
+ * most 8 outputs) keep their hidden layers' hi/lo fragments as one stream per wave, [8 waves][units][4 fragments][64
+ * lanes][8 halves], a unit = 16-deep half step of a layer whose K is rounded up to a multiple of 64 with zero weights.
+ * With w_stream set the forward runs 48- / 64-row tiles on the tracer's pipelined evaluator structure.
+ * nefii_mlp_stream_bytes: size of the buffer, 0 when the shape does not qualify; nefii_pack_mlp_stream: device-side
+ * gather from the layers' w_f16x3 - call after every nefii_pack_linear_f16x3 (the weights train). */
+size_t nefii_mlp_stream_bytes(const nefii_mlp *h_mlp);
+int nefii_pack_mlp_stream(const nefii_mlp *h_mlp, void *w_stream, void *stream);
+
 /* Transposed counterpart for the split-precision input-gradient GEMMs (nefii_sdf_value_grad picks its split-precision
  * kernel when every layer carries both w_f16x3 and w_bwd_f16x3). */
 int nefii_pack_linear_f16x3_bwd(const float *W, int n_out, int k_in, int x_src0, int x_len, int e_src0, int e_len,

@@ -74,6 +74,8 @@ SIGNATURES = {
     'nefii_sdf_value_grad_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp), I64]),
     'nefii_sdf_stream_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp)]),
     'nefii_pack_sdf_stream': (I, [ctypes.POINTER(Mlp), P, P]),
+    'nefii_mlp_stream_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp)]),
+    'nefii_pack_mlp_stream': (I, [ctypes.POINTER(Mlp), P, P]),
     'nefii_sdf_eval': (I, [ctypes.POINTER(Mlp), P, I64, P, P]),
     'nefii_sdf_eval_coarse': (I, [ctypes.POINTER(Mlp), P, I64, P, P]),
     'nefii_sdf_coarse_supported': (I, [ctypes.POINTER(Mlp)]),

@@ -948,11 +948,11 @@ __device__ __forceinline__ void qload_a(QAct<QT> &st, const _Float16 *ah, const 
 }
 
 // one half step: HALF selects the feature-tile pair (ft = 2 HALF, 2 HALF + 1) whose fragments stage J holds
-template <int QT, int FT, int J, int HALF, int ABUF, bool LOADA>
+template <int QT, int FT, int J, int HALF, int ABUF, bool LOADA, int XP = QGeo<FT>::XP>
 __device__ __forceinline__ void qstep(P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], PCursor &cur, const _Float16 *ah,
                                       const _Float16 *al, int s32, f32x4 (&acc)[FT * QT]) {
     pload<8>(b[(J + 3) % 4], cur);
-    if (LOADA) qload_a<QT, QGeo<FT>::XP>(a[ABUF ^ 1], ah, al, s32 + 1);
+    if (LOADA) qload_a<QT, XP>(a[ABUF ^ 1], ah, al, s32 + 1);
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -979,16 +979,16 @@ __device__ __forceinline__ void qstep(P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], P
 }
 
 // k-loop of one layer: `units` stream units (a multiple of 4), stage 0 first
-template <int QT, int FT>
+template <int QT, int FT, int XP = QGeo<FT>::XP>
 __device__ __forceinline__ void qgemm(int units, P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], PCursor &cur,
                                       const _Float16 *ah, const _Float16 *al, f32x4 (&acc)[FT * QT]) {
     if constexpr (FT == 4) {
         for (int hs = 0; hs < units; hs += 4) {
             const int s32 = hs >> 1;
-            qstep<QT, FT, 0, 0, 0, true>(b, a, cur, ah, al, s32, acc);
-            qstep<QT, FT, 1, 1, 0, false>(b, a, cur, ah, al, s32, acc);
-            qstep<QT, FT, 2, 0, 1, true>(b, a, cur, ah, al, s32 + 1, acc);
-            qstep<QT, FT, 3, 1, 1, false>(b, a, cur, ah, al, s32 + 1, acc);
+            qstep<QT, FT, 0, 0, 0, true, XP>(b, a, cur, ah, al, s32, acc);
+            qstep<QT, FT, 1, 1, 0, false, XP>(b, a, cur, ah, al, s32, acc);
+            qstep<QT, FT, 2, 0, 1, true, XP>(b, a, cur, ah, al, s32 + 1, acc);
+            qstep<QT, FT, 3, 1, 1, false, XP>(b, a, cur, ah, al, s32 + 1, acc);
         }
     } else {
         for (int s32 = 0; s32 < units; s32 += 4) {

@@ -1,5 +1,7 @@
 // nefii_mlp.hip - fused MLP kernels (forward, hidden-gradient backward, SDF value+gradient) and the
 // weight packer, for gfx950.  Tile machinery in mlp_tile.h.
+#include <cstdlib>
+
 #include "mlp_tile.h"
 
 using namespace nefii;
@@ -583,6 +585,289 @@ __global__ __launch_bounds__(256, 1) void mlp_forward16_kernel(nefii_mlp m, cons
     }
 }
 
+// ================================================================================================
+// Streamed split-precision forward for the radiance / material MLPs: the tracer's "16q" machine (mlp_tile.h) on nets
+// whose hidden layers are all 512 wide - 8 waves, each owning 64 features of every hidden layer, the layers' hi/lo
+// fragments read as ONE prefetched stream per wave (nefii_mlp.w_stream, nefii_pack_mlp_stream), 48- or 64-row tiles.
+// The 32-row kernel above re-reads every layer's fragments per tile with nothing in flight: 9.3 us per row on
+// config 3's secondary points against ~2 us per row here.
+//   image row: [features of layer 0 | hidden block .. column 512) [encodings, zero-padded to EW) ; a layer's inputs are
+//   the columns [512 - k_x, 512 + k_e) and its stream units cover that K rounded up to a multiple of 64 (zero weights).
+//   64-row tiles; EW = 64: encodings of up to 64 columns (material: PE(x)); EW = 96: up to 96 (radiance: PE(x), PE(v),
+//   n) - 158 of the 160 KiB of LDS.  The K padding may reach past a row's EW columns (radiance layer 0: 608 -> 640):
+//   what it reads there - the next row's first columns, the tail behind the last row - is finite and meets zero weights.
+// The last layer (n_pad 32, at most 8 outputs) is a 32x32x16 GEMM with K split over the waves, reduced through LDS.
+// ================================================================================================
+// ELU on the hardware exponential: e^x - 1 from v_exp_f32 (absolute error ~6e-8, the rounding of e^x near 1), and the
+// degree-4 series where that cancels (|x| < 1/16: truncation error < 1e-8).  The libm expm1f of act_fwd is ~40
+// instructions per value - on 64 values per lane and layer it was a third of the streamed tile's time.
+__device__ __forceinline__ float elu_fast(float x) {
+    const float t = __builtin_amdgcn_exp2f(x * 1.44269504088896340736f) - 1.f;
+    const float p = x * __builtin_fmaf(x, __builtin_fmaf(x, __builtin_fmaf(x, 1.f / 24.f, 1.f / 6.f), 0.5f), 1.f);
+    const float r = __builtin_fabsf(x) < 0.0625f ? p : t;
+    return x > 0.f ? x : r;
+}
+
+template <int QT, int EW>
+struct LdsM {
+    static constexpr int XP = 512 + EW + 8;         // halves per row: 584 / 616 (16 B * odd)
+    _Float16 Xh[16 * QT * XP], Xl[16 * QT * XP];
+    _Float16 tail[64];                              // the K padding and the A-fragment read-ahead of the last row land here
+};
+__host__ __device__ __forceinline__ int m_units(const nefii_layer &L) { return ((L.k_x + L.k_e + 63) & ~63) >> 4; }
+
+// encoding width the streamed kernel needs for this net (64 / 96), 0: the net does not take it
+static int mstream_shape(const nefii_mlp *m) {
+    const int NH = m->n_layers - 1;
+    if (NH < 1 || NH > 12) return 0;
+    for (int l = 0; l <= NH; ++l)
+        if (!m->layer[l].w_f16x3 || !m->layer[l].bias) return 0;
+    const nefii_layer &L0 = m->layer[0];
+    if (L0.n_pad != 512 || L0.k_x > 512 || (L0.k_x & 15) || L0.k_e > 96 || L0.k_x + L0.k_e == 0) return 0;
+    for (int l = 1; l < NH; ++l)
+        if (m->layer[l].n_pad != 512 || m->layer[l].k_x != 512 || m->layer[l].k_e != 0) return 0;
+    const nefii_layer &LL = m->layer[NH];
+    if (LL.k_x != 512 || LL.k_e != 0 || LL.n_pad != 32 || LL.n_out > 8) return 0;
+    return L0.k_e <= 64 ? 64 : 96;
+}
+static int mstream_units(const nefii_mlp *m) {
+    int G = 0;
+    for (int l = 0; l < m->n_layers - 1; ++l) G += m_units(m->layer[l]);
+    return G;
+}
+
+extern "C" size_t nefii_mlp_stream_bytes(const nefii_mlp *h_mlp) {
+    if (!h_mlp || h_mlp->n_layers < 2 || h_mlp->n_layers > NEFII_MAX_LAYERS || !mstream_shape(h_mlp)) return 0;
+    return (size_t)8 * mstream_units(h_mlp) * 256 * sizeof(half8);
+}
+
+// dst[((wave*G + g)*4 + 2 f + part)*64 + lane][j] = W[n = 64 wave + 16 (2 (g&1) + f) + (lane&15)][k = 32 (g>>1) + 8 (lane>>4) + j]
+// of unit g's layer (hi / lo), gathered from the layer's 32x32x16 fragments; zeros past the layer's own K
+__global__ void pack_mlp_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int G) {
+    const int g = blockIdx.x, wave = blockIdx.y;
+    int l = 0, s = g;
+    while (s >= m_units(m.layer[l])) s -= m_units(m.layer[l]), ++l;
+    const half8 *w = reinterpret_cast<const half8 *>(m.layer[l].w_f16x3);
+    const int frag = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = frag >> 1, part = frag & 1, kg = lane >> 4;
+    const int half = s & 1, s32 = s >> 1;
+    const int n = 64 * wave + 16 * (2 * half + f) + (lane & 15);
+    const int s16 = 2 * s32 + (kg >> 1), t = n >> 5, lane_src = (n & 31) + 32 * (kg & 1);
+    half8 v;
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+    if (s16 < ((m.layer[l].k_x + m.layer[l].k_e) >> 4)) v = w[(((size_t)s16 * 16 + t) * 2 + part) * 64 + lane_src];
+    dst[((size_t)wave * G + g) * 256 + threadIdx.x] = v;
+}
+
+extern "C" int nefii_pack_mlp_stream(const nefii_mlp *h_mlp, void *w_stream, void *stream) {
+    if (!h_mlp || !w_stream) return NEFII_E_ARG;
+    if (nefii_mlp_stream_bytes(h_mlp) == 0) return NEFII_E_UNSUPPORTED;
+    const int G = mstream_units(h_mlp);
+    hipLaunchKernelGGL(pack_mlp_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_mlp, (half8 *)w_stream, G);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int QT, int EW>
+__global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, const float *__restrict__ in_a,
+                                                               const float *__restrict__ in_b,
+                                                               const float *__restrict__ in_c,
+                                                               const float *__restrict__ feat, int64_t n,
+                                                               float *__restrict__ out, int out_stride,
+                                                               float *__restrict__ hidden_out, int hid_stride,
+                                                               float *__restrict__ stash, int stash_stride, int G) {
+    constexpr int ROWS = 16 * QT, XP = LdsM<QT, EW>::XP, EP = 512, NW = 8, NJ = 4 * QT, RT = (QT + 1) / 2;
+    __shared__ LdsM<QT, EW> lds;
+    __shared__ float raw[ROWS * 9];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int NH = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
+    {   // the K-padded stream multiplies what follows a layer's own columns by zero weights: keep the image finite
+        uint32_t *z = reinterpret_cast<uint32_t *>(&lds);
+        for (int i = tid; i < (int)(sizeof(lds) / 4); i += 512) z[i] = 0u;
+    }
+    P16<8>::Stage b[4];
+    PCursor cur;
+    cur.bytes = (unsigned)G * 4096;
+    cur.base = reinterpret_cast<const half8 *>(m.w_stream) + (size_t)wave * G * 256 + lane;
+    cur.off = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) pload<8>(b[u], cur);
+    const int boff = 64 * wave + lane;
+    const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4), *ql0 = lds.Xl + (lane & 15) * XP + 8 * (lane >> 4);
+    const int w0 = enc_width(m.enc_freqs[0]), w1 = enc_width(m.enc_freqs[1]), w2 = enc_width(m.enc_freqs[2]);
+    const int F = m.feat_width, kx0 = m.layer[0].k_x;
+    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * ROWS;
+        for (int i = tid; i < ROWS * 9; i += 512) {
+            const int p = i / 9, c = i - 9 * p, which = c / 3;
+            const float *src = which == 0 ? in_a : (which == 1 ? in_b : in_c);
+            int64_t idx = base + p;
+            if (idx >= n) idx = n - 1;
+            raw[i] = (src && m.enc_freqs[which] >= 0) ? src[idx * 3 + (c - 3 * which)] : 0.f;
+        }
+        if (feat && F == kx0 && (F & 3) == 0 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0) {
+            const int q4 = kx0 >> 2;                    // 16-byte loads, four features per thread and trip
+            for (int i = tid; i < ROWS * q4; i += 512) {
+                const int p = i / q4, f = 4 * (i - p * q4);
+                int64_t idx = base + p;
+                if (idx >= n) idx = n - 1;
+                const float4v v = *reinterpret_cast<const float4v *>(feat + idx * F + f) * A16_SCALE;
+                const half4 hi = __builtin_convertvector(v, half4);
+                *reinterpret_cast<half4 *>(lds.Xh + p * XP + EP - kx0 + f) = hi;
+                *reinterpret_cast<half4 *>(lds.Xl + p * XP + EP - kx0 + f) =
+                    __builtin_convertvector(v - __builtin_convertvector(hi, float4v), half4);
+            }
+        } else {
+            for (int i = tid; i < ROWS * kx0; i += 512) {
+                const int p = i / kx0, f = i - p * kx0;
+                int64_t idx = base + p;
+                if (idx >= n) idx = n - 1;
+                const float v = (feat && f < F) ? feat[idx * F + f] : 0.f;
+                split16a(v, lds.Xh[p * XP + EP - kx0 + f], lds.Xl[p * XP + EP - kx0 + f]);
+            }
+        }
+        float bnext = m.layer[0].bias[boff];
+        __syncthreads();
+        for (int i = tid; i < ROWS * EW; i += 512) {
+            const int p = i / EW, c = i - p * EW;
+            float val = 0.f;
+            if (c < w0) val = enc_value(raw + p * 9, c);
+            else if (c < w0 + w1) val = enc_value(raw + p * 9 + 3, c - w0);
+            else if (c < w0 + w1 + w2) val = enc_value(raw + p * 9 + 6, c - w0 - w1);
+            split16a(val, lds.Xh[p * XP + EP + c], lds.Xl[p * XP + EP + c]);
+        }
+        __syncthreads();
+        for (int l = 0; l < NH; ++l) {
+            const nefii_layer &L = m.layer[l];
+            const int units = m_units(L);
+            const _Float16 *ah = qh0 + (EP - L.k_x), *al = ql0 + (EP - L.k_x);
+            const float *bp = m.layer[l + 1 < NH ? l + 1 : l].bias + boff;
+            asm volatile("" ::"s"(units), "v"(ah), "v"(al), "v"(bp));
+            __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see "16p")
+            __builtin_amdgcn_sched_barrier(0);
+            const float bvec = bnext;
+            f32x4 acc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+            QAct<QT> a[2];
+            qload_a<QT, XP>(a[0], ah, al, 0);
+            qgemm<QT, 4, XP>(units, b, a, cur, ah, al, acc);
+            bnext = *bp;
+            __builtin_amdgcn_sched_barrier(0);
+            half4 phi[NJ], plo[NJ];
+            const int bsrc = __builtin_bit_cast(int, bvec);
+            const bool pre_last = hidden_out != nullptr && l == NH - 1;
+            auto epilogue = [&](auto actc) {        // the activation id resolved once per layer, not per value
+                constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) {
+                    float4v bs;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        bs[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
+                    const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const int j = ft * QT + qt;
+                        float4v hv;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float z = __builtin_fmaf(acc[j][k], inv_scale, bs[k]);
+                            hv[k] = ACT == NEFII_ACT_ELU ? elu_fast(z) : act_fwd(z, ACT);
+                        }
+                        const int64_t row = base + 16 * qt + (lane & 15);
+                        if (row < n) {
+                            if (stash) *reinterpret_cast<float4v *>(stash + ((size_t)l * n + row) * stash_stride + f0) = hv;
+                            if (pre_last) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k)
+                                    if (f0 + k < L.n_out) hidden_out[(size_t)row * hid_stride + f0 + k] = hv[k];
+                            }
+                        }
+                        const float4v hs = hv * A16_SCALE;
+                        const half4 hi = __builtin_convertvector(hs, half4);
+                        phi[j] = hi;
+                        plo[j] = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+                    }
+                }
+            };
+            if (m.act == NEFII_ACT_RELU)
+                epilogue(std::integral_constant<int, NEFII_ACT_RELU>{});
+            else if (m.act == NEFII_ACT_ELU)
+                epilogue(std::integral_constant<int, NEFII_ACT_ELU>{});
+            else
+                epilogue(std::integral_constant<int, NEFII_ACT_SOFTPLUS100>{});
+            __syncthreads();
+            _Float16 *xh = lds.Xh + (EP - L.n_pad), *xl = lds.Xl + (EP - L.n_pad);
+#pragma unroll
+            for (int ft = 0; ft < 4; ++ft) {
+                const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int query = 16 * qt + (lane & 15);
+                    *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                    *reinterpret_cast<half4 *>(xl + query * XP + f0) = plo[ft * QT + qt];
+                }
+            }
+            __syncthreads();
+        }
+        // last layer: one 32-feature tile, 32x32x16 fragments of its own w_f16x3, K split over the waves
+        {
+            const int r = lane & 31, h = lane >> 5;
+            const nefii_layer &L = m.layer[NH];
+            const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;        // NT = 1
+            const int ksw = (L.k_x >> 4) / NW;
+            f32x16 acc2[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
+            for (int u = 0; u < ksw; ++u) {
+                const int s = wave * ksw + u;
+                const half8 wh = wl[(size_t)s * 128], wlo = wl[(size_t)s * 128 + 64];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const int rowc = 32 * rt + r < ROWS ? 32 * rt + r : ROWS - 1;       // 48-row tiles: half a row tile
+                    const half8 xh8 = *reinterpret_cast<const half8 *>(lds.Xh + rowc * XP + 8 * h + 16 * s);
+                    const half8 xl8 = *reinterpret_cast<const half8 *>(lds.Xl + rowc * XP + 8 * h + 16 * s);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh8, acc2[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh8, acc2[rt], 0, 0, 0);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl8, acc2[rt], 0, 0, 0);
+                }
+            }
+            __syncthreads();            // every wave is done reading the image: its lo half becomes the reduction scratch
+            float *psum = reinterpret_cast<float *>(lds.Xl);       // [wave][row][8 features]
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                if (32 * rt + r < ROWS) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) psum[(wave * ROWS + 32 * rt + r) * 8 + i + 4 * h] = acc2[rt][i];
+                }
+            __syncthreads();
+            for (int i = tid; i < ROWS * 8; i += 512) {
+                const int p = i >> 3, c = i & 7;
+                if (c < L.n_out && base + p < n) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) sum += psum[(w * ROWS + p) * 8 + c];
+                    const float z = sum * inv_scale + L.bias[c];
+                    if (stash) stash[((size_t)NH * n + base + p) * stash_stride + c] = z;
+                    out[(size_t)(base + p) * out_stride + c] = head_fwd(z, m.head);
+                }
+            }
+            __syncthreads();
+            // the scratch held fp32 partial sums: what the next tile's padded k-steps may touch must be finite halves
+            for (int i = tid; i < NW * ROWS * 8 / 2; i += 512) reinterpret_cast<uint32_t *>(lds.Xl)[i] = 0u;
+        }
+    }
+}
+
 static int check_mlp16(const nefii_mlp *m, bool bwd) {
     int rc = check_mlp(m);
     if (rc) return rc;
@@ -594,6 +879,15 @@ static int check_mlp16(const nefii_mlp *m, bool bwd) {
     return 0;
 }
 
+// NEFII_MLP_STREAM=0: keep the 32-row kernel (A/B measurements)
+static bool mlp_stream_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("NEFII_MLP_STREAM");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
+
 extern "C" int nefii_mlp_forward_f16(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
                                      const float *feat, int64_t n, float *out, int out_stride, float *hidden_out,
                                      int hid_stride, float *stash, int stash_stride, int single_pass, void *stream) {
@@ -602,6 +896,25 @@ extern "C" int nefii_mlp_forward_f16(const nefii_mlp *h_mlp, const float *in_a, 
     if (n <= 0) return 0;
     if (!out) return NEFII_E_ARG;
     const int64_t n_tiles = (n + TILE - 1) / TILE;
+    if (!single_pass && h_mlp->w_stream && mlp_stream_enabled()) {
+        const int ew = mstream_shape(h_mlp), G = mstream_units(h_mlp);
+        if (ew == 64) {
+            const int64_t t = (n + 63) / 64;
+            hipLaunchKernelGGL((mlp_forward16q_kernel<4, 64>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream,
+                               *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash,
+                               stash_stride, G);
+            HIP_CHECK_LAUNCH();
+            return 0;
+        }
+        if (ew == 96) {
+            const int64_t t = (n + 63) / 64;
+            hipLaunchKernelGGL((mlp_forward16q_kernel<4, 96>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream,
+                               *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash,
+                               stash_stride, G);
+            HIP_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (single_pass)
         hipLaunchKernelGGL(mlp_forward16_kernel<true>, dim3(grid_for(n_tiles, 1)), dim3(WG), 0, (hipStream_t)stream, *h_mlp,
                            in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash, stash_stride);

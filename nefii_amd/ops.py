@@ -104,6 +104,15 @@ class PackedMLP:
                 m.w_stream = self.w_stream.data_ptr()
             else:
                 m.reserved = 0
+        # radiance / material nets with 512-wide hidden layers: the split-precision forward reads the hidden layers as a
+        # fragment stream too (nefii_mlp_forward_f16 on 48- / 64-row tiles); re-packed with the weights every pack()
+        self.mlp_stream = False
+        if self.half == 'f16x3' and torch.device(device).type == 'cuda':
+            nbytes = _lib.lib().nefii_mlp_stream_bytes(ctypes.byref(m))
+            if nbytes:
+                self.w_stream = torch.zeros(nbytes // 2, device=device, dtype=torch.float16)
+                m.w_stream = self.w_stream.data_ptr()
+                self.mlp_stream = True
         self.hidden_stride = max(s.n_pad for s in specs)
         self.packed_version = None
 
@@ -134,7 +143,10 @@ class PackedMLP:
                     _lib.check(lib.nefii_pack_linear_f16x3_bwd(_ptr(w), s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0,
                                                                s.e_len, s.scale, _ptr(self.w_f16b[l]), st),
                                'nefii_pack_linear_f16x3_bwd')
-        if self.w_stream is not None:
+        if self.mlp_stream:
+            _lib.check(lib.nefii_pack_mlp_stream(ctypes.byref(self.struct), _ptr(self.w_stream), st),
+                       'nefii_pack_mlp_stream')
+        elif self.w_stream is not None:
             _lib.check(lib.nefii_pack_sdf_stream(ctypes.byref(self.struct), _ptr(self.w_stream), st),
                        'nefii_pack_sdf_stream')
 
