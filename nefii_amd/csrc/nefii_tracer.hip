@@ -1073,36 +1073,44 @@ int stream_steps_sp(const nefii_mlp *m) {
 }
 
 // ---- fourth copy: the value + gradient kernel's stream (sdf_value_grad16q_kernel) ------------------------------------------
-// 512-wide softplus nets with a one-column last layer and transposed fragments on every layer.  Per wave: the forward
-// units of the plain 16x16x32 stream, then the BACKWARD units - for l = NH-1 .. 1 the half steps of the transposed layer
-// (contraction over layer l's 512 outputs, the wave's 64 of its 512 hidden inputs as output features), gathered from
-// nefii_layer.w_bwd_f16x3 - so that one cursor runs forward, backward, and wraps to the next tile's forward.
-bool vg_shape(const nefii_mlp *m) {
-    if (shape16p(m) != 4 || m->reserved != 1 || m->act != NEFII_ACT_SOFTPLUS100) return false;
+// Softplus nets of the pipelined shapes (512- or 256-wide) with transposed fragments on every layer.  Per wave: the
+// forward units of the plain 16x16x32 stream, then the BACKWARD units - for l = NH-1 .. 1 the units of the transposed
+// layer (contraction over layer l's W outputs, the wave's share of its W hidden inputs as output features), gathered
+// from nefii_layer.w_bwd_f16x3 - so that one cursor runs forward, backward, and wraps to the next tile's forward.
+// Returns the feature tiles per wave (4 / 2), 0 when the net does not take the kernel.
+int vg_shape(const nefii_mlp *m) {
+    const int ft = shape16p(m);
+    if (!ft || m->reserved != 1 || m->act != NEFII_ACT_SOFTPLUS100) return 0;
     const int NH = m->n_layers - 1;
-    if (NH < 2 || NH > 12 || m->layer[NH].n_out != 1 || m->layer[0].k_e != 64) return false;
-    if (m->enc_freqs[0] < 0 || m->enc_freqs[1] >= 0 || m->enc_freqs[2] >= 0 || m->feat_width != 0) return false;
+    if (NH < 2 || NH > 12 || m->layer[0].k_e != 64) return 0;
+    if (m->enc_freqs[0] < 0 || m->enc_freqs[1] >= 0 || m->enc_freqs[2] >= 0 || m->feat_width != 0) return 0;
     for (int l = 0; l <= NH; ++l)
-        if (!m->layer[l].w_f16x3 || !m->layer[l].w_bwd_f16x3 || !m->layer[l].bias) return false;
-    return true;
+        if (!m->layer[l].w_f16x3 || !m->layer[l].w_bwd_f16x3 || !m->layer[l].bias) return 0;
+    return ft;
 }
-int vg_units_bwd(const nefii_mlp *m) { return vg_shape(m) ? (m->n_layers - 2) * (m->layer[0].n_pad >> 4) : 0; }
+// backward units of one layer: 16-deep half steps (512-wide), whole 32-deep steps (256-wide)
+__host__ __device__ __forceinline__ int vg_units_layer(int n_pad, int ft) { return ft == 4 ? n_pad >> 4 : n_pad >> 5; }
+int vg_units_bwd(const nefii_mlp *m) {
+    const int ft = vg_shape(m);
+    return ft ? (m->n_layers - 2) * vg_units_layer(m->layer[0].n_pad, ft) : 0;
+}
 // half8 offset of the copy in w_stream
 size_t vg_stream_offset(const nefii_mlp *m) {
     return (size_t)8 * (stream_steps(m) + stream_steps8(m)) * 256 + (size_t)8 * stream_steps_sp(m) * shape16p(m) * 64;
 }
 
-__global__ void pack_sdf_stream_bwd_kernel(nefii_mlp m, half8 *__restrict__ dst, int Gw, int g0) {
+__global__ void pack_sdf_stream_bwd_kernel(nefii_mlp m, half8 *__restrict__ dst, int Gw, int g0, int ft) {
     const int g = blockIdx.x, wave = blockIdx.y;
-    const int NH = m.n_layers - 1, U = m.layer[0].n_pad >> 4;
+    const int NH = m.n_layers - 1, U = vg_units_layer(m.layer[0].n_pad, ft);
     const int l = NH - 1 - g / U, s = g % U;
     const nefii_layer &L = m.layer[l];
     const half8 *wb = reinterpret_cast<const half8 *>(L.w_bwd_f16x3);
     const int KT = (L.k_x + L.k_e) >> 5;
     const int frag = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int f = frag >> 1, part = frag & 1, kg = lane >> 4;
-    const int half = s & 1, s32 = s >> 1;
-    const int kk = 64 * wave + 16 * (2 * half + f) + (lane & 15);       // hidden input of layer l = output feature here
+    // kk: hidden input of layer l = output feature here
+    const int half = s & 1, s32 = ft == 4 ? s >> 1 : s;
+    const int kk = ft == 4 ? 64 * wave + 16 * (2 * half + f) + (lane & 15) : 32 * wave + 16 * f + (lane & 15);
     const int s16 = 2 * s32 + (kg >> 1), t = kk >> 5, lane_src = (kk & 31) + 32 * (kg & 1);
     dst[((size_t)wave * Gw + g0 + g) * 256 + threadIdx.x] = wb[(((size_t)s16 * KT + t) * 2 + part) * 64 + lane_src];
 }
@@ -1120,17 +1128,18 @@ __global__ void pack_sdf_stream_bwd_kernel(nefii_mlp m, half8 *__restrict__ dst,
 //              layer 0 comes from a 32x32x16 side GEMM of waves 0-3 over the layer's own transposed fragments, kept
 //              as fp32 in the LDS image's (free by then) encoding columns; last the chain through the encoding.
 // ================================================================================================
-template <int QT>
-__device__ __forceinline__ float *vg_ge_row(LdsQ<4> &lds, int te, int row) {
-    return reinterpret_cast<float *>((te ? lds.Xl : lds.Xh) + row * QGeo<4>::XP + QGeo<4>::HW);
+template <int FT>
+__device__ __forceinline__ float *vg_ge_row(LdsQ<FT> &lds, int te, int row) {
+    return reinterpret_cast<float *>((te ? lds.Xl : lds.Xh) + row * QGeo<FT>::XP + QGeo<FT>::HW);
 }
 
-// GE[row][32 te ..] += gz_l[row][:] . W_l[:, encoding columns 32 te ..] for the layer's two encoding tiles; waves 0..3
-template <int QT>
-__device__ __forceinline__ void vg_enc_grad(const nefii_layer &L, LdsQ<4> &lds, int wave, int lane, float inv_scale) {
-    static_assert(QT == 4, "two 32-row tiles");
-    constexpr int XP = QGeo<4>::XP, EP = QGeo<4>::HW;
-    if (wave >= 4) return;
+// GE[row][32 te ..] += gz_l[row][:] . W_l[:, encoding columns 32 te ..] for the layer's two encoding tiles; one wave per
+// (encoding tile, 32-row tile): waves 0..3 (64-row tiles) / 0..5 (96-row tiles)
+template <int QT, int FT>
+__device__ __forceinline__ void vg_enc_grad(const nefii_layer &L, LdsQ<FT> &lds, int wave, int lane, float inv_scale) {
+    static_assert(QT % 2 == 0 && QT <= 8, "whole 32-row tiles, one wave each");
+    constexpr int XP = QGeo<FT>::XP, EP = QGeo<FT>::HW;
+    if (wave >= QT) return;
     const int te = wave & 1, rt = wave >> 1;
     const int r = lane & 31, h = lane >> 5;
     const int KT = (L.k_x + L.k_e) >> 5, t = (L.k_x >> 5) + te, S = L.n_pad >> 4;
@@ -1153,19 +1162,20 @@ __device__ __forceinline__ void vg_enc_grad(const nefii_layer &L, LdsQ<4> &lds, 
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], xl, acc, 0, 0, 0);
         }
     }
-    float *ge = vg_ge_row<QT>(lds, te, 32 * rt + r);       // this lane owns its 16 slots of the row: plain read-modify-write
+    float *ge = vg_ge_row<FT>(lds, te, 32 * rt + r);       // this lane owns its 16 slots of the row: plain read-modify-write
 #pragma unroll
     for (int i = 0; i < 16; ++i) ge[(i & 3) + 8 * (i >> 2) + 4 * h] += acc[i] * inv_scale;
 }
 
-template <int QT>
+template <int QT, int FT>
 __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                                   float *__restrict__ sdf_out, int out_stride,
                                                                   float *__restrict__ feat_out, int feat_stride,
                                                                   float *__restrict__ grad_out, float4v *__restrict__ ws,
                                                                   size_t vg_off, int Gw) {
-    constexpr int FT = 4, ROWS = 16 * QT, NW = 8, RT = QT / 2, XP = QGeo<4>::XP, EP = QGeo<4>::HW, NJ = FT * QT;
-    __shared__ LdsQ<4> lds;
+    constexpr int ROWS = 16 * QT, NW = 8, RT = QT / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, NJ = FT * QT;
+    static_assert(ROWS <= QGeo<FT>::ROWS, "rows of the LDS image");
+    __shared__ LdsQ<FT> lds;
     __shared__ float raw[ROWS * 9];
     __shared__ float psum[NW * ROWS];
     const int tid = threadIdx.x;
@@ -1183,7 +1193,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
     cur.off = 0;
 #pragma unroll
     for (int u = 0; u < 3; ++u) pload<8>(b[u], cur);
-    const int boff = 64 * wave + lane;
+    const int boff = 16 * FT * wave + (lane & (16 * FT - 1));
     const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4), *ql0 = lds.Xl + (lane & 15) * XP + 8 * (lane >> 4);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t base = tile * ROWS;
@@ -1195,12 +1205,12 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
         }
         float bnext = m.layer[0].bias[boff];
         __syncthreads();
-        encode_tile16q<4>(m, raw, lds, ROWS);
+        encode_tile16q<FT>(m, raw, lds, ROWS);
         __syncthreads();
         // ------------------------------------------------ forward
         for (int l = 0; l < NH; ++l) {
             const nefii_layer &L = m.layer[l];
-            const int units = q_units<4>(L);
+            const int units = q_units<FT>(L);
             const _Float16 *ah = qh0 + (EP - L.k_x), *al = ql0 + (EP - L.k_x);
             const float *bp = m.layer[l + 1 < NH ? l + 1 : l].bias + boff;
             asm volatile("" ::"s"(units), "v"(ah), "v"(al), "v"(bp));
@@ -1214,7 +1224,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
                 for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
             QAct<QT> a[2];
             qload_a<QT, XP>(a[0], ah, al, 0);
-            qgemm<QT, 4>(units, b, a, cur, ah, al, acc);
+            qgemm<QT, FT>(units, b, a, cur, ah, al, acc);
             bnext = *bp;
             __builtin_amdgcn_sched_barrier(0);
             half4 phi[NJ], plo[NJ];
@@ -1239,7 +1249,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
                     plo[j] = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
                     if (feat) {
                         const int64_t row = base + 16 * qt + (lane & 15);
-                        const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+                        const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
                         if (row < n) {
 #pragma unroll
                             for (int k = 0; k < 4; ++k)
@@ -1252,7 +1262,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
             _Float16 *xh = lds.Xh + (EP - L.n_pad), *xl = lds.Xl + (EP - L.n_pad);
 #pragma unroll
             for (int ft = 0; ft < FT; ++ft) {
-                const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+                const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
                     const int query = 16 * qt + (lane & 15);
@@ -1262,8 +1272,45 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
             }
             __syncthreads();
         }
-        // last layer, its one column: 32x32x16 fragments of the layer's own w_f16x3, K split over the waves (as in "16q")
-        {
+        // last layer: 32x32x16 fragments of the layer's own w_f16x3.  One column (use_last_as_f nets): K split over the
+        // waves (as in "16q"); a wide one (SDF + feature columns): whole (column tile, row tile) products per wave.
+        if (m.layer[NH].n_pad > 32) {
+            const int r = lane & 31, h = lane >> 5;
+            const nefii_layer &L = m.layer[NH];
+            const int NT = L.n_pad >> 5, S = L.k_x >> 4;
+            const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
+            for (int c = wave; c < NT * RT; c += NW) {
+                const int t = c / RT, rt = c - t * RT;
+                const _Float16 *ah = lds.Xh + (32 * rt + r) * XP + 8 * h + (EP - L.k_x);
+                const _Float16 *al = lds.Xl + (32 * rt + r) * XP + 8 * h + (EP - L.k_x);
+                f32x16 acc2;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+                for (int s0 = 0; s0 < S; s0 += 4) {
+                    half8 wh[4], wlo[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        wh[u] = wl[((size_t)(s0 + u) * NT + t) * 128], wlo[u] = wl[((size_t)(s0 + u) * NT + t) * 128 + 64];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const half8 xh8 = *reinterpret_cast<const half8 *>(ah + 16 * (s0 + u));
+                        const half8 xl8 = *reinterpret_cast<const half8 *>(al + 16 * (s0 + u));
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], xh8, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo[u], xh8, acc2, 0, 0, 0);
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[u], xl8, acc2, 0, 0, 0);
+                    }
+                }
+                const int64_t row = base + 32 * rt + r;
+                if (row < n) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int f = 32 * t + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (f < L.n_out) sdf_out[(size_t)row * out_stride + f] = acc2[i] * inv_scale + L.bias[f];
+                    }
+                }
+            }
+            __syncthreads();        // every wave is done reading h_{NH-1} from the image
+        } else {
             const int r = lane & 31, h = lane >> 5;
             const nefii_layer &L = m.layer[NH];
             const int NT = L.n_pad >> 5;
@@ -1306,12 +1353,12 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
             const half8 *wlb = reinterpret_cast<const half8 *>(LL.w_bwd_f16x3);       // s16 = 0: outputs 0..7 of lanes 0..31
             const float4v *st = stash + (size_t)(NH - 1) * SL;
             for (int i = tid; i < ROWS * 32; i += 512) {
-                vg_ge_row<QT>(lds, 0, i >> 5)[i & 31] = 0.f;
-                vg_ge_row<QT>(lds, 1, i >> 5)[i & 31] = 0.f;
+                vg_ge_row<FT>(lds, 0, i >> 5)[i & 31] = 0.f;
+                vg_ge_row<FT>(lds, 1, i >> 5)[i & 31] = 0.f;
             }
 #pragma unroll
             for (int ft = 0; ft < FT; ++ft) {
-                const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+                const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
                 float4v wv;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1336,8 +1383,8 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
         }
         for (int l = NH - 1; l >= 1; --l) {
             const nefii_layer &L = m.layer[l];
-            if (L.k_e) vg_enc_grad<QT>(L, lds, wave, lane, inv_scale);
-            const int units = L.n_pad >> 4;
+            if (L.k_e) vg_enc_grad<QT, FT>(L, lds, wave, lane, inv_scale);
+            const int units = vg_units_layer(L.n_pad, FT);
             const _Float16 *ah = qh0 + (EP - L.n_pad), *al = ql0 + (EP - L.n_pad);
             asm volatile("" ::"s"(units), "v"(ah), "v"(al));
             __builtin_amdgcn_s_waitcnt(0x0070);
@@ -1349,7 +1396,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
                 for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
             QAct<QT> a[2];
             qload_a<QT, XP>(a[0], ah, al, 0);
-            qgemm<QT, 4>(units, b, a, cur, ah, al, acc);
+            qgemm<QT, FT>(units, b, a, cur, ah, al, acc);
             half4 phi[NJ], plo[NJ];
             const float4v *st = stash + (size_t)(l - 1) * SL;
 #pragma unroll
@@ -1373,7 +1420,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
             _Float16 *xh = lds.Xh + (EP - L.k_x), *xl = lds.Xl + (EP - L.k_x);
 #pragma unroll
             for (int ft = 0; ft < FT; ++ft) {
-                const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+                const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
                     const int query = 16 * qt + (lane & 15);
@@ -1383,7 +1430,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
             }
             __syncthreads();
         }
-        vg_enc_grad<QT>(m.layer[0], lds, wave, lane, inv_scale);
+        vg_enc_grad<QT, FT>(m.layer[0], lds, wave, lane, inv_scale);
         __syncthreads();
         // chain through the positional encoding
         if (tid < ROWS * 3) {
@@ -1391,7 +1438,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
             if (base + p < n) {
                 const float *v = raw + p * 9;
                 const int w0 = enc_width(m.enc_freqs[0]);
-                const float *g0 = vg_ge_row<QT>(lds, 0, p), *g1 = vg_ge_row<QT>(lds, 1, p);
+                const float *g0 = vg_ge_row<FT>(lds, 0, p), *g1 = vg_ge_row<FT>(lds, 1, p);
                 float g = 0.f;
                 for (int col = 0; col < w0; ++col) {
                     int comp;
@@ -1554,20 +1601,20 @@ extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, voi
                            (half8 *)w_stream + (size_t)8 * (G + G8) * 256, Gs, ft);
         HIP_CHECK_LAUNCH();
     }
-    if (vg_shape(h_sdf)) {
+    if (const int ft = vg_shape(h_sdf)) {
         const int Gb = vg_units_bwd(h_sdf), Gw = G + Gb;
         half8 *dst = (half8 *)w_stream + vg_stream_offset(h_sdf);
-        hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, 4, 0);
+        hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, ft, 0);
         HIP_CHECK_LAUNCH();
-        hipLaunchKernelGGL(pack_sdf_stream_bwd_kernel, dim3(Gb, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, G);
+        hipLaunchKernelGGL(pack_sdf_stream_bwd_kernel, dim3(Gb, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, G, ft);
         HIP_CHECK_LAUNCH();
     }
     return 0;
 }
 
 namespace nefii {
-static int vg_grid(int64_t n) {
-    const int64_t n_tiles = (n + 63) / 64;
+static int vg_grid(int64_t n, int rows) {
+    const int64_t n_tiles = (n + rows - 1) / rows;
     return (int)(n_tiles < 256 ? (n_tiles > 0 ? n_tiles : 1) : 256);     // one workgroup per CU, grid-strided
 }
 // NEFII_VG_STREAM=0: keep the generic 32-row kernel (A/B measurements)
@@ -1579,15 +1626,23 @@ static bool vg_enabled() {
     return v;
 }
 size_t value_grad_stream_ws_bytes(const nefii_mlp *m, int64_t n) {
-    if (!m || n <= 0 || !m->w_stream || !vg_enabled() || !vg_shape(m)) return 0;
-    return (size_t)vg_grid(n) * (m->n_layers - 1) * 8 * 16 * 64 * sizeof(float4v);
+    if (!m || n <= 0 || !m->w_stream || !vg_enabled()) return 0;
+    const int ft = vg_shape(m);
+    if (!ft) return 0;
+    const int rows = ft == 4 ? 64 : 96;        // stash: one float4 per lane and (feature tile, query tile) of a wave
+    return (size_t)vg_grid(n, rows) * (m->n_layers - 1) * 8 * (ft * rows / 16) * 64 * sizeof(float4v);
 }
 int value_grad_stream_launch(const nefii_mlp *m, const float *x, int64_t n, float *sdf_out, int out_stride, float *feat_out,
                              int feat_stride, float *grad_out, float *ws, hipStream_t st) {
-    if (!m->w_stream || !vg_enabled() || !vg_shape(m)) return NEFII_E_UNSUPPORTED;
+    const int ft = m->w_stream && vg_enabled() ? vg_shape(m) : 0;
+    if (!ft) return NEFII_E_UNSUPPORTED;
     const int Gw = stream_steps(m) + vg_units_bwd(m);
-    hipLaunchKernelGGL(sdf_value_grad16q_kernel<4>, dim3(vg_grid(n)), dim3(512), 0, st, *m, x, n, sdf_out, out_stride,
-                       feat_out, feat_stride, grad_out, reinterpret_cast<float4v *>(ws), vg_stream_offset(m), Gw);
+    if (ft == 4)
+        hipLaunchKernelGGL((sdf_value_grad16q_kernel<4, 4>), dim3(vg_grid(n, 64)), dim3(512), 0, st, *m, x, n, sdf_out, out_stride,
+                           feat_out, feat_stride, grad_out, reinterpret_cast<float4v *>(ws), vg_stream_offset(m), Gw);
+    else
+        hipLaunchKernelGGL((sdf_value_grad16q_kernel<6, 2>), dim3(vg_grid(n, 96)), dim3(512), 0, st, *m, x, n, sdf_out, out_stride,
+                           feat_out, feat_stride, grad_out, reinterpret_cast<float4v *>(ws), vg_stream_offset(m), Gw);
     HIP_CHECK_LAUNCH();
     return 0;
 }

@@ -64,30 +64,39 @@ def test_sdf_forward_and_gradient(name, hidden, n):
     assert rel_l2(feat, hid) < 1e-7
 
 
-@pytest.mark.parametrize('n', [1, 63, 64, 65, 1000, 20011])
-def test_sdf_value_grad_on_the_fragment_stream(n):
-    """nefii_sdf_value_grad of a 512-wide net with a fragment stream: forward and backward on the pipelined stream
-    (sdf_value_grad16q_kernel) - value, last-hidden features and d sdf / dx against the fp64 oracle on ragged sizes
-    (tiles of 64 rows; 20011 rows = 313 tiles on 256 workgroups: a second tile per workgroup reuses its stash slot)."""
+@pytest.mark.parametrize('name,n', [('physg', 1), ('physg', 63), ('physg', 64), ('physg', 65), ('physg', 1000),
+                                    ('physg', 20011), ('neus', 1), ('neus', 95), ('neus', 97), ('neus', 1000), ('neus', 30011)])
+def test_sdf_value_grad_on_the_fragment_stream(name, n):
+    """nefii_sdf_value_grad of a net with a fragment stream: forward and backward on the pipelined stream
+    (sdf_value_grad16q_kernel) - value (and feature columns), last-hidden features and d sdf / dx against the fp64
+    oracle on ragged sizes.  physg: 512 wide, 64-row tiles, one-column last layer, features = last hidden activation;
+    neus: 256 wide, 96-row tiles, 257-column last layer.  The big sizes give a workgroup a second tile (its stash slot
+    is reused)."""
     import ctypes
     from nefii_amd import ops, _lib
-    mc = syn.model_conf('physg')
+    mc = syn.model_conf(name)
     sd = syn.make_state_dict(mc, seed=3, bumpy=0.004)
     g = torch.Generator().manual_seed(11)
     for l in mc['implicit_network']['skip_in']:          # live sin/cos columns at the skip layer, as after training
         w = sd['implicit_network.lin%d.weight_v' % l]
         w[:, -36:] = torch.randn(w.shape[0], 36, generator=g) * 0.02
     pm = build_sdf(mc, sd, f16x3=True)
-    n_tiles = (n + 63) // 64
+    rows, slot = (64, 128 * 1024) if name == 'physg' else (96, 96 * 1024)
+    n_tiles = (n + rows - 1) // rows
     assert _lib.lib().nefii_sdf_value_grad_workspace_bytes(ctypes.byref(pm.struct), n) == \
-        min(n_tiles, 256) * (pm.n_layers - 1) * 128 * 1024, 'the streamed kernel did not take this net'
+        min(n_tiles, 256) * (pm.n_layers - 1) * slot, 'the streamed kernel did not take this net'
     x = ball_points(n, 5)
     sd64 = {k: v.double() for k, v in sd.items()}
     ref = nets.sdf_forward(sd64, mc['implicit_network'], x.double())
     gref = nets.sdf_gradient(sd64, mc['implicit_network'], x.double())
-    out, feat, grad = ops.sdf_value_grad(pm, x.to(DEV), want_feat=True)
-    assert (out[:, 0].cpu().double() - ref[:, 0]).abs().max().item() < 3e-6
-    assert (feat.cpu().double() - ref[:, 1:]).abs().max().item() < 3e-6
+    last_as_f = bool(mc['implicit_network'].get('use_last_as_f'))
+    out, feat, grad = ops.sdf_value_grad(pm, x.to(DEV), want_feat=last_as_f)
+    if last_as_f:
+        assert (out[:, 0].cpu().double() - ref[:, 0]).abs().max().item() < 3e-6
+        assert (feat.cpu().double() - ref[:, 1:]).abs().max().item() < 3e-6
+    else:
+        assert out.shape == ref.shape
+        assert (out.cpu().double() - ref).abs().max().item() < 3e-6
     assert (grad.cpu().double() - gref).abs().max().item() < 1e-5
     out2, _, grad2 = ops.sdf_value_grad(pm, x.to(DEV), want_feat=False)
     assert torch.equal(out2, out) and torch.equal(grad2, grad)

@@ -36,5 +36,6 @@ for n in [int(a) for a in sys.argv[1:]] or [4096, 139264]:
     print('n %7d  %.3f ms per call   max|sdf err| %.2e   max|grad err| %.2e   max|feature err| %.2e   all rows finite %s' % (
         n, ms, (out[:m, 0].cpu().double() - y[:, 0].detach()).abs().max().item(),
         (grad[:m].cpu().double() - gr).abs().max().item(),
-        (feat[:m].cpu().double() - y[:, 1:].detach()).abs().max().item() if y.shape[1] == 1 + feat.shape[1] else float('nan'),
+        (feat[:m].cpu().double() - y[:, 1:].detach()).abs().max().item()
+        if mc['implicit_network'].get('use_last_as_f') else (out[:m, 1:].cpu().double() - y[:, 1:].detach()).abs().max().item(),
         bool(torch.isfinite(grad).all() and torch.isfinite(feat).all())))
