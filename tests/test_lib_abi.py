@@ -91,3 +91,44 @@ def test_sdf_stream_size():
         for l, s in enumerate(specs):
             m.layer[l].k_x, m.layer[l].k_e, m.layer[l].n_out, m.layer[l].n_pad = s.k_x, s.k_e, s.n_out, s.n_pad
         assert lib.nefii_sdf_stream_bytes(ctypes.byref(m)) == want
+
+
+def test_value_grad_and_mlp_stream_sizes():
+    """The fourth copy of the SDF stream (forward + transposed units for nefii_sdf_value_grad) appears once every layer
+    carries transposed fragments, and the radiance / material nets' own stream follows the 64-padded K of their layers
+    (sizes only: no kernel runs here)."""
+    from nefii_amd import _lib, ops, synthetic as syn
+    lib = _lib.lib()
+
+    def descriptor(specs, act, with_bwd):
+        m = _lib.Mlp()
+        m.n_layers, m.act, m.reserved = len(specs), act, 1
+        for l, s in enumerate(specs):
+            L = m.layer[l]
+            L.k_x, L.k_e, L.n_out, L.n_pad = s.k_x, s.k_e, s.n_out, s.n_pad
+            L.w_f16x3, L.bias = 64, 64                  # non-null: only looked at, never read
+            L.w_bwd_f16x3 = 64 if with_bwd else None
+        return m
+
+    for name, fwd_units, plain in [('physg', 4 + 32 * 3 + 36 + 32 * 3, None), ('neus', 4 + 8 * 3 + 12 + 8 * 3, None)]:
+        mc = syn.model_conf(name)
+        specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
+        m0, m1 = descriptor(specs, ops.ACT_SOFTPLUS100, False), descriptor(specs, ops.ACT_SOFTPLUS100, True)
+        for m in (m0, m1):
+            m.enc_freqs[0], m.enc_freqs[1], m.enc_freqs[2] = enc[0], -1, -1
+        base = lib.nefii_sdf_stream_bytes(ctypes.byref(m0))
+        bwd_units = (len(specs) - 2) * (32 if name == 'physg' else 8)
+        assert lib.nefii_sdf_stream_bytes(ctypes.byref(m1)) == base + 8 * (fwd_units + bwd_units) * 4096
+        m1.act = ops.ACT_RELU                           # the streamed kernel is the softplus nets'
+        assert lib.nefii_sdf_stream_bytes(ctypes.byref(m1)) == base
+    mc = syn.model_conf('conf')
+    F = mc['feature_vector_size']
+    specs, enc, head = ops.radiance_specs(mc['rendering_network'], F)
+    assert lib.nefii_mlp_stream_bytes(ctypes.byref(descriptor(specs, ops.ACT_RELU, False))) == \
+        8 * ((512 + 128) // 16 + 3 * 32) * 4096         # layer 0: 512 features + 96 encoding columns, K 608 -> 640
+    specs, enc = ops.material_specs(mc['envmap_material_network'], F, 4)
+    assert lib.nefii_mlp_stream_bytes(ctypes.byref(descriptor(specs, ops.ACT_ELU, False))) == \
+        8 * ((512 + 64) // 16 + (len(specs) - 2) * 32) * 4096
+    specs, enc, head = ops.radiance_specs(syn.model_conf('conf', hidden=64)['rendering_network'], 64)
+    assert lib.nefii_mlp_stream_bytes(ctypes.byref(descriptor(specs, ops.ACT_RELU, False))) == 0
+

@@ -37,5 +37,5 @@ for n in [int(a) for a in sys.argv[1:]] or [4096, 139264]:
         n, ms, (out[:m, 0].cpu().double() - y[:, 0].detach()).abs().max().item(),
         (grad[:m].cpu().double() - gr).abs().max().item(),
         (feat[:m].cpu().double() - y[:, 1:].detach()).abs().max().item()
-        if mc['implicit_network'].get('use_last_as_f') else (out[:m, 1:].cpu().double() - y[:, 1:].detach()).abs().max().item(),
+        if out.shape[1] == 1 else (out[:m, 1:].cpu().double() - y[:, 1:].detach()).abs().max().item(),
         bool(torch.isfinite(grad).all() and torch.isfinite(feat).all())))
