@@ -151,6 +151,43 @@ def test_sdf_eval_split_precision(name, hidden, n):
         assert (out - f32).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize('name,n', [('conf', 1), ('conf', 65), ('conf', 1000), ('neus', 129)])
+def test_streamed_mlp_forward_matches_the_f32_kernels(name, n):
+    """The split-precision forward of the radiance / material nets on the fragment stream (mlp_forward16q_kernel, 64-row
+    tiles): outputs, the last hidden activation and EVERY layer's stash row against the f32-input MFMA kernels on ragged
+    sizes (the stash feeds nefii_mlp_backward_f16 / _wgrad_f16)."""
+    from nefii_amd import ops
+    mc = syn.model_conf(name)
+    sd = syn.make_state_dict(mc, seed=4)
+    F = mc['feature_vector_size']
+    g = torch.Generator().manual_seed(6)
+    x = ball_points(n, 8).to(DEV)
+    v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(DEV)
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(DEV)
+    feat = (torch.randn(n, F, generator=g) * 0.3).to(DEV)
+    specs, enc, head = ops.radiance_specs(mc['rendering_network'], F)
+    rw = [nets.linear_params(sd, 'rendering_network.lin%d' % l) for l in range(len(specs))]
+    mcfg = mc['envmap_material_network']
+    mspecs, menc = ops.material_specs(mcfg, F, 4 if mcfg.get('roughness_mlp') else 3)
+    lp = 'envmap_material_network.diffuse_albedo_layers'
+    mw = [(sd['%s.%d.weight' % (lp, 2 * l)], sd['%s.%d.bias' % (lp, 2 * l)]) for l in range(len(mspecs))]
+    for sp, en, act, hd, wb, args in ((specs, enc, ops.ACT_RELU, head, rw, (x, v, nrm, feat)),
+                                      (mspecs, menc, ops.ACT_ELU, ops.HEAD_SIGMOID, mw, (x, None, None, feat))):
+        outs = []
+        for half in ('f16x3', False):
+            pm = ops.PackedMLP(sp, act, hd, en, F, DEV, half=half)
+            pm.pack([w.to(DEV) for w, _ in wb], [b.to(DEV) for _, b in wb])
+            if half:
+                assert pm.mlp_stream, 'the streamed kernel did not take this net'
+            outs.append(ops.mlp_forward(pm, *args, want_hidden=True, want_stash=True))
+        (o16, h16, s16), (o32, h32, s32) = outs
+        assert (o16 - o32).abs().max().item() < 2e-5
+        assert (h16 - h32).abs().max().item() < 2e-5
+        for l in range(len(sp)):
+            w = sp[l].n_out
+            assert (s16[l, :, :w] - s32[l, :, :w]).abs().max().item() < 3e-5, l
+
+
 @pytest.mark.parametrize('half', [False, 'f16x3', 'f16'])
 @pytest.mark.parametrize('name,hidden,n', [('physg', 64, 500), ('conf', 64, 301), ('conf', 512, 200), ('physg', 512, 64),
                                            ('conf', 512, 3000)])
