@@ -33,9 +33,13 @@ for n in [int(a) for a in sys.argv[1:]] or [4096, 139264]:
     xr = x[:m].cpu().double().requires_grad_(True)
     y = nets.sdf_forward(sd64, mc['implicit_network'], xr)
     gr, = torch.autograd.grad(y[:, 0].sum(), xr)
+    if y.shape[1] == 1 + feat.shape[1]:          # use_last_as_f nets: the feature columns are the last hidden activation
+        ferr = (feat[:m].cpu().double() - y[:, 1:].detach()).abs().max().item()
+    elif out.shape[1] > 1:                       # the last layer carries the feature columns itself
+        ferr = (out[:m, 1:].cpu().double() - y[:, 1:].detach()).abs().max().item()
+    else:
+        ferr = float('nan')
     print('n %7d  %.3f ms per call   max|sdf err| %.2e   max|grad err| %.2e   max|feature err| %.2e   all rows finite %s' % (
         n, ms, (out[:m, 0].cpu().double() - y[:, 0].detach()).abs().max().item(),
-        (grad[:m].cpu().double() - gr).abs().max().item(),
-        (feat[:m].cpu().double() - y[:, 1:].detach()).abs().max().item()
-        if out.shape[1] == 1 else (out[:m, 1:].cpu().double() - y[:, 1:].detach()).abs().max().item(),
+        (grad[:m].cpu().double() - gr).abs().max().item(), ferr,
         bool(torch.isfinite(grad).all() and torch.isfinite(feat).all())))
