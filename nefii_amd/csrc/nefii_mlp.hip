@@ -1113,6 +1113,158 @@ __global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const float *__restric
     }
 }
 
+// ---- the same product as a blocked GEMM (layers of at least 64 x 64 weights) ---------------------------------------------
+// The kernel above feeds each 32x32x16 MFMA from 40 scalar loads per lane (dz and x are POINT-major, the MFMA wants 8
+// consecutive points per lane): it is bound by vector-memory issue.  Here a workgroup of 4 waves owns a 128 x 128 block of
+// dW over a slice of the points: 32-point slabs of dz (x S) and x go through LDS as fp16 [point][column] rows (16-byte
+// global loads, coalesced 512 B per row; two slabs in flight), and the MFMA operands come back TRANSPOSED through
+// ds_read_b64_tr_b16 (gfx950: a 16-lane group reads 4 rows x 16 columns and each lane receives one column) - two reads
+// per operand fragment, no shuffles.  Row stride 160 halves (320 B): the four rows of a block fall 16 banks apart and the
+// half-wave's second block 8 banks further, so every transposed read is conflict-free.  Blocks of one point slice are
+// mapped to ONE XCD (workgroups are dealt round-robin over the 8 XCDs): its 16 column blocks share the slice's rows in
+// that XCD's L2 instead of fetching them eight times.  Partial products leave with one atomic per element and block.
+constexpr int WG2_ROWS = 32, WG2_STRIDE = 160, WG2_POINTS = 4096;
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ half8 wg2_fragment(const _Float16 *tile, int col0, int row0, int lane) {
+    // block rows row0 .. row0+3 (then +4 .. +7), columns col0 + 16 ((lane>>4)&1) + 0..15; lane 4q+p of a 16-lane group
+    // addresses row q, columns 4p .. 4p+3
+    const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3;
+    const _Float16 *a = tile + (row0 + 8 * (lane >> 5) + q) * WG2_STRIDE + col0 + 16 * ((lane >> 4) & 1) + 4 * pp;
+    typedef short4v __attribute__((address_space(3))) * lds_ptr;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a));
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * WG2_STRIDE));
+    const half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
+    return half8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
+}
+
+template <bool XVEC>
+__global__ __launch_bounds__(256, 2) void mlp_wgrad16t_kernel(const float *__restrict__ dz, int dz_stride,
+                                                              const float *__restrict__ x, int x_stride, int64_t P, int n_out,
+                                                              int k_in, float scale, const float *__restrict__ gscale,
+                                                              float *__restrict__ dW, float *__restrict__ db, int splits,
+                                                              int tiles_n, int tiles_k) {
+    __shared__ __attribute__((aligned(16))) _Float16 A[2][WG2_ROWS * WG2_STRIDE], B[2][WG2_ROWS * WG2_STRIDE];
+    // XCD-aware order: the tiles_n * tiles_k blocks of one point slice get consecutive positions on one XCD
+    const int nt = tiles_n * tiles_k;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % nt, slice = 8 * (j / nt) + xcd;
+    if (slice >= splits) return;
+    const int tn = tile % tiles_n, tk = tile / tiles_n;
+    const int n0 = 128 * tn, k0 = 128 * tk;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int64_t chunk = ((P + splits - 1) / splits + WG2_ROWS - 1) / WG2_ROWS * WG2_ROWS;
+    const int64_t p_begin = (int64_t)slice * chunk;
+    const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;
+    if (p_begin >= p_end) return;
+    const float S = gscale[0];
+    // staging: thread -> columns 4 c4 .. 4 c4+3 of rows r8, r8 + 8, r8 + 16, r8 + 24
+    const int c4 = tid & 31, r8 = tid >> 5;
+    const int na = n0 + 4 * c4, ka = k0 + 4 * c4;
+    const bool n_in = na + 3 < n_out, k_in_ok = ka + 3 < k_in;      // whole float4 inside (else element-wise)
+    float4v ra[4], rb[4];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto fetch = [&](int64_t pb) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pr = pb + r8 + 8 * u;
+            const int64_t pc = pr < p_end ? pr : p_end - 1;
+            const bool live = pr < p_end;
+            float4v a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+            if (n_in) {
+                a = *reinterpret_cast<const float4v *>(dz + pc * dz_stride + na);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = dz[pc * dz_stride + (na + e < n_out ? na + e : n_out - 1)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = na + e < n_out ? a[e] : 0.f;
+            }
+            if (XVEC && k_in_ok) {
+                b = *reinterpret_cast<const float4v *>(x + pc * x_stride + ka);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = x[pc * x_stride + (ka + e < k_in ? ka + e : k_in - 1)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[e] = ka + e < k_in ? b[e] : 0.f;
+            }
+            ra[u] = live ? a : float4v{0.f, 0.f, 0.f, 0.f};
+            rb[u] = live ? b : float4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[e] += ra[u][e];
+            const int off = (r8 + 8 * u) * WG2_STRIDE + 4 * c4;
+            *reinterpret_cast<half4 *>(&A[buf][off]) = __builtin_convertvector(ra[u] * S, half4);
+            *reinterpret_cast<half4 *>(&B[buf][off]) = __builtin_convertvector(rb[u], half4);
+        }
+    };
+    f32x16 acc[4];
+    zero_acc(acc);
+    const int an = 64 * (wave & 1), bk = 64 * (wave >> 1);
+    fetch(p_begin);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t pb = p_begin; pb < p_end; pb += WG2_ROWS) {
+        const bool more = pb + WG2_ROWS < p_end;
+        if (more) fetch(pb + WG2_ROWS);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = wg2_fragment(A[buf], an + 32 * t, 16 * ks, lane);
+                bf[t] = wg2_fragment(B[buf], bk + 32 * t, 16 * ks, lane);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 2; ++v)
+                    acc[2 * t + v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[t], bf[v], acc[2 * t + v], 0, 0, 0);
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const float os = scale / S;
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = n0 + an + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h, k = k0 + bk + 32 * v + i;
+                if (nn < n_out && k < k_in) atomicAdd(&dW[(size_t)nn * k_in + k], acc[2 * t + v][r] * os);
+            }
+    if (db && tk == 0) {
+        // column sums of this thread's rows: reduce the 8 row groups through LDS, then one atomic per column and block
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(&A[0][0]);         // [8][128]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[r8 * 128 + 4 * c4 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 128 && n0 + tid < n_out) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) sum += red[g * 128 + tid];
+            atomicAdd(&db[n0 + tid], sum);
+        }
+    }
+}
+
+// NEFII_WGRAD_TR=0: keep the scalar-load kernel (A/B measurements)
+static bool wgrad_tr_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("NEFII_WGRAD_TR");
+        return !(e && atoi(e) == 0);
+    }();
+    return v;
+}
+
 extern "C" int nefii_mlp_wgrad_f16(const float *dz, int dz_stride, const float *x, int x_stride, int64_t n, int n_out,
                                    int k_in, float scale, const float *gscale, float *dW, float *db, void *stream) {
     if (!dz || !x || !dW || !gscale || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
@@ -1130,6 +1282,22 @@ extern "C" int nefii_mlp_wgrad_f16(const float *dz, int dz_stride, const float *
         }
     }
     if (n <= 0) return 0;
+    if (wgrad_tr_enabled() && n_out >= 64 && k_in >= 64 && n >= 1024 && (dz_stride & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(dz) & 15) == 0) {
+        // blocked GEMM with transposed LDS reads; dW / db were zeroed above (n >= 1024 > 256 points: split > 1)
+        int splits = (int)((n + WG2_POINTS - 1) / WG2_POINTS);
+        splits = (splits + 7) / 8 * 8;
+        const int tiles_n = (n_out + 127) / 128, tiles_k = (k_in + 127) / 128;
+        const unsigned blocks = (unsigned)(tiles_n * tiles_k * splits);
+        if ((x_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+            hipLaunchKernelGGL(mlp_wgrad16t_kernel<true>, dim3(blocks), dim3(256), 0, st, dz, dz_stride, x, x_stride, n, n_out,
+                               k_in, scale, gscale, dW, db, splits, tiles_n, tiles_k);
+        else
+            hipLaunchKernelGGL(mlp_wgrad16t_kernel<false>, dim3(blocks), dim3(256), 0, st, dz, dz_stride, x, x_stride, n, n_out,
+                               k_in, scale, gscale, dW, db, splits, tiles_n, tiles_k);
+        HIP_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid((n_out + 63) / 64, (k_in + 255) / 256, split);
     hipLaunchKernelGGL(mlp_wgrad16_kernel, grid, dim3(256), 0, st, dz, dz_stride, x, x_stride, n, n_out, k_in, scale, gscale,
                        dW, db, split > 1 ? 1 : 0);

@@ -151,6 +151,34 @@ def test_sdf_eval_split_precision(name, hidden, n):
         assert (out - f32).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize('n,n_out,k_in,x_stride', [(5000, 512, 512, 512), (4097, 512, 605, 605), (1024, 512, 575, 576),
+                                                    (70001, 512, 512, 512), (3000, 100, 200, 200), (2000, 3, 512, 512)])
+def test_weight_gradient_gemm_fp16(n, n_out, k_in, x_stride):
+    """nefii_mlp_wgrad_f16: dW = scale * dz^T x and db = column sums of dz, with S dz and x rounded to fp16 and fp32
+    accumulation - against the same product in torch on the rounded operands.  Layers of at least 64 x 64 weights and 1024
+    points take the blocked kernel (LDS slabs read back transposed by ds_read_b64_tr_b16; ragged point counts, a k_in that
+    is not a multiple of 128 or of 4, a partial column block); the small ones the scalar-load kernel."""
+    import ctypes
+    from nefii_amd import _lib
+    from nefii_amd.ops import _ptr, _stream
+    g = torch.Generator().manual_seed(n + k_in)
+    dz = (torch.randn(n, 512, generator=g) * 3e-7).to(DEV)           # gradients as small as in training
+    dz[:, n_out:] = 0
+    x = torch.randn(n, x_stride, generator=g).to(DEV)
+    S = torch.tensor([2.0 ** 28], device=DEV)
+    scale = 0.7
+    dW = torch.full((n_out, k_in), 7.0, device=DEV)
+    db = torch.full((n_out,), 7.0, device=DEV)
+    _lib.check(_lib.lib().nefii_mlp_wgrad_f16(_ptr(dz), 512, _ptr(x), x_stride, n, n_out, k_in, scale, _ptr(S), _ptr(dW),
+                                              _ptr(db), _stream()), 'nefii_mlp_wgrad_f16')
+    a = (dz[:, :n_out].double() * S.double()).half().double()
+    b = x[:, :k_in].half().double()
+    want = (a.t() @ b) * (scale / S.double())
+    assert rel_l2(dW, want) < 2e-6, rel_l2(dW, want)
+    assert ((dW.double() - want).abs().max() / want.abs().max()).item() < 2e-5
+    assert rel_l2(db, dz[:, :n_out].double().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize('name,n', [('conf', 1), ('conf', 65), ('conf', 1000), ('neus', 129)])
 def test_streamed_mlp_forward_matches_the_f32_kernels(name, n):
     """The split-precision forward of the radiance / material nets on the fragment stream (mlp_forward16q_kernel, 64-row
