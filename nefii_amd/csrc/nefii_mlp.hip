@@ -636,9 +636,22 @@ static int mstream_units(const nefii_mlp *m) {
     return G;
 }
 
+// backward copy (layers with transposed fragments): for l = NL-1 .. 1 the 32-deep k-steps of the transposed layer -
+// contraction over layer l's outputs, padded to a multiple of 128 - hi fragments of the wave's 4 feature tiles (its 64 of
+// the layer's 512 hidden inputs); the one-pass fp16 backward (mlp_backward16s_kernel) reads it
+__host__ __device__ __forceinline__ int mb_units(const nefii_layer &L) { return ((L.n_pad + 127) & ~127) >> 5; }
+static int mstream_units_bwd(const nefii_mlp *m) {
+    int G = 0;
+    for (int l = 1; l < m->n_layers; ++l) {
+        if (!m->layer[l].w_bwd_f16x3) return 0;
+        G += mb_units(m->layer[l]);
+    }
+    return G;
+}
+
 extern "C" size_t nefii_mlp_stream_bytes(const nefii_mlp *h_mlp) {
     if (!h_mlp || h_mlp->n_layers < 2 || h_mlp->n_layers > NEFII_MAX_LAYERS || !mstream_shape(h_mlp)) return 0;
-    return (size_t)8 * mstream_units(h_mlp) * 256 * sizeof(half8);
+    return (size_t)8 * (mstream_units(h_mlp) + mstream_units_bwd(h_mlp)) * 256 * sizeof(half8);
 }
 
 // dst[((wave*G + g)*4 + 2 f + part)*64 + lane][j] = W[n = 64 wave + 16 (2 (g&1) + f) + (lane&15)][k = 32 (g>>1) + 8 (lane>>4) + j]
@@ -659,12 +672,36 @@ __global__ void pack_mlp_stream_kernel(nefii_mlp m, half8 *__restrict__ dst, int
     dst[((size_t)wave * G + g) * 256 + threadIdx.x] = v;
 }
 
+// dst[((wave*G + g)*4 + f)*64 + lane][j] = hi(W_l[n = 32 s + 8 (lane>>4) + j][k = 64 wave + 16 f + (lane&15)]) for unit g =
+// (layer l counted down from the last, 32-deep step s); zeros past the layer's own outputs
+__global__ void pack_mlp_stream_bwd_kernel(nefii_mlp m, half8 *__restrict__ dst, int G) {
+    const int g = blockIdx.x, wave = blockIdx.y;
+    int l = m.n_layers - 1, s = g;
+    while (s >= mb_units(m.layer[l])) s -= mb_units(m.layer[l]), --l;
+    const nefii_layer &L = m.layer[l];
+    const half8 *wb = reinterpret_cast<const half8 *>(L.w_bwd_f16x3);
+    const int KT = (L.k_x + L.k_e) >> 5;
+    const int f = threadIdx.x >> 6, lane = threadIdx.x & 63, kg = lane >> 4;
+    const int kk = 64 * wave + 16 * f + (lane & 15);
+    const int s16 = 2 * s + (kg >> 1), t = kk >> 5, lane_src = (kk & 31) + 32 * (kg & 1);
+    half8 v;
+    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+    if (s16 < (L.n_pad >> 4)) v = wb[(((size_t)s16 * KT + t) * 2) * 64 + lane_src];
+    dst[((size_t)wave * G + g) * 256 + threadIdx.x] = v;
+}
+
 extern "C" int nefii_pack_mlp_stream(const nefii_mlp *h_mlp, void *w_stream, void *stream) {
     if (!h_mlp || !w_stream) return NEFII_E_ARG;
     if (nefii_mlp_stream_bytes(h_mlp) == 0) return NEFII_E_UNSUPPORTED;
     const int G = mstream_units(h_mlp);
     hipLaunchKernelGGL(pack_mlp_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_mlp, (half8 *)w_stream, G);
     HIP_CHECK_LAUNCH();
+    const int Gb = mstream_units_bwd(h_mlp);
+    if (Gb > 0) {
+        hipLaunchKernelGGL(pack_mlp_stream_bwd_kernel, dim3(Gb, 8), dim3(256), 0, (hipStream_t)stream, *h_mlp,
+                           (half8 *)w_stream + (size_t)8 * G * 256, Gb);
+        HIP_CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -1015,6 +1052,114 @@ __global__ __launch_bounds__(256, 2) void mlp_backward16_kernel(nefii_mlp m, con
     }
 }
 
+// The one-pass fp16 backward on the fragment stream (nets mstream_shape() takes): the single-pass evaluator's machine
+// (mlp_tile.h "16s": hi fragments, one 32-deep k-step of the wave's four feature tiles per 4 KiB unit, hi-only activation
+// image of 64 rows) over the transposed layers, last to first.  The image holds S dz_l in fp16, a layer's k-loop contracts
+// over its outputs, the epilogue multiplies by act'(h_{l-1}) from the forward's stash, writes dz_{l-1} (fp32, row-major:
+// what nefii_mlp_wgrad_f16 reads) and parks S dz_{l-1} as the next image.  The 32-row kernel above fetched each layer's
+// fragments per tile with nothing in flight (~30 GB/s per CU).
+__global__ __launch_bounds__(512, 2) void mlp_backward16s_kernel(nefii_mlp m, const float *__restrict__ d_out, int out_stride,
+                                                                const float *__restrict__ stash, int stash_stride, int64_t n,
+                                                                float *__restrict__ dz, int dz_stride,
+                                                                const float *__restrict__ scale, size_t stream_off, int G) {
+    constexpr int QT = 4, FT = 4, ROWS = 64, XP = QGeo<4>::XP, NJ = FT * QT;
+    __shared__ LdsS<4, ROWS> lds;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int Lm1 = m.n_layers - 1;
+    const float S = scale[0];
+    const float inv = 1.f / (W16_SCALE * S);
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
+    {   // the K-padded stream meets whatever follows a layer's own columns with zero weights: keep the image finite
+        uint32_t *z = reinterpret_cast<uint32_t *>(&lds);
+        for (int i = tid; i < (int)(sizeof(lds) / 4); i += 512) z[i] = 0u;
+    }
+    SStage<4> b[4];
+    PCursor cur;
+    cur.bytes = (unsigned)G * 4096;
+    cur.base = reinterpret_cast<const half8 *>(m.w_stream) + stream_off + (size_t)wave * G * 256 + lane;
+    cur.off = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) sload<4>(b[u], cur);
+    const _Float16 *qh0 = lds.Xh + (lane & 15) * XP + 8 * (lane >> 4);
+    __syncthreads();
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t base = tile * ROWS;
+        {   // seed: dz_last = d_out * head'(pre); the last layer's n_pad columns of the image (zeros past n_out)
+            const nefii_layer &L = m.layer[Lm1];
+            const int kpad = mb_units(L) * 32;          // the columns the first k-loop reads: zeros past the layer's outputs
+            for (int i = tid; i < ROWS * kpad; i += 512) {
+                const int p = i / kpad, c = i - p * kpad;
+                float v = 0.f;
+                if (base + p < n && c < L.n_pad) {
+                    if (c < L.n_out) {
+                        const float pre = stash[((size_t)Lm1 * n + base + p) * stash_stride + c];
+                        const float y = head_fwd(pre, m.head);
+                        v = d_out[(size_t)(base + p) * out_stride + c] * head_bwd_from_out(y, pre, m.head);
+                    }
+                    dz[((size_t)Lm1 * n + base + p) * dz_stride + c] = v;
+                }
+                lds.Xh[p * XP + c] = (_Float16)(v * S);
+            }
+        }
+        __syncthreads();
+        for (int l = Lm1; l >= 1; --l) {
+            const nefii_layer &L = m.layer[l];
+            const int units = mb_units(L);
+            asm volatile("" ::"s"(units));
+            __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see "16p")
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+            SAct<QT> a[2];
+            sload_a<QT, XP>(a[0], qh0, 0);
+            sgemm<QT, FT, true>(units, b, a, cur, qh0, acc);
+            // dH_{l-1} -> dz_{l-1} = dH * act'(h_{l-1}); rows past n carry zeros
+            half4 phi[NJ];
+            const float *sp = stash + (size_t)(l - 1) * n * stash_stride;
+            float *dp = dz + (size_t)(l - 1) * n * dz_stride;
+            auto epilogue = [&](auto actc) {
+                constexpr int ACT = decltype(actc)::value;
+#pragma unroll
+                for (int ft = 0; ft < FT; ++ft) {
+                    const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const int j = ft * QT + qt;
+                        const int64_t row = base + 16 * qt + (lane & 15);
+                        float4v v = {0.f, 0.f, 0.f, 0.f};
+                        if (row < n) {
+                            const float4v h = *reinterpret_cast<const float4v *>(sp + (size_t)row * stash_stride + f0);
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) v[k] = acc[j][k] * inv * act_bwd_from_out(h[k], ACT);
+                            *reinterpret_cast<float4v *>(dp + (size_t)row * dz_stride + f0) = v;
+                        }
+                        phi[j] = __builtin_convertvector(v * S, half4);
+                    }
+                }
+            };
+            if (m.act == NEFII_ACT_RELU)
+                epilogue(std::integral_constant<int, NEFII_ACT_RELU>{});
+            else if (m.act == NEFII_ACT_ELU)
+                epilogue(std::integral_constant<int, NEFII_ACT_ELU>{});
+            else
+                epilogue(std::integral_constant<int, NEFII_ACT_SOFTPLUS100>{});
+            __syncthreads();
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) {
+                const int f0 = 64 * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+                    *reinterpret_cast<half4 *>(lds.Xh + (16 * qt + (lane & 15)) * XP + f0) = phi[ft * QT + qt];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 extern "C" int nefii_mlp_backward_f16(const nefii_mlp *h_mlp, const float *d_out, int out_stride, const float *stash,
                                       int stash_stride, int64_t n, float *dz, int dz_stride, const float *scale,
                                       void *stream) {
@@ -1022,6 +1167,15 @@ extern "C" int nefii_mlp_backward_f16(const nefii_mlp *h_mlp, const float *d_out
     if (rc) return rc;
     if (n <= 0) return 0;
     if (!d_out || !stash || !dz || !scale) return NEFII_E_ARG;
+    if (h_mlp->w_stream && mlp_stream_enabled() && mstream_shape(h_mlp) && mstream_units_bwd(h_mlp) > 0 &&
+        (stash_stride & 3) == 0 && (dz_stride & 3) == 0) {
+        const int64_t t = (n + 63) / 64;
+        hipLaunchKernelGGL(mlp_backward16s_kernel, dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream, *h_mlp,
+                           d_out, out_stride, stash, stash_stride, n, dz, dz_stride, scale,
+                           (size_t)8 * mstream_units(h_mlp) * 256, mstream_units_bwd(h_mlp));
+        HIP_CHECK_LAUNCH();
+        return 0;
+    }
     const int64_t n_tiles = (n + TILE - 1) / TILE;
     hipLaunchKernelGGL(mlp_backward16_kernel, dim3(grid_for(n_tiles, 2)), dim3(WG), 0, (hipStream_t)stream, *h_mlp, d_out,
                        out_stride, stash, stash_stride, n, dz, dz_stride, scale);

@@ -151,6 +151,43 @@ def test_sdf_eval_split_precision(name, hidden, n):
         assert (out - f32).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize('name,n', [('conf', 1), ('conf', 65), ('conf', 2000), ('neus', 129)])
+def test_streamed_mlp_backward_matches_the_f32_kernels(name, n):
+    """nefii_mlp_backward_f16 on the fragment stream (mlp_backward16s_kernel: one fp16 pass, 64-row tiles) against the
+    f32-input MFMA backward on the same stash and output gradient: every layer's dz within the one-pass fp16 error, with
+    gradients as small as in training (carried by the power-of-two scale)."""
+    from nefii_amd import ops
+    mc = syn.model_conf(name)
+    sd = syn.make_state_dict(mc, seed=4)
+    F = mc['feature_vector_size']
+    g = torch.Generator().manual_seed(16)
+    x = ball_points(n, 8).to(DEV)
+    v = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(DEV)
+    nrm = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(DEV)
+    feat = (torch.randn(n, F, generator=g) * 0.3).to(DEV)
+    specs, enc, head = ops.radiance_specs(mc['rendering_network'], F)
+    rw = [nets.linear_params(sd, 'rendering_network.lin%d' % l) for l in range(len(specs))]
+    mcfg = mc['envmap_material_network']
+    mspecs, menc = ops.material_specs(mcfg, F, 4 if mcfg.get('roughness_mlp') else 3)
+    lp = 'envmap_material_network.diffuse_albedo_layers'
+    mw = [(sd['%s.%d.weight' % (lp, 2 * l)], sd['%s.%d.bias' % (lp, 2 * l)]) for l in range(len(mspecs))]
+    for sp, en, act, hd, wb, args in ((specs, enc, ops.ACT_RELU, head, rw, (x, v, nrm, feat)),
+                                      (mspecs, menc, ops.ACT_ELU, ops.HEAD_SIGMOID, mw, (x, None, None, feat))):
+        pm32 = ops.PackedMLP(sp, act, hd, en, F, DEV, half=False)
+        pm16 = ops.PackedMLP(sp, act, hd, en, F, DEV, half='f16x3')
+        for pm in (pm32, pm16):
+            pm.pack([w.to(DEV) for w, _ in wb], [b.to(DEV) for _, b in wb])
+        assert pm16.mlp_stream, 'the streamed kernels did not take this net'
+        out, _, stash = ops.mlp_forward(pm32, *args, want_stash=True)
+        d_out = (torch.randn(n, out.shape[1], generator=g) * 1e-6).to(DEV)
+        dz32 = ops.mlp_backward(pm32, d_out, stash)
+        dz16 = ops.mlp_backward(pm16, d_out, stash, ops.mlp_grad_scale(d_out))
+        for l in range(len(sp)):
+            w = sp[l].n_out
+            assert torch.isfinite(dz16[l, :, :w]).all()
+            assert rel_l2(dz16[l, :, :w], dz32[l, :, :w]) < 4e-3, (l, rel_l2(dz16[l, :, :w], dz32[l, :, :w]))
+
+
 @pytest.mark.parametrize('n,n_out,k_in,x_stride', [(5000, 512, 512, 512), (4097, 512, 605, 605), (1024, 512, 575, 576),
                                                     (70001, 512, 512, 512), (3000, 100, 200, 200), (2000, 3, 512, 512)])
 def test_weight_gradient_gemm_fp16(n, n_out, k_in, x_stride):

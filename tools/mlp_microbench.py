@@ -1,5 +1,5 @@
-"""nefii_mlp_forward_f16 (split-precision forward of the radiance and material MLPs, training mode: with stash) - time
-per call at n points.  NEFII_MLP_STREAM=0 selects the 32-row kernel.  Usage: python tools/mlp_microbench.py [n ...]"""
+"""nefii_mlp_forward_f16 (split-precision forward of the radiance and material MLPs, with / without the stash) and
+nefii_mlp_backward_f16 (one fp16 pass) - time per call at n points.  NEFII_MLP_STREAM=0 selects the 32-row kernel.  Usage: python tools/mlp_microbench.py [n ...]"""
 import os
 import sys
 
@@ -52,5 +52,18 @@ for kind in ('radiance', 'material'):
             e1.record()
             torch.cuda.synchronize()
             ms[want] = e0.elapsed_time(e1) / 10
-        print('%-9s %s  n %7d  %.3f ms per call with stash, %.3f without   streamed %s   finite %s' % (
-            kind, name, n, ms[True], ms[False], pm.mlp_stream, bool(torch.isfinite(out).all())))
+        out, hid, stash = ops.mlp_forward(*args, want_stash=True)
+        d_out = torch.randn_like(out) * 1e-6
+        gs = ops.mlp_grad_scale(d_out)
+        for _ in range(3):
+            dz = ops.mlp_backward(pm, d_out, stash, gs)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dz = ops.mlp_backward(pm, d_out, stash, gs)
+        e1.record()
+        torch.cuda.synchronize()
+        print('%-9s %s  n %7d  forward %.3f ms per call with stash, %.3f without; backward %.3f   streamed %s   finite %s' % (
+            kind, name, n, ms[True], ms[False], e0.elapsed_time(e1) / 10, pm.mlp_stream,
+            bool(torch.isfinite(out).all() and torch.isfinite(dz).all())))
