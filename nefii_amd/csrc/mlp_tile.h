@@ -535,22 +535,26 @@ __device__ __forceinline__ float softplus100_s16(float zs) {
 
 // The same for the single-pass (coarse) evaluator, two values per instruction in packed fp16: its results are rounded to
 // fp16 anyway, and what the coarse pass may get wrong is measured per network (nefii_tracer_params.coarse_tau), so the
-// epilogue - half of that evaluator's tile time at 52 VALU cycles per value - can afford fp16 arithmetic behind the
-// fp32 bias add: |z| (v_and), x C_T (v_pk_mul), 2 x v_exp_f16, + 1 (v_pk_add), 2 x v_log_f16, max(z, 0) (v_pk_max),
-// fma (v_pk_fma): 32 cycles per value.
+// epilogue - a quarter of that evaluator's tile time, and paced by the quarter-rate transcendental unit - can afford fp16
+// arithmetic behind the fp32 bias add, and ONE transcendental per value instead of two:
+//   16 softplus = max(zs, 0) + (16 ln2 / 100) log2(1 + e),  e = 2^(-|zs| 100 log2(e) / 16) in (0, 1],
+//   log2(1 + e) ~ e (a1 + e (a2 + e (a3 + e a4)))  (minimax on [0, 1]: 1.0e-4; with the fp16 Horner steps the result is
+//   within 3.1e-4 of the exact value, the v_exp / v_add / v_log chain it replaces within 3.2e-4).
+// |z| (v_and), x C_T (v_pk_mul), 2 x v_exp_f16, 4 x v_pk_fma (the last one adds max(z, 0), v_pk_max).
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ half2v softplus100_s16_pk(half2v zs) {
     const _Float16 C_T = (_Float16)(-1.44269504088896340736f * 100.f / A16_SCALE);
-    const _Float16 C_L = (_Float16)(0.69314718055994530942f * A16_SCALE / 100.f);
+    constexpr float C_L = 0.69314718055994530942f * A16_SCALE / 100.f;
+    const _Float16 B1 = (_Float16)(1.43901483f * C_L), B2 = (_Float16)(-0.67994519f * C_L);
+    const _Float16 B3 = (_Float16)(0.32559803f * C_L), B4 = (_Float16)(-0.08477006f * C_L);
     const half2v t = __builtin_elementwise_abs(zs) * C_T;
     half2v e;
     e[0] = __builtin_exp2f16(t[0]);
     e[1] = __builtin_exp2f16(t[1]);
-    const half2v u = e + (_Float16)1.f;
-    half2v l;
-    l[0] = __builtin_log2f16(u[0]);
-    l[1] = __builtin_log2f16(u[1]);
-    return __builtin_elementwise_fma(l, half2v{C_L, C_L}, __builtin_elementwise_max(zs, half2v{(_Float16)0.f, (_Float16)0.f}));
+    half2v q = __builtin_elementwise_fma(e, half2v{B4, B4}, half2v{B3, B3});
+    q = __builtin_elementwise_fma(e, q, half2v{B2, B2});
+    q = __builtin_elementwise_fma(e, q, half2v{B1, B1});
+    return __builtin_elementwise_fma(e, q, __builtin_elementwise_max(zs, half2v{(_Float16)0.f, (_Float16)0.f}));
 }
 // four accumulator values -> bias, activation, packed halves
 __device__ __forceinline__ half4 softplus100_s16_pk4(const float4v &av, float k16, const float4v &bs) {
