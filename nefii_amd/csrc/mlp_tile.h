@@ -1515,6 +1515,131 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT
     }
 }
 
+// "16s" with TWO activation images (the hi-only image of a 64- / 96-row tile is 75 KB: both fit the LDS): layer l reads
+// image l & 1 and writes the other one, so the epilogue stores each packed value as it is produced and the barrier that
+// made the stores wait for every wave to be done reading falls away - one barrier per layer instead of two, no parked
+// results (32 registers less).  The encoding columns live in both images (the skip layer reads them from whichever
+// image its hidden block is in).
+template <int FT, int ROWS>
+struct LdsS2 {
+    _Float16 X[2][ROWS * QGeo<FT>::XP];
+    _Float16 tail[128];
+};
+
+template <int QT, int FT>
+__device__ __forceinline__ void sdf_tile16s2(const nefii_mlp &m, LdsS2<FT, 16 * QT> &lds, float *raw, float *const *dest,
+                                             SStage<FT> (&b)[4], PCursor &cur) {
+    constexpr int NW = 8, RT = (QT + 1) / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, EW = QGeo<FT>::EW, RMAX = 16 * QT;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NH = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    const float k16 = inv_scale * A16_SCALE;
+    const int boff = 16 * FT * wave + (lane & (16 * FT - 1));
+    float bnext = m.layer[0].bias[boff];        // biases run one layer ahead (see sdf_tile16q)
+    {
+        const int w0 = enc_width(m.enc_freqs[0]);
+        for (int i = threadIdx.x; i < RMAX * EW; i += 512) {
+            const int p = i / EW, c = i - p * EW;
+            const _Float16 v = (_Float16)((c < w0 ? enc_value(raw + p * 9, c) : 0.f) * A16_SCALE);
+            lds.X[0][p * XP + EP + c] = v;
+            lds.X[1][p * XP + EP + c] = v;
+        }
+    }
+    __syncthreads();
+    const int qoff = (lane & 15) * XP + 8 * (lane >> 4);
+    for (int l = 0; l < NH; ++l) {
+        const nefii_layer &L = m.layer[l];
+        const int units = s_units(L);
+        const _Float16 *ah = lds.X[l & 1] + qoff + (EP - L.k_x);
+        _Float16 *xh = lds.X[(l & 1) ^ 1] + (EP - L.n_pad);
+        const float *bp = m.layer[l + 1 < NH ? l + 1 : l].bias + boff;
+        asm volatile("" ::"s"(units), "v"(ah), "v"(xh), "v"(bp));
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see 16p)
+        __builtin_amdgcn_sched_barrier(0);
+        const float bvec = bnext;
+        f32x4 acc[FT * QT];
+#pragma unroll
+        for (int j = 0; j < FT * QT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+        SAct<QT> a[2];
+        sload_a<QT, XP>(a[0], ah, 0);
+        sgemm<QT, FT, true>(units, b, a, cur, ah, acc);
+        bnext = *bp;
+        __builtin_amdgcn_sched_barrier(0);
+        const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
+        auto body = [&](auto fast) {        // the activation id resolved once per layer, not per value (see pepilogue)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) {
+                const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
+                float4v bs;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    bs[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const f32x4 &av = acc[ft * QT + qt];
+                    half4 packed;
+                    if constexpr (decltype(fast)::value) {
+                        packed = softplus100_s16_pk4(av, k16, bs);
+                    } else {
+                        float4v hs;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float zs = __builtin_fmaf(av[k], k16, bs[k]);
+                            hs[k] = act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
+                        }
+                        packed = __builtin_convertvector(hs, half4);
+                    }
+                    *reinterpret_cast<half4 *>(xh + (16 * qt + (lane & 15)) * XP + f0) = packed;
+                }
+            }
+        };
+        if (m.act == NEFII_ACT_SOFTPLUS100)
+            body(std::true_type{});
+        else
+            body(std::false_type{});
+        __syncthreads();
+    }
+    // last layer, column 0 only: hi fragments of the layer's own w_f16x3 (32x32x16), K split over the waves
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const nefii_layer &L = m.layer[NH];
+        const int NT = L.n_pad >> 5;
+        const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
+        const _Float16 *ah = lds.X[NH & 1] + r * XP + 8 * h + (EP - L.k_x);
+        const int ksw = (L.k_x >> 4) / NW;
+        f32x16 acc2[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
+        for (int u = 0; u < ksw; ++u) {
+            const int s = wave * ksw + u;
+            const half8 wh = wl[(size_t)s * NT * 128];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const half8 xh8 = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP + 16 * s);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh8, acc2[rt], 0, 0, 0);
+            }
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+                if (32 * rt + r < RMAX) raw[wave * RMAX + 32 * rt + r] = acc2[rt][0];
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 * QT) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += raw[w * RMAX + threadIdx.x];
+            float *d = dest[threadIdx.x];
+            if (d) *d = sum * inv_scale + L.bias[0];
+        }
+        __syncthreads();
+    }
+}
+
 // accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
 #define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \

@@ -850,23 +850,36 @@ __device__ __forceinline__ void zero_lds_s(LdsS<FT, ROWS> &lds) {
     __syncthreads();
 }
 
+// DB (the 64- / 96-row default tiles): two activation images, one barrier per layer (mlp_tile.h, sdf_tile16s2)
+template <int FT, int ROWS, bool DB>
+using LdsSx = typename std::conditional<DB, LdsS2<FT, ROWS>, LdsS<FT, ROWS>>::type;
+template <typename LDS>
+__device__ __forceinline__ void zero_lds_any(LDS &lds) {
+    uint32_t *p = reinterpret_cast<uint32_t *>(&lds);
+    for (int i = threadIdx.x; i < (int)(sizeof(LDS) / 4); i += blockDim.x) p[i] = 0u;
+    __syncthreads();
+}
+
 template <int QT, int FT, bool DB = true>
 __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, int round) {
     constexpr int ROWS = 16 * QT, RMAX = ROWS;
-    __shared__ LdsS<FT, ROWS> lds;
+    __shared__ LdsSx<FT, ROWS, DB> lds;
     __shared__ float raw[RMAX * 9];
     __shared__ float *dest[RMAX];
     const int64_t total = (int64_t)P.counters[round * NCNT + 5] * P.p.n_steps;
     const int64_t n_tiles = (total + ROWS - 1) / ROWS;
     if (blockIdx.x >= n_tiles) return;
-    zero_lds_s(lds);        // the K-padded stream multiplies what follows a layer's own columns by zero weights: keep it finite
+    zero_lds_any(lds);      // the K-padded stream multiplies what follows a layer's own columns by zero weights: keep it finite
     SStage<FT> b[4];
     PCursor cur;
     prime16s<FT>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         decode_tile_coarse<ROWS>(P, tile, total, raw, dest);
         __syncthreads();
-        sdf_tile16s<QT, FT, DB>(m, lds, raw, dest, b, cur);
+        if constexpr (DB)
+            sdf_tile16s2<QT, FT>(m, lds, raw, dest, b, cur);
+        else
+            sdf_tile16s<QT, FT, false>(m, lds, raw, dest, b, cur);
     }
 }
 
@@ -874,11 +887,11 @@ template <int QT, int FT, bool DB = true>
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
     constexpr int ROWS = 16 * QT, RMAX = ROWS;
-    __shared__ LdsS<FT, ROWS> lds;
+    __shared__ LdsSx<FT, ROWS, DB> lds;
     __shared__ float raw[RMAX * 9];
     __shared__ float *dest[RMAX];
     const int64_t n_tiles = (n + ROWS - 1) / ROWS;
-    zero_lds_s(lds);
+    zero_lds_any(lds);
     SStage<FT> b[4];
     PCursor cur;
     prime16s<FT>(m, b, cur);
@@ -893,7 +906,10 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, cons
             dest[tid] = live ? out + q : nullptr;
         }
         __syncthreads();
-        sdf_tile16s<QT, FT, DB>(m, lds, raw, dest, b, cur);
+        if constexpr (DB)
+            sdf_tile16s2<QT, FT>(m, lds, raw, dest, b, cur);
+        else
+            sdf_tile16s<QT, FT, false>(m, lds, raw, dest, b, cur);
 #ifdef NEFII_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) g_stamp_tile = g_stamp_tile + 1;
         __syncthreads();
