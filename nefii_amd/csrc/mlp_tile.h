@@ -1376,8 +1376,10 @@ __device__ __forceinline__ void prime16s(const nefii_mlp &m, SStage<FT> (&b)[4],
     for (int u = 0; u < 3; ++u) sload<FT>(b[u], cur);
 }
 
-// One tile of 16 * QT queries through the whole SDF network in a single fp16 pass.
-template <int QT, int FT, bool DB = true>
+// One tile of 16 * QT queries through the whole SDF network in a single fp16 pass - the BIG-tile form (96 / 128 queries,
+// NEFII_COARSE_QT): one activation image, activation fragments read single-buffered and the whole epilogue behind the
+// barrier to fit 256 registers.  The default 64- / 96-row tiles run sdf_tile16s2 below.
+template <int QT, int FT, bool DB = false>
 __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT> &lds, float *raw, float *const *dest,
                                             SStage<FT> (&b)[4], PCursor &cur) {
     constexpr int NW = 8, RT = (QT + 1) / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, RMAX = 16 * QT;
@@ -1404,75 +1406,53 @@ __device__ __forceinline__ void sdf_tile16s(const nefii_mlp &m, LdsS<FT, 16 * QT
         for (int j = 0; j < FT * QT; ++j)
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
-        SAct<QT> a[DB ? 2 : 1];
+        static_assert(!DB, "the double-buffered tiles are sdf_tile16s2's");
+        SAct<QT> a[1];
         NEFII_STAMP(0);
-        if constexpr (DB) sload_a<QT, XP>(a[0], ah, 0);
-        sgemm<QT, FT, DB>(units, b, a, cur, ah, acc);
+        sgemm<QT, FT, false>(units, b, a, cur, ah, acc);
         bnext = *bp;
         __builtin_amdgcn_sched_barrier(0);
         NEFII_STAMP(1);
         _Float16 *xh = lds.Xh + (EP - L.n_pad);
-        if constexpr (DB) {
-            // epilogue arithmetic ahead of the barrier (it overlaps the SIMD partner's k-loop), packed results parked in
-            // registers until every wave is done reading the activation image
-            half4 phi[FT * QT];
-            if (m.act == NEFII_ACT_SOFTPLUS100)
-                sepilogue<QT, FT, true>(acc, bvec, k16, lane, m.act, phi);
-            else
-                sepilogue<QT, FT, false>(acc, bvec, k16, lane, m.act, phi);
-            NEFII_STAMP(2);
-            __syncthreads();
-            NEFII_STAMP(3);
+        // big tiles: no registers to park the packed results in - the whole epilogue runs behind the barrier, each
+        // feature tile's values stored as they are produced
+        NEFII_STAMP(2);
+        __syncthreads();
+        NEFII_STAMP(3);
+        const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
+        auto body = [&](auto fast) {        // the activation id resolved once per layer, not per value (see pepilogue)
 #pragma unroll
             for (int ft = 0; ft < FT; ++ft) {
                 const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
+                float4v bs;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    bs[k] = __builtin_bit_cast(float,
+                                               __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) {
+                    const f32x4 &av = acc[ft * QT + qt];
+                    half4 packed;
+                    if constexpr (decltype(fast)::value) {
+                        packed = softplus100_s16_pk4(av, k16, bs);
+                    } else {
+                        float4v hs;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float zs = __builtin_fmaf(av[k], k16, bs[k]);
+                            hs[k] = act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
+                        }
+                        packed = __builtin_convertvector(hs, half4);
+                    }
                     const int query = 16 * qt + (lane & 15);
-                    *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                    *reinterpret_cast<half4 *>(xh + query * XP + f0) = packed;
                 }
             }
-        } else {
-            // big tiles: no registers to park the packed results in - the whole epilogue runs behind the barrier, each
-            // feature tile's values stored as they are produced
-            NEFII_STAMP(2);
-            __syncthreads();
-            NEFII_STAMP(3);
-            const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
-            auto body = [&](auto fast) {        // the activation id resolved once per layer, not per value (see pepilogue)
-#pragma unroll
-                for (int ft = 0; ft < FT; ++ft) {
-                    const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
-                    float4v bs;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        bs[k] = __builtin_bit_cast(float,
-                                                   __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) {
-                        const f32x4 &av = acc[ft * QT + qt];
-                        half4 packed;
-                        if constexpr (decltype(fast)::value) {
-                            packed = softplus100_s16_pk4(av, k16, bs);
-                        } else {
-                            float4v hs;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float zs = __builtin_fmaf(av[k], k16, bs[k]);
-                                hs[k] = act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
-                            }
-                            packed = __builtin_convertvector(hs, half4);
-                        }
-                        const int query = 16 * qt + (lane & 15);
-                        *reinterpret_cast<half4 *>(xh + query * XP + f0) = packed;
-                    }
-                }
-            };
-            if (m.act == NEFII_ACT_SOFTPLUS100)
-                body(std::true_type{});
-            else
-                body(std::false_type{});
-        }
+        };
+        if (m.act == NEFII_ACT_SOFTPLUS100)
+            body(std::true_type{});
+        else
+            body(std::false_type{});
         __syncthreads();
         NEFII_STAMP(4);
     }
@@ -1563,10 +1543,12 @@ __device__ __forceinline__ void sdf_tile16s2(const nefii_mlp &m, LdsS2<FT, 16 * 
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
         SAct<QT> a[2];
+        NEFII_STAMP(0);
         sload_a<QT, XP>(a[0], ah, 0);
         sgemm<QT, FT, true>(units, b, a, cur, ah, acc);
         bnext = *bp;
         __builtin_amdgcn_sched_barrier(0);
+        NEFII_STAMP(1);
         const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
         auto body = [&](auto fast) {        // the activation id resolved once per layer, not per value (see pepilogue)
 #pragma unroll
@@ -1599,7 +1581,10 @@ __device__ __forceinline__ void sdf_tile16s2(const nefii_mlp &m, LdsS2<FT, 16 * 
             body(std::true_type{});
         else
             body(std::false_type{});
+        NEFII_STAMP(2);
         __syncthreads();
+        NEFII_STAMP(3);
+        NEFII_STAMP(4);
     }
     // last layer, column 0 only: hi fragments of the layer's own w_f16x3 (32x32x16), K split over the waves
     {
