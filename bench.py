@@ -334,6 +334,12 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                    'rank_param_spread': param_spread,
                    'nonfinite_steps': int(step.nonfinite_steps.item()),     # steps cancelled by TrainStep's NaN guard
                    'trace_prefetch': len(nxt) if nxt is not None else 0,   # batches traced ahead, beside the tail of batch i
+                   # MC workloads: does the secondary trace also fill the outputs of rays that MISS (min-SDF search,
+                   # argmin fallback)?  Nothing reads them (idr_train.py:819 masks secondary_points with the hit mask);
+                   # the default skips them - every consumed output bit-identical
+                   # (test_secondary_trace_without_the_miss_search_changes_nothing_that_is_read);
+                   # NEFII_SECONDARY_MISS_SEARCH=1 executes them as the reference does
+                   'secondary_miss_search': bool(model.secondary_miss_search) if indirect else None,
                    'loss': float(lo['loss'].item())},
         'roofline': roofline,
     }

@@ -238,6 +238,9 @@ class IDRNetwork(nn.Module):
         self.state_freeze_geo = False
         self.state_freeze_idr = False
         self.state_freeze_env_mat = False
+        # True: the secondary trace also fills the outputs of rays that miss (min-SDF search, as the reference executes
+        # it; nothing reads them - model/path_tracing_render.py)
+        self.secondary_miss_search = os.environ.get('NEFII_SECONDARY_MISS_SEARCH', '0') == '1'
 
     # ---- freeze surface used by the runners (idr_train.py:621-630) ------------------------------
     def freeze_geometry(self):

@@ -49,10 +49,22 @@ def pt_render_indirect_mlp(lgtSGs, specular_reflectance, roughness, diffuse_albe
         wi, own, tab = ops.mis_sample(lgtSGs, r1, n3, v3, uniforms)
         # secondary rays: origin = surface point, one batched trace of the 3N rays
         origins = p3.detach().unsqueeze(0).expand(3, n, 3).reshape(-1, 1, 3)
-        sec_pts, sec_hit, sec_dist = model.ray_tracer(sdf=model.implicit_network,
-                                                      cam_loc=origins.reshape(-1, 3),
-                                                      object_mask=torch.ones(3 * n, dtype=torch.bool, device=dev),
-                                                      ray_directions=wi.reshape(-1, 1, 3))
+        # What the trace returns for rays that MISS has no consumer: visibility and the indirect radiance use the hit mask
+        # and the hit points, and the secondary-consistency step masks secondary_points with secondary_mask
+        # (idr_train.py:819).  So the secondary trace skips what only fills those outputs - the min-SDF search of the
+        # rays that leave without a hit and the bracket search's argmin fallback (a quarter of config 3's SDF
+        # evaluations): it runs the tracer's eval-mode recurrences, whose hits are bit-identical (object_mask is all
+        # ones here).  secondary_points[~secondary_mask] is then unspecified; model.secondary_miss_search = True
+        # (NEFII_SECONDARY_MISS_SEARCH=1) restores the reference's values.
+        rt = model.ray_tracer
+        prev = rt.miss_search
+        rt.miss_search = bool(getattr(model, 'secondary_miss_search', False))
+        try:
+            sec_pts, sec_hit, sec_dist = rt(sdf=model.implicit_network, cam_loc=origins.reshape(-1, 3),
+                                            object_mask=torch.ones(3 * n, dtype=torch.bool, device=dev),
+                                            ray_directions=wi.reshape(-1, 1, 3))
+        finally:
+            rt.miss_search = prev
         vis = 1.0 - sec_hit.to(torch.float32)                                    # [3n]
         hidx = torch.nonzero(sec_hit).flatten()
     # indirect radiance at secondary hits (gradient reaches the radiance network: not detached in the reference)

@@ -43,6 +43,11 @@ class RayTracing(nn.Module):
         # its eval-mode schedule): same gradients and parameter trajectory, different mask_loss value.  Default False
         # keeps the reference's outputs.
         self.skip_min_sdf_search = False
+        # False while a caller traces rays whose MISS outputs nothing reads (the secondary rays of pt_render_indirect_mlp:
+        # their only consumer masks them with the hit mask, idr_train.py:819): the trace then runs the reference's
+        # eval-mode recurrences (ray_tracing.py:62-96 without the `if self.training` blocks) - no min-SDF search for the
+        # rays that leave without a hit, no argmin fallback in the bracket search - whose hits are the training path's
+        self.miss_search = True
         # a list: traces append their deferred round-prefix checks instead of syncing (ops.trace_rays `deferred`)
         self.deferred_checks = None
         # Coarse pass (nefii_tracer_params.coarse_tau): the 100 samples of the bracket search and of the min-SDF search are
@@ -94,7 +99,10 @@ class RayTracing(nn.Module):
         if self._lin is None or self._lin.device != dev or self._lin.numel() != self.n_steps:
             self._lin = torch.linspace(0, 1, steps=self.n_steps).to(dev)     # ray_tracing.py:203
         steps = None
-        training = self.training and not self.skip_min_sdf_search
+        training = self.training and not self.skip_min_sdf_search and self.miss_search
+        if self.training and not self.skip_min_sdf_search and not self.miss_search and \
+                isinstance(self.minsdf_steps_override, (list, tuple)):
+            self._calls += 1        # this call's entry of the per-call override list stays unused
         if training:
             if self.minsdf_steps_override is not None:
                 ov = self.minsdf_steps_override

@@ -92,6 +92,7 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
     t_oracle = time.time() - t0
     # ---- HIP path
     m = build_model(mc, sd, True)
+    m.secondary_miss_search = True      # as the oracle (and the reference) runs the secondary trace: its evaluation counts
     m.ray_tracer.minsdf_steps_override = [steps1, steps2] if mc_shading else steps1
     m.ray_tracer.collect_counters = True
     m.ray_tracer.counter_sum = None
@@ -137,6 +138,45 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
             want = want[:, 0] if k == 'normal_values' else want.mean(1)
             assert rel_l2(multi[k], want) < 1e-5, k
         assert torch.equal(multi['network_object_mask'], out['network_object_mask'].reshape(S, R).all(1))
+
+
+@pytest.mark.parametrize('wl', ['cfg3', 'cfg4'])
+def test_secondary_trace_without_the_miss_search_changes_nothing_that_is_read(wl):
+    """The default secondary trace skips what only fills the outputs of rays that MISS (min-SDF search, argmin fallback):
+    against model.secondary_miss_search = True (the reference's recurrences) every output is bit-identical except
+    secondary_points of rays outside secondary_mask - which idr_train.py:819 masks - and it executes fewer SDF
+    evaluations."""
+    from nefii_amd import ops
+    w = syn.WORKLOADS[wl]
+    mc, sd = syn.workload_state_dict(wl, seed=0)
+    inp, gt = syn.make_inputs(64, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=2)
+    flat, gt_flat, R = per_ray_layout(inp, gt)
+    n_ray = flat['uv'].shape[1]
+    g = torch.Generator().manual_seed(7)
+    steps1, steps2 = torch.rand(100, generator=g), torch.rand(100, generator=g)
+    uniforms = torch.rand(n_ray, 7, generator=g)
+    outs, evals = [], []
+    for keep in (False, True):
+        m = build_model(mc, sd, True)
+        assert m.secondary_miss_search is False
+        m.secondary_miss_search = keep
+        m.ray_tracer.minsdf_steps_override = [steps1, steps2]
+        m.ray_tracer.collect_counters = True
+        m.ray_tracer.counter_sum = None
+        outs.append(gpu_forward_with_per_ray_draws(m, to_dev(flat), uniforms))
+        evals.append(ops.algorithmic_evals(m.ray_tracer.counter_sum.cpu().long(), 100).sum().item())
+    fast, full = outs
+    mask = full['secondary_mask']
+    assert mask.float().mean().item() > 0.2 and (~mask).float().mean().item() > 0.2
+    for k, v in full.items():
+        if v is None or k == 'secondary_points':
+            continue
+        assert torch.equal(fast[k], v), k
+    sel = mask.expand_as(full['secondary_points'])
+    assert torch.equal(fast['secondary_points'][sel], full['secondary_points'][sel])
+    assert torch.isfinite(fast['secondary_points']).all()
+    assert evals[0] < 0.9 * evals[1], evals
+    print('[%s] algorithmic SDF evaluations %d -> %d' % (wl, evals[1], evals[0]))
 
 
 @pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg4'])
