@@ -161,8 +161,8 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
 
     # NEFII_BENCH_PREFETCH=1 (default): every step also enqueues the trace of the next batch (TrainStep.prefetch_trace)
     nxt = inp if os.environ.get('NEFII_BENCH_PREFETCH', '1') != '0' else None
-    if nxt is not None:         # batches known ahead of time (a dataloader's prefetch queue): 3 by default
-        nxt = [inp] * max(1, int(os.environ.get('NEFII_BENCH_LOOKAHEAD', '3')))
+    if nxt is not None:         # batches known ahead of time (a dataloader's prefetch queue): 3, or 5 when traced in groups of 3
+        nxt = [inp] * max(1, int(os.environ.get('NEFII_BENCH_LOOKAHEAD', str(step.preferred_lookahead(inp)))))
     for _ in range(warmup):
         step(inp, gt, nxt)
     # the graph of the step's tail is captured once per padded hit count, after 3 eager steps: with fewer warm-up steps

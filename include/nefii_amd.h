@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 5
+#define NEFII_ABI_VERSION 6
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -173,6 +173,9 @@ typedef struct nefii_tracer_params {
                                 split evaluator's.  0 = off.  nefii_sdf_eval_coarse measures the bound for a net. */
     int32_t coarse_cap;      /* most samples of one ray re-evaluated individually; a ray with more takes all n_steps
                                 in split precision instead.  <= 0: 64.  At most 100. */
+    int32_t minsdf_group;    /* > 0: minsdf_steps holds one row of n_steps uniform draws per minsdf_group consecutive rays
+                                (several batches - each with the draw the reference makes per call, ray_tracing.py:316 -
+                                traced as ONE call); 0: one row for all rays */
 } nefii_tracer_params;
 #define NEFII_TRACE_COUNTERS 8   /* int32 counters per round, see nefii_trace_rays */
 

@@ -14,7 +14,7 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 5
+ABI_VERSION = 6
 TRACE_COUNTERS = 8          # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
@@ -40,7 +40,8 @@ class TracerParams(ctypes.Structure):
                 ('line_search_step', ctypes.c_float), ('line_step_iters', ctypes.c_int32),
                 ('sphere_tracing_iters', ctypes.c_int32), ('n_steps', ctypes.c_int32),
                 ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32), ('bisect_levels', ctypes.c_int32),
-                ('precision', ctypes.c_int32), ('coarse_tau', ctypes.c_float), ('coarse_cap', ctypes.c_int32)]
+                ('precision', ctypes.c_int32), ('coarse_tau', ctypes.c_float), ('coarse_cap', ctypes.c_int32),
+                ('minsdf_group', ctypes.c_int32)]
 
 
 class LossParams(ctypes.Structure):

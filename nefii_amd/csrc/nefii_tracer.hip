@@ -71,6 +71,13 @@ struct Params {
     RayState s;
 };
 
+// uniform draw i of ray r's min-SDF search: one row for the whole call, or one row per minsdf_group consecutive rays
+// (several batches traced as one call keep their own draws)
+__device__ __forceinline__ float minsdf_step(const Params &P, int64_t r, int i) {
+    const int g = P.p.minsdf_group;
+    return P.steps[(g > 0 ? (r / g) * (int64_t)P.p.n_steps : 0) + i];
+}
+
 // ---- work-list append: block-aggregated ------------------------------------------------------
 // each thread contributes up to 2 single queries, one dense ray (split precision or coarse), one bisecting ray and
 // n_ref coarse samples to refine (bit set `cmask`).
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                 amin = i;
             }
         const float tmin = P.s.t_min[r], tmax = P.s.t_max[r];
-        const float dist = fadd(fmul(P.steps[amin], fsub(tmax, tmin)), tmin);
+        const float dist = fadd(fmul(minsdf_step(P, r, amin), fsub(tmax, tmin)), tmin);
         finish(P, r, dist, fl & F_HIT);
         P.s.flags[r] = (fl & ~F_PHASE) | PH_DONE;
     }
@@ -546,7 +553,7 @@ __device__ __forceinline__ RoundWork round_work(const Params &P, int round) {
 __device__ __forceinline__ float dense_depth(const Params &P, int64_t r, int i, bool minsdf) {
     if (minsdf) {
         const float tmin = P.s.t_min[r], tmax = P.s.t_max[r];
-        return fadd(fmul(P.steps[i], fsub(tmax, tmin)), tmin);
+        return fadd(fmul(minsdf_step(P, r, i), fsub(tmax, tmin)), tmin);
     }
     const float a = P.s.t_s[r];
     return fadd(a, fmul(P.lin[i], fsub(P.s.t_e[r], a)));
@@ -1814,6 +1821,7 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     P.obj = object_mask;
     P.lin = lin_steps;
     P.steps = minsdf_steps ? minsdf_steps : lin_steps;
+    if (!minsdf_steps) P.p.minsdf_group = 0;
     P.out_pts = out_points;
     P.out_dist = out_dists;
     P.out_hit = out_hit;

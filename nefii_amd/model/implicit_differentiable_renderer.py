@@ -328,6 +328,39 @@ class IDRNetwork(nn.Module):
         return {'points': points, 'network_object_mask': network_object_mask, 'object_mask': object_mask,
                 'ray_dirs': ray_dirs.reshape(-1, 3), 'multi': shape}
 
+    def trace_points_group(self, inputs):
+        """trace_points of several batches (one image each, equal shapes) as ONE tracer call: G x S rays per round instead
+        of G traces whose late rounds each keep a handful of tiles busy.  Every batch keeps its own camera and its own
+        draw of the min-SDF search (RayTracing.steps_per_batch), so each slice equals that batch's own trace.  Returns the
+        per-batch ctx dicts (views into the call's outputs)."""
+        if self.training and not self.state_freeze_geo:
+            raise NotImplementedError('the kernel path needs frozen geometry (freeze_geometry())')
+        dirs, cams, masks, shapes = [], [], [], []
+        for input in inputs:
+            uv, object_mask = input['uv'], input['object_mask'].reshape(-1)
+            shape = None
+            if uv.dim() == 4:
+                B, S, R, _ = uv.shape
+                shape = (B, S, R)
+                uv = uv.reshape(B, S * R, 2)
+                object_mask = object_mask.reshape(B, S, 1).expand(B, S, R).reshape(-1)
+            ray_dirs, cam_loc = rend_util.get_camera_params(uv, input['pose'], input['intrinsics'])
+            if ray_dirs.shape[0] != 1 or (dirs and ray_dirs.shape != dirs[0].shape):
+                raise ValueError('trace_points_group: one image per batch, equal ray counts')
+            dirs.append(ray_dirs), cams.append(cam_loc), masks.append(object_mask), shapes.append(shape)
+        rt = self.ray_tracer
+        rt.steps_per_batch = True
+        try:
+            with torch.no_grad():
+                points, hit, dists = rt(sdf=self.implicit_network, cam_loc=torch.cat(cams), object_mask=torch.cat(masks),
+                                        ray_directions=torch.cat(dirs))
+        finally:
+            rt.steps_per_batch = False
+        S = dirs[0].shape[1]
+        return [{'points': points[g * S:(g + 1) * S], 'network_object_mask': hit[g * S:(g + 1) * S],
+                 'object_mask': masks[g], 'ray_dirs': dirs[g].reshape(-1, 3), 'multi': shapes[g]}
+                for g in range(len(inputs))]
+
     def attach_surface(self, ctx):
         """SDF value (and, for small batches, features and gradient) at the traced points - the part of trace_head that
         has to be redone when a trace enqueued ahead of time turns out to need more rounds (training/step.py)."""

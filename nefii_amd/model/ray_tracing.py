@@ -48,6 +48,9 @@ class RayTracing(nn.Module):
         # eval-mode recurrences (ray_tracing.py:62-96 without the `if self.training` blocks) - no min-SDF search for the
         # rays that leave without a hit, no argmin fallback in the bracket search - whose hits are the training path's
         self.miss_search = True
+        # True while TrainStep traces several batches as ONE call (cam_loc [G,3], ray_directions [G,S,3]): every batch keeps
+        # the uniform draw of the min-SDF search the reference makes per call (ray_tracing.py:316), in batch order
+        self.steps_per_batch = False
         # a list: traces append their deferred round-prefix checks instead of syncing (ops.trace_rays `deferred`)
         self.deferred_checks = None
         # Coarse pass (nefii_tracer_params.coarse_tau): the 100 samples of the bracket search and of the min-SDF search are
@@ -103,17 +106,23 @@ class RayTracing(nn.Module):
         if self.training and not self.skip_min_sdf_search and not self.miss_search and \
                 isinstance(self.minsdf_steps_override, (list, tuple)):
             self._calls += 1        # this call's entry of the per-call override list stays unused
+        group = 0
         if training:
-            if self.minsdf_steps_override is not None:
-                ov = self.minsdf_steps_override
-                if isinstance(ov, (list, tuple)):      # one entry per trace call (primary, secondary, ...)
-                    ov = ov[self._calls % len(ov)]
-                    self._calls += 1
-                steps = ov.to(dev)
-            else:
-                # drawn on the host exactly like minimal_sdf_points (:316); always drawn (the reference draws only
-                # when some ray needs the search, a data-dependent host sync this build avoids)
-                steps = torch.empty(self.n_steps).uniform_(0.0, 1.0).to(dev)
+            rows = B if (self.steps_per_batch and B > 1) else 1
+            drawn = []
+            for _ in range(rows):
+                if self.minsdf_steps_override is not None:
+                    ov = self.minsdf_steps_override
+                    if isinstance(ov, (list, tuple)):      # one entry per trace call (primary, secondary, ...)
+                        ov = ov[self._calls % len(ov)]
+                        self._calls += 1
+                    drawn.append(ov.reshape(-1))
+                else:
+                    # drawn on the host exactly like minimal_sdf_points (:316); always drawn (the reference draws only
+                    # when some ray needs the search, a data-dependent host sync this build avoids)
+                    drawn.append(torch.empty(self.n_steps).uniform_(0.0, 1.0))
+            steps = (drawn[0] if rows == 1 else torch.stack([d.cpu() for d in drawn])).to(dev).contiguous()
+            group = S if rows > 1 else 0
         n_rays = dirs.shape[0]
         levels = self.bisect_levels or self.auto_levels(n_rays, self.concurrent)
         tau = 0.0
@@ -123,7 +132,7 @@ class RayTracing(nn.Module):
             tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
                 net.coarse_tau(self.object_bounding_sphere)
         params = ops.make_tracer_params(self._cfg(), training, self.precision, levels, coarse_tau=tau,
-                                        coarse_cap=self.coarse_cap)
+                                        coarse_cap=self.coarse_cap, minsdf_group=group)
         state = None
         if self.adaptive_rounds:      # one guess per (mode, batch size): primary and secondary traces differ
             import math
@@ -131,7 +140,7 @@ class RayTracing(nn.Module):
         res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs,
                              object_mask.reshape(-1), self._lin, steps, want_counters=self.collect_counters,
                              rounds_state=state,
-                             groups=self.stream_groups or 1,
+                             groups=1 if group else (self.stream_groups or 1),
                              deferred=self.deferred_checks if state is not None else None)
         if self.collect_counters:
             self.last_counters = res[3]

@@ -237,14 +237,15 @@ class IDRTrainRunner:
             self.train_sampler_generator.manual_seed(epoch)
             resample = getattr(self.loss, 'sample_each_iter', False)
 
-            def batches():       # three batches of lookahead: TrainStep traces them beside the tail of the current one
+            def batches():       # batches of lookahead (3, or 5 when small batches are traced in groups): TrainStep traces
+                                 # them beside the tail of the current one
                 window = []
                 for item in self.train_dataloader:
                     if resample:
                         self._resample()
                     window.append((item[0], {k: v.to(self.device) for k, v in item[1].items()},
                                    {'rgb': item[2]['rgb'].to(self.device)}))
-                    if len(window) == 4:
+                    if len(window) == 1 + self.step.preferred_lookahead(window[0][1]):
                         yield window[0], (None if resample else [w[1] for w in window[1:]])
                         window.pop(0)
                 while window:

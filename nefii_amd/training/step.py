@@ -267,21 +267,71 @@ class TrainStep:
     # traced while this batch's shading / backward / Adam runs: the tail's small kernels (24-128 workgroups) fill the
     # CUs that the tracer's latency-bound rounds (fewer tiles than CUs) leave idle.  Same arithmetic, same order of the
     # tracer's random draws; only the schedule changes.
+    def trace_group_for(self, model_input):
+        """Batches traced per tracer call when their rays are enqueued ahead (prefetch_group).  Tiny batches (config 1:
+        512 rays) are traced three at a time: a lone trace of a few hundred rays is all launch and tile latency, and one
+        call of three batches costs hardly more than one of one (config 1: 1.95 -> 1.63 ms per step).  From a few thousand
+        rays on it no longer pays - config 2 (4096 rays): 3.10 vs 3.12 ms per step, the three traces in flight already fill
+        each other's gaps - and big batches fill the chip on their own: 1.  NEFII_TRACE_GROUP overrides."""
+        env = os.environ.get('NEFII_TRACE_GROUP')
+        if env:
+            return max(1, int(env))
+        uv = model_input['uv']
+        if uv.shape[0] != 1:
+            return 1
+        n_rays = uv.shape[1] * (uv.shape[2] if uv.dim() == 4 else 1)
+        return 3 if n_rays <= 2048 else 1
+
+    def preferred_lookahead(self, model_input):
+        """Upcoming batches a caller should hand to __call__ (next_input): three traces in flight for big batches; for
+        grouped traces two groups minus one, so that a group is enqueued while a whole traced group is still waiting."""
+        g = self.trace_group_for(model_input)
+        return 3 if g <= 1 else 2 * g - 1
+
+    def _trace_stream_next(self, after):
+        if self._trace_stream is None:
+            n = max(1, int(os.environ.get('NEFII_TRACE_STREAMS', '3')))
+            self._trace_pool = [torch.cuda.Stream() for _ in range(n)]
+        self._trace_pool.append(self._trace_pool.pop(0))
+        self._trace_stream = self._trace_pool[0]
+        self._trace_stream.wait_event(after if after is not None else torch.cuda.current_stream().record_event())
+        return self._trace_stream
+
+    def prefetch_group(self, inputs, after=None):
+        """prefetch_trace for several upcoming batches as ONE tracer call (IDRNetwork.trace_points_group)."""
+        m = self.model
+        if len(inputs) == 1:
+            return self.prefetch_trace(inputs[0], after)
+        if not (m.training and getattr(m, 'state_freeze_geo', False) and next(m.parameters()).is_cuda):
+            return
+        st = self._trace_stream_next(after)
+        checks = []
+        with torch.cuda.stream(st):
+            m.ray_tracer.deferred_checks = checks
+            m.ray_tracer.concurrent = True
+            try:
+                ctxs = m.trace_points_group(inputs)
+                if not self.surface_in_tail:
+                    for c in ctxs:
+                        m.attach_surface(c)
+            finally:
+                m.ray_tracer.deferred_checks = None
+                m.ray_tracer.concurrent = False
+            ev = st.record_event()
+        grp = {'done': False, 'ctxs': ctxs}
+        for inp, c in zip(inputs, ctxs):
+            self._prefetch.append((inp, c, ev, checks, grp))
+
     def prefetch_trace(self, model_input, after=None):
         """after: event on the caller's stream behind which the inputs are ready (default: now).  Must not be an event
         behind this step's tail - the trace would wait for exactly what it is meant to run beside."""
         m = self.model
         if not (m.training and getattr(m, 'state_freeze_geo', False) and next(m.parameters()).is_cuda):
             return
-        if self._trace_stream is None:
-            n = max(1, int(os.environ.get('NEFII_TRACE_STREAMS', '3')))
-            self._trace_pool = [torch.cuda.Stream() for _ in range(n)]
         # consecutive traces rotate over the streams: the trace enqueued now starts beside the one(s) still running -
         # its dense rounds fill what the others' latency-bound rounds leave idle (config 2, 1 / 2 streams: 5.26 / 5.06 ms in
         # round 1; with the coarse pass 2 / 3 / 4 streams and batches of lookahead: 3.68 / 3.34 / 3.94 ms)
-        self._trace_pool.append(self._trace_pool.pop(0))
-        self._trace_stream = self._trace_pool[0]
-        self._trace_stream.wait_event(after if after is not None else torch.cuda.current_stream().record_event())
+        self._trace_stream_next(after)
         checks = []
         with torch.cuda.stream(self._trace_stream):
             m.ray_tracer.deferred_checks = checks       # no host sync inside the trace: its round-prefix check waits
@@ -295,7 +345,7 @@ class TrainStep:
                 m.ray_tracer.deferred_checks = None
                 m.ray_tracer.concurrent = False
             ev = self._trace_stream.record_event()
-        self._prefetch.append((model_input, ctx, ev, checks))
+        self._prefetch.append((model_input, ctx, ev, checks, None))
 
     def _n_prefetched(self, model_input):
         return sum(1 for pf in self._prefetch if pf[0] is model_input)
@@ -305,15 +355,21 @@ class TrainStep:
             self._prefetch = []         # the caller changed its mind about the next batch
             return None
         pf = self._prefetch.pop(0)      # oldest first: enqueue order
-        _, ctx, ev, checks = pf
+        _, ctx, ev, checks, grp = pf
         cur = torch.cuda.current_stream()
         cur.wait_event(ev)
         ev.synchronize()
-        for chk in checks:
-            more = chk()
-            if more is not None:        # the guessed round prefix was too short: the check ran the remaining rounds
-                ctx['points'], ctx['network_object_mask'] = more[0], more[1]
-                ctx.pop('pre', None)
+        if grp is None or not grp['done']:
+            for chk in checks:
+                more = chk()
+                if more is not None:        # the guessed round prefix was too short: the check ran the remaining rounds
+                    group = [ctx] if grp is None else grp['ctxs']
+                    S = more[0].shape[0] // len(group)
+                    for g, c in enumerate(group):
+                        c['points'], c['network_object_mask'] = more[0][g * S:(g + 1) * S], more[1][g * S:(g + 1) * S]
+                        c.pop('pre', None)
+            if grp is not None:
+                grp['done'] = True
         for v in list(ctx.values()) + list(ctx.get('pre') or ()):
             if torch.is_tensor(v):
                 v.record_stream(cur)          # allocated on the trace stream, consumed here
@@ -365,8 +421,19 @@ class TrainStep:
                 ctx = m.trace_head(model_input)         # own trace first: the tracer's random draws keep their order
             # enqueued BEFORE this batch's own (earlier enqueued) trace is waited for: the trace streams then always have
             # the next trace(s) queued behind / beside the running one and never idle while the host checks and launches
-            for inp in expected[len(queued):]:
-                self.prefetch_trace(inp)
+            todo = expected[len(queued):]
+            G = self.trace_group_for(model_input)
+            if G <= 1:
+                for inp in todo:
+                    self.prefetch_trace(inp)
+            else:
+                while len(todo) >= G:
+                    self.prefetch_group(todo[:G])
+                    todo = todo[G:]
+                # never let the queue run dry: when no traced batch would be left for the next call, trace what there is
+                left = len(self._prefetch) - (1 if self._prefetch and self._prefetch[0][0] is model_input else 0)
+                if left == 0 and todo:
+                    self.prefetch_group(todo)
         if ctx is None:
             ctx = self._take_prefetched(model_input)
         if self.graph and self._eager_steps >= self.graph_after and self.model.training:

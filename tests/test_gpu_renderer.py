@@ -534,31 +534,36 @@ def test_bench_two_processes_share_one_gpu():
     assert d['cfg3']['roofline']['secondary_hit_fraction'] > 0.2 and 0 < d['roofline']['frac_step'] < d['roofline']['frac_kernel']
 
 
+@pytest.mark.parametrize('lookahead', [2, 5])
 @pytest.mark.parametrize('graph', [False, True])
-def test_prefetched_trace_gives_the_same_steps(graph):
+def test_prefetched_trace_gives_the_same_steps(graph, lookahead):
     """TrainStep(next_input=...): tracing the next batch beside this batch's tail changes the schedule, not the result -
-    same losses and parameter trajectory as the plain sequence of steps, also when a prefetch is not consumed."""
+    same losses and parameter trajectory as the plain sequence of steps, also when a prefetch is not consumed.  Small
+    batches are traced in groups of three as ONE tracer call (5 batches of lookahead: whole groups; 2: partial ones),
+    each batch with its own min-SDF draw."""
     from nefii_amd.training.step import TrainStep
     mc = syn.model_conf('physg', hidden=64)
     sd = syn.make_state_dict(mc, seed=4, bumpy=0.02)
     lc = syn.loss_conf('physg')
     lc['idr_rgb_weight'] = 1.0
     batches = []
-    for it in range(6):
+    NB = 6 if lookahead == 2 else 10
+    for it in range(NB):
         inp, gt = syn.make_inputs(256, (64, 64), 100.0 + 5 * it, (0.2, 0.1, 2.0 + 0.04 * it), -1, seed=30 + it)
         batches.append((to_dev(inp), {'rgb': gt.to(DEV)}))
     runs = []
     for prefetch in (False, True):
         m = build_model(mc, sd, True)
-        m.ray_tracer.minsdf_steps_override = [torch.rand(100, generator=torch.Generator().manual_seed(3 + i)) for i in range(6)]
+        m.ray_tracer.minsdf_steps_override = [torch.rand(100, generator=torch.Generator().manual_seed(3 + i)) for i in range(NB)]
         st = TrainStep(m, lc, graph=graph, graph_bucket=64, graph_after=2)
         losses = []
         for i, (inp, gt) in enumerate(batches):
             nxt = None
             if prefetch and i != 3:                          # one step announces nothing
-                nxt = [b[0] for b in batches[i + 1:i + 3]] or None      # two batches of lookahead
-                if i == 1:
-                    nxt = nxt[0]                             # a single dict is accepted too
+                nxt = [b[0] for b in batches[i + 1:i + 1 + lookahead]] or None      # batches of lookahead
+                if i == 1 and lookahead == 2:
+                    nxt = nxt[0]        # a single dict is accepted too (with more batches already traced ahead it
+                                        # would read as a change of plan: they are dropped and traced again)
             out, lo = st(inp, gt, nxt)
             losses.append({k: v.item() for k, v in lo.items()})
         runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}))
