@@ -176,6 +176,9 @@ typedef struct nefii_tracer_params {
     int32_t minsdf_group;    /* > 0: minsdf_steps holds one row of n_steps uniform draws per minsdf_group consecutive rays
                                 (several batches - each with the draw the reference makes per call, ray_tracing.py:316 -
                                 traced as ONE call); 0: one row for all rays */
+    int32_t small_round;     /* rounds of at most this many split-precision queries run on 32-query tiles (more CUs, shorter
+                                round; 1.5x the chip time per query); 0: 8192.  Traces that overlap other work pass a
+                                smaller value. */
 } nefii_tracer_params;
 #define NEFII_TRACE_COUNTERS 8   /* int32 counters per round, see nefii_trace_rays */
 

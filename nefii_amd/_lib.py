@@ -41,7 +41,7 @@ class TracerParams(ctypes.Structure):
                 ('sphere_tracing_iters', ctypes.c_int32), ('n_steps', ctypes.c_int32),
                 ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32), ('bisect_levels', ctypes.c_int32),
                 ('precision', ctypes.c_int32), ('coarse_tau', ctypes.c_float), ('coarse_cap', ctypes.c_int32),
-                ('minsdf_group', ctypes.c_int32)]
+                ('minsdf_group', ctypes.c_int32), ('small_round', ctypes.c_int32)]
 
 
 class LossParams(ctypes.Structure):

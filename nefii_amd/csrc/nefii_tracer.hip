@@ -771,6 +771,9 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, 
 // and epilogue (the fragment stream per tile is the same: ~110 instead of ~150 us per round).  Kept as two kernels:
 // fused into one, the register allocation of the 64-query path degraded (60 spills, dense rounds +25 %).
 constexpr int64_t SMALL_ROUND = 64 * 128;
+// nefii_tracer_params.small_round overrides the threshold: a trace that runs beside others is bound by chip time, not by
+// its own latency, and a 32-query tile costs 1.5x the chip time per query of a 64-query one
+__device__ __forceinline__ int64_t small_round(const Params &P) { return P.p.small_round > 0 ? P.p.small_round : SMALL_ROUND; }
 template <int NW, int RT>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Params P, nefii_mlp m, int round) {
     __shared__ Lds16p lds;
@@ -778,7 +781,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Param
     __shared__ float *dest[TILE_W];
     const RoundWork W = round_work(P, round);
     const int64_t total = W.total;
-    if ((total <= SMALL_ROUND) != (RT == 1)) return;
+    if ((total <= small_round(P)) != (RT == 1)) return;
     constexpr int ROWS = 32 * RT;
     const int64_t n_tiles = (total + ROWS - 1) / ROWS;
     if (blockIdx.x >= n_tiles) return;
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
     // 32-query tiles, that remainder goes to the 32-query instance (a wave of those is done in ~110 instead of ~160 us).
     constexpr int ROWS = 16 * QT, BIG = QGeo<FT>::ROWS, NCU = 256;
     int64_t first = 0, n_tiles;                     // this instance's tiles: first .. first + n_tiles - 1, ROWS queries each
-    if (total <= SMALL_ROUND) {
+    if (total <= small_round(P)) {
         n_tiles = QT == 2 ? (total + 31) / 32 : 0;
     } else {
         const int64_t nbig = (total + BIG - 1) / BIG, whole = nbig / NCU * NCU, rem = nbig - whole;

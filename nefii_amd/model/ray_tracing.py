@@ -75,6 +75,17 @@ class RayTracing(nn.Module):
             return 3
         return 5
 
+    @staticmethod
+    def small_round_for(n_rays, concurrent):
+        """Largest round (split-precision queries) that runs on 32-query tiles.  A lone trace wants short rounds: 8192
+        (one 32-query tile per CU).  A trace that runs beside others (TrainStep's lookahead) is bound by chip time, and a
+        32-query tile costs 1.5x the chip time per query of a 64-query one: only rounds that would not even give a
+        quarter of the CUs a 64-query tile stay on the small tiles.  NEFII_SMALL_ROUND overrides."""
+        env = os.environ.get('NEFII_SMALL_ROUND')
+        if env:
+            return int(env)
+        return 4096 if concurrent and n_rays > 1024 else 0
+
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
         object.__setattr__(self, '_net', implicit_network)
@@ -132,7 +143,8 @@ class RayTracing(nn.Module):
             tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
                 net.coarse_tau(self.object_bounding_sphere)
         params = ops.make_tracer_params(self._cfg(), training, self.precision, levels, coarse_tau=tau,
-                                        coarse_cap=self.coarse_cap, minsdf_group=group)
+                                        coarse_cap=self.coarse_cap, minsdf_group=group,
+                                        small_round=self.small_round_for(n_rays, self.concurrent))
         state = None
         if self.adaptive_rounds:      # one guess per (mode, batch size): primary and secondary traces differ
             import math

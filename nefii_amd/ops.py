@@ -365,9 +365,11 @@ def executed_evals(counters, n_steps, tri_nodes=None):
 PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}
 
 
-def make_tracer_params(cfg, training, precision='f32', bisect_levels=3, coarse_tau=0.0, coarse_cap=0, minsdf_group=0):
+def make_tracer_params(cfg, training, precision='f32', bisect_levels=3, coarse_tau=0.0, coarse_cap=0, minsdf_group=0,
+                       small_round=0):
     p = TracerParams()
     p.minsdf_group = int(minsdf_group)
+    p.small_round = int(small_round)
     p.precision = PRECISIONS[precision]
     p.bisect_levels = bisect_levels
     p.coarse_tau = float(coarse_tau)

@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     # nefii_layer: 4 x int32 + 4 pointers; nefii_mlp: 8 x int32 + 12 layers
     assert ctypes.sizeof(_lib.Layer) == 16 + 5 * 8
     assert ctypes.sizeof(_lib.Mlp) == 40 + 12 * ctypes.sizeof(_lib.Layer)
-    assert ctypes.sizeof(_lib.TracerParams) == 52         # 3 floats + 7 int32 + coarse_tau + coarse_cap + minsdf_group
+    assert ctypes.sizeof(_lib.TracerParams) == 56         # 3 floats + 7 int32 + coarse_tau + coarse_cap + minsdf_group + small_round
 
 
 def test_host_side_argument_checks_need_no_gpu():
