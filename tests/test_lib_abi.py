@@ -132,3 +132,51 @@ def test_value_grad_and_mlp_stream_sizes():
     specs, enc, head = ops.radiance_specs(syn.model_conf('conf', hidden=64)['rendering_network'], 64)
     assert lib.nefii_mlp_stream_bytes(ctypes.byref(descriptor(specs, ops.ACT_RELU, False))) == 0
 
+
+
+def _integration_stub():
+    """The ```python block of INTEGRATION.md section B (the binding a maintainer would paste), up to - not including -
+    the first line that talks to the library."""
+    text = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    blocks = re.findall(r'```python\n(.*?)```', text, flags=re.S)
+    stub = [b for b in blocks if 'class TracerParams' in b]
+    assert len(stub) == 1, 'INTEGRATION.md: exactly one ctypes stub expected'
+    return stub[0]
+
+
+def test_integration_md_stub_matches_the_abi():
+    """INTEGRATION.md's reference-side binding is executable documentation: its ctypes structs must have the field order,
+    types and sizes of nefii_amd/_lib.py (which the GPU suite runs on), its version constant the header's, and it must
+    perform the nefii_abi_version() handshake.  (Round 2 shipped a stub that ended at coarse_cap while the header had grown
+    minsdf_group / small_round: a pasted copy would have handed the library a short struct.)"""
+    from nefii_amd import _lib
+    stub = _integration_stub()
+    # the struct definitions and the version constant: everything that needs no library handle
+    lines, keep = [], False
+    for ln in stub.splitlines():
+        if ln.startswith('class ') or ln.startswith('NEFII_ABI_VERSION'):
+            keep = True
+        elif ln and not ln[0].isspace() and not ln.startswith('class '):
+            keep = ln.startswith('NEFII_ABI_VERSION')
+        if keep:
+            lines.append(ln)
+    ns = {'ctypes': ctypes}
+    exec('\n'.join(lines), ns)
+    for name in ('Layer', 'Mlp', 'TracerParams'):
+        doc, own = ns[name], getattr(_lib, name)
+        assert ctypes.sizeof(doc) == ctypes.sizeof(own), name
+        assert [f[0] for f in doc._fields_] == [f[0] for f in own._fields_], name
+        for (fn, ft), (_, ot) in zip(doc._fields_, own._fields_):
+            assert ctypes.sizeof(ft) == ctypes.sizeof(ot) and getattr(doc, fn).offset == getattr(own, fn).offset, (name, fn)
+    header = open(os.path.join(ROOT, 'include', 'nefii_amd.h')).read()
+    version = int(re.search(r'#define\s+NEFII_ABI_VERSION\s+(\d+)', header).group(1))
+    assert ns['NEFII_ABI_VERSION'] == version == _lib.ABI_VERSION
+    assert 'lib.nefii_abi_version() != NEFII_ABI_VERSION' in stub, 'the stub must check the library version'
+    # the positional TracerParams(...) call of the stub fills every field
+    call = re.search(r'TracerParams\((self\..*?)\)\s*#', stub, flags=re.S).group(1)
+    assert len([a for a in call.replace('\n', ' ').split(',') if a.strip()]) == len(_lib.TracerParams._fields_)
+    # and the header's struct has the same members in the same order
+    body = re.search(r'typedef struct nefii_tracer_params \{(.*?)\} nefii_tracer_params;', header, flags=re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    members = [m.strip() for decl in re.findall(r'(?:float|int32_t)\s+([^;]+);', body) for m in decl.split(',')]
+    assert members == [f[0] for f in _lib.TracerParams._fields_]
