@@ -899,8 +899,13 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, con
                 }
             }
             __syncthreads();
-            // the scratch held fp32 partial sums: what the next tile's padded k-steps may touch must be finite halves
-            for (int i = tid; i < NW * ROWS * 8 / 2; i += 512) reinterpret_cast<uint32_t *>(lds.Xl)[i] = 0u;
+            // The scratch held fp32 partial sums - NW * ROWS * 8 of them, 16 KiB: rows 0-13 of the lo image.  What the next
+            // tile's zero-weight k-steps read there must be finite halves (0 x NaN = NaN): the row's 8 pad columns, which
+            // no loader rewrites, and - nets whose layer 0 takes fewer than 512 features - the next row's first columns.
+            // All of it is cleared (until round 3 only the first half was), and the barrier keeps a late wave's zeros from
+            // landing on lo halves the next tile's feature staging has already written.
+            for (int i = tid; i < NW * ROWS * 8; i += 512) reinterpret_cast<uint32_t *>(lds.Xl)[i] = 0u;
+            __syncthreads();
         }
     }
 }

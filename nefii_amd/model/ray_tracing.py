@@ -139,7 +139,10 @@ class RayTracing(nn.Module):
         tau = 0.0
         # (batches of up to 1024 rays are latency-bound - a handful of tiles per round: the coarse pass's extra round per
         # dense search costs them more than its cheaper samples save; config 1: 2.39 vs 2.2 ms per step)
-        if self.coarse and self.precision == 'f16x3w' and n_rays > 1024:
+        # ... and geometry that still trains (model/trainable_geometry.py) changes its weights every step: the bound would
+        # have to be re-measured per forward (two 65 k-point evaluations and a host sync) - no coarse pass there
+        frozen = not any(p.requires_grad for p in net.parameters())
+        if self.coarse and self.precision == 'f16x3w' and n_rays > 1024 and (frozen or self.coarse_tau_override is not None):
             tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
                 net.coarse_tau(self.object_bounding_sphere)
         params = ops.make_tracer_params(self._cfg(), training, self.precision, levels, coarse_tau=tau,

@@ -165,6 +165,7 @@ class TrainStep:
         # same Adam as the reference (idr_train.py:188-196); `fused` only selects torch's single-kernel
         # implementation of the identical update when the parameters live on the GPU
         fused = next(model.parameters()).is_cuda
+        self._fused = fused
         self.graph = bool(graph) and fused and getattr(model, 'render_type', None) == 'sg'
         self.graph_bucket, self.graph_after = int(graph_bucket), int(graph_after)
         self._graphs = {}
@@ -195,9 +196,10 @@ class TrainStep:
 
     def _update(self, loss):
         """Gradient exchange + both Adam updates, with the reference's NaN check (idr_train.py:754-757: before
-        backward / step) as a device-side guard: when the loss is not finite on ANY rank, every rank zeroes its
-        gradients before Adam runs, so parameters and optimizer moments stay finite and the runner can still write a
-        usable emergency checkpoint.  The flag travels in the gradient all-reduce: one collective, no host sync."""
+        backward / step) as a device-side guard: when the loss - or a gradient - is not finite on ANY rank, every rank
+        zeroes its gradients and both optimizers skip the step: parameters, moments and step counters are those of the
+        last good iteration, so the emergency checkpoint the runner writes is the pre-NaN state.  The flag travels in
+        the gradient all-reduce: one collective, no host sync."""
         bad = (~torch.isfinite(loss.detach())).reshape(1).to(torch.float32)
         grads = [p.grad for p in self.trainable if p.grad is not None]
         if grads:       # a finite loss can still come with a non-finite gradient (0 x inf in some backward): same treatment
@@ -210,8 +212,18 @@ class TrainStep:
             if p.grad is not None:
                 p.grad.masked_fill_(bad, 0.0)
         self.nonfinite_steps += bad.to(self.nonfinite_steps.dtype)
-        self.idr_optimizer.step()
-        self.sg_optimizer.step()
+        # ... and the optimizers SKIP the step (zero gradients alone would still move the parameters by the first
+        # moment, decay both moments and advance the step counters).  On the GPU the fused Adam takes the flag the way
+        # torch.amp.GradScaler hands it over (optimizer.found_inf: the kernel leaves parameters and moments alone and
+        # the step counter is taken back) - on the device, capturable; the CPU implementation (multi-process gloo tests)
+        # has no such input, there the flag is read.
+        if self._fused:
+            self.idr_optimizer.found_inf = self.sg_optimizer.found_inf = bad.to(torch.float32)
+            self.idr_optimizer.step()
+            self.sg_optimizer.step()
+        elif not bool(bad):
+            self.idr_optimizer.step()
+            self.sg_optimizer.step()
 
     def retensor_lr(self):
         """After optimizer.load_state_dict, which installs the CHECKPOINT's param_groups and state: a reference checkpoint
@@ -464,10 +476,18 @@ class TrainStep:
         (idr_train.py:804-852): ties the material/light decomposition to the radiance field where the camera
         never looks."""
         pts, mask, dirs = (model_outputs.get(k) for k in ('secondary_points', 'secondary_mask', 'secondary_dir'))
-        if pts is None or mask is None or dirs is None:
+        dev = self.nonfinite_steps.device
+        # Whether this step's collective runs is decided by CONFIGURATION (the render type produces secondary rays, several
+        # ranks train), never by data: a rank whose pixel slice has no primary hit gets no secondary outputs at all
+        # (shade_tail: ret = {}), one with hits may have no secondary hit - both still enter the all-reduce with zero
+        # gradients and step their optimizers like their peers.  Returning here would pair this rank's NEXT all-reduce
+        # with its peers' current one (fixed-size buffers: silently), averaging gradients of different steps.
+        has_secondary = getattr(self.model, 'render_type', 'sg') != 'sg'
+        none = pts is None or mask is None or dirs is None
+        if not has_secondary or (none and self.world_size <= 1):
             return None
-        m = mask.reshape(-1)
-        idx = torch.nonzero(m).flatten()[:self.secondary_batch_size]
+        idx = torch.zeros(0, dtype=torch.long, device=dev) if none else \
+            torch.nonzero(mask.reshape(-1)).flatten()[:self.secondary_batch_size]
         if idx.numel() == 0 and self.world_size <= 1:
             return None
         self.idr_optimizer.zero_grad()
@@ -483,5 +503,5 @@ class TrainStep:
             loss.backward()
         # several ranks: whether this rank has secondary hits is data, whether the collective runs must not be - a rank
         # without any still enters the all-reduce (with zero gradients) and steps its optimizers like its peers
-        self._update(loss if loss is not None else torch.zeros((), device=pts.device))
+        self._update(loss if loss is not None else torch.zeros((), device=dev))
         return loss

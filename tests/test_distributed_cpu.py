@@ -264,10 +264,12 @@ def _step_worker(rank, world, port, tmp):
     st = TrainStep(model, LOSS_CONF, world_size=world, secondary_train_interval=2, secondary_batch_size=64, num_rays=2)
     torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(tmp, 'init%d.pt' % rank))
     # iteration 0: rank 1's slice has no hit at all (no gradient there) and no secondary hit (its secondary step has
-    # nothing to differentiate); iteration 1: everyone has hits; iteration 2: rank 1's loss is not finite
-    plan = [(rank == 0, rank == 0), (True, None), (True, True)]
+    # nothing to differentiate); iteration 1: rank 1's loss is not finite (no secondary step: 1 % 2); iteration 2: everyone
+    # has hits and secondary hits; iteration 4 (a secondary iteration again): rank 1 has no primary hit, so its forward
+    # returns NO secondary outputs at all (IDRNetwork.shade_tail: ret = {}) while rank 0 trains on its secondary hits
+    plan = [(rank == 0, rank == 0), (True, None), (True, True), (True, None), (rank == 0, True if rank == 0 else None)]
     for it, (hits, sec) in enumerate(plan):
-        model.poison = it == 2 and rank == 1
+        model.poison = it == 1 and rank == 1
         inp, gt = _fake_batch(rank, hits, sec)
         st(inp, gt)
         torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(tmp, 'it%d_r%d.pt' % (it, rank)))
@@ -289,12 +291,20 @@ def test_train_step_collectives_do_not_depend_on_the_data(tmp_path):
         got = L('init%d.pt' % r)
         for k in ref0:
             assert torch.equal(got[k], ref0[k]), (r, k)
-    for it in range(3):
+    for it in range(5):
         a, b = L('it%d_r0.pt' % it), L('it%d_r1.pt' % it)
         for k in a:
             assert torch.equal(a[k], b[k]), (it, k)
             assert torch.isfinite(a[k]).all(), (it, k)
     assert L('bad0.pt').item() == 1 and L('bad1.pt').item() == 1
+    # the NaN iteration is SKIPPED on every rank, not run on zero gradients: parameters are exactly those of iteration 0
+    # (Adam on a zero gradient would still have moved them by the first moment), and the next iterations train again
+    a, b = L('it0_r0.pt'), L('it1_r0.pt')
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = L('it2_r0.pt')
+    assert any(not torch.equal(b[k], c[k]) for k in b)
+    d, e = L('it3_r0.pt'), L('it4_r0.pt')
+    assert any(not torch.equal(d[k], e[k]) for k in d)
     # iteration 0 against one process: primary gradient = (rank 0's gradient + 0) / 2, then the secondary step likewise
     model = FakeIDR(seed=10)
     st = TrainStep(model, LOSS_CONF, world_size=1, secondary_train_interval=0, num_rays=2)

@@ -56,6 +56,10 @@ def kernel_probe():
                 bad_rows = (~torch.isfinite(o16).all(dim=1)).nonzero().flatten()
                 bad_stash = int((~torch.isfinite(s16)).sum())
                 err = (o16 - o32).abs().max().item() if bad_rows.numel() == 0 else float('nan')
+                off = ((o16 - o32).abs().amax(dim=1) > 1e-3).nonzero().flatten()
+                if off.numel():
+                    print('       %d rows differ by more than 1e-3: rows mod 64 %s, tiles (row // 64) %s ...' % (
+                        off.numel(), sorted(set((off % 64).tolist())), sorted(set((off // 64).tolist()))[:12]))
                 print('%-6s %-9s n=%6d stream=%s: non-finite output rows %d (first %s, rows mod 64: %s), non-finite stash '
                       'entries %d, max |f16x3 - f32| %.3g' % (
                           name, kind, n, pm16.mlp_stream, bad_rows.numel(), bad_rows[:6].tolist(),
@@ -64,8 +68,12 @@ def kernel_probe():
                 gs = ops.mlp_grad_scale(d_out)
                 dz16 = ops.mlp_backward(pm16, d_out, s16, gs)
                 dz32 = ops.mlp_backward(pm32, d_out, s32)
+                # (compare what both kernels define: hidden layers in full, the last layer's n_out columns)
+                L = len(pm16.specs)
+                a_ = torch.cat([dz16[:L - 1].reshape(-1), dz16[L - 1][:, :pm16.specs[-1].n_out].reshape(-1)])
+                b_ = torch.cat([dz32[:L - 1].reshape(-1), dz32[L - 1][:, :pm16.specs[-1].n_out].reshape(-1)])
                 print('       backward: non-finite dz entries %d, rel err vs f32 %.3g' % (
-                    int((~torch.isfinite(dz16)).sum()), ((dz16 - dz32).norm() / dz32.norm()).item()), flush=True)
+                    int((~torch.isfinite(a_)).sum()), ((a_ - b_).norm() / b_.norm()).item()), flush=True)
 
 
 class Watch:
@@ -148,6 +156,17 @@ def step_probe(workload='cfg3', steps=30, lookahead=3):
                         return r
                     return staticmethod(wrapped)
                 setattr(cls, meth, make(fn, cls.__name__ + '.' + meth))
+    # HUNT_SAVE=1: keep stream-ordered clones of the sampler's inputs and outputs of every call (no host sync) and look at
+    # the calls that produced non-finite values afterwards: which entries, from which inputs, and what a re-run gives
+    saved = []
+    if os.environ.get('HUNT_SAVE', '0') == '1':
+        raw_mis = ops.mis_sample
+
+        def mis(lgt, rough, normal, view, uniforms):
+            r = raw_mis(lgt, rough, normal, view, uniforms)
+            saved.append((W.step, [t.detach().clone() for t in (lgt, rough, normal, view, uniforms)], [t.clone() for t in r]))
+            return r
+        ops.mis_sample = mis
     nxt = [inp] * lookahead if lookahead > 0 else None
     losses = []
     for i in range(steps):
@@ -165,6 +184,35 @@ def step_probe(workload='cfg3', steps=30, lookahead=3):
     print('losses:', ['%.5f' % float(x) for x in torch.stack(losses).cpu()])
     if W.rows:
         W.report()
+    if saved:
+        ops.mis_sample = raw_mis
+        shown = 0
+        for stp, ins, outs in saved:
+            wi, own, tab = outs
+            bad = ~torch.isfinite(tab).all(dim=-1)          # [3, n]
+            if not bad.any():
+                continue
+            lgt, rough, normal, view, uni = ins
+            n = normal.shape[0]
+            idx = bad.any(dim=0).nonzero().flatten()
+            wi2, own2, tab2 = raw_mis(lgt, rough, normal, view, uni)
+            torch.cuda.synchronize()
+            again = int((~torch.isfinite(tab2)).sum())
+            same = bool(torch.equal(torch.nan_to_num(tab2), torch.nan_to_num(tab)) and torch.equal(wi2, wi))
+            print('step %d: n=%d, %d points with a non-finite pdf table (samples %s); re-run on the saved inputs: %d '
+                  'non-finite, identical to the first run: %s' % (stp, n, idx.numel(), bad.any(dim=1).tolist(), again, same))
+            print('   inputs finite: lgt %s rough %s normal %s view %s uniforms %s; |normal| min %.3g max %.3g, rough min %.3g '
+                  'max %.3g, uniforms min %.3g max %.9g' % (
+                      *[bool(torch.isfinite(t).all()) for t in ins], normal.norm(dim=-1).min().item(),
+                      normal.norm(dim=-1).max().item(), rough.min().item(), rough.max().item(), uni.min().item(),
+                      uni.max().item()))
+            for p_ in idx[:4].tolist():
+                print('   point %d: normal %s view %s rough %.4f uniforms %s\n      wi %s\n      own %s tab %s' % (
+                    p_, normal[p_].tolist(), view[p_].tolist(), rough.reshape(-1)[p_].item(), uni[p_].tolist(),
+                    wi[:, p_].tolist(), own[:, p_].tolist(), tab[:, p_].tolist()))
+            shown += 1
+            if shown >= 4:
+                break
 
 
 if __name__ == '__main__':
