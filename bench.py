@@ -170,22 +170,30 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     priming = max(0, step.graph_after + 1 - warmup) if use_graph else 0     # the same count on every rank
     for _ in range(priming):
         step(inp, gt, nxt)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out, lo = step(inp, gt, nxt)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    # the timed region - exactly `steps` steps between barrier + synchronize on both sides, max over ranks - is measured
+    # `repeats` times back to back (63 ms of a 20-step config-2 region is a thin basis for a headline: boxes and moments
+    # differ by a few percent); the line reports the MEDIAN repetition and lists them all
+    reps = []
+    for _ in range(max(1, args.repeats)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, lo = step(inp, gt, nxt)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = t.item()
+        reps.append(elapsed)
+    elapsed = sorted(reps)[len(reps) // 2]
     ms_per_step = elapsed / steps * 1e3
     value = rays_per_rank * world / (elapsed / steps)
+    nonfinite_timed = int(step.nonfinite_steps.item())      # steps the NaN guard cancelled so far (warm-up + timed)
 
     # ---- un-timed side measurements (every rank runs the steps: they contain the gradient all-reduce)
     # (1) the same step without the min-SDF search that is dead work under frozen geometry
@@ -278,6 +286,9 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
         a_step += n_hit2 * (2 * f_eval + 3 * f_rad)
     a_ray = a_step / rays_per_rank
     frac_step = a_ray * (value / world) / (peak * 1e12)
+    # the evaluators' algorithmic flops over the TIMED step (several traces run beside each other there, so this can
+    # exceed frac_kernel, which prices one trace's evaluator launches run back to back on one stream)
+    frac_chip = queries * f_eval / (ms_per_step * 1e-3) / (peak * 1e12)
     # HBM traffic of the same kernels: NOT measured by this run - read from the rocprofv3 PMC passes of this command
     # committed under profiles/ (tools/profile_round.sh; separate FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied
     # by tools/pmc_traffic.py), and only quoted for the workload / kernels it was measured on
@@ -295,7 +306,11 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     roofline = {'bound': 'mfma',
                 'kernel': kname + ' (fused SDF MLP over the tracer work list)',
                 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                'frac_kernel': achieved / peak, 'frac_step': frac_step,
+                'frac_kernel': achieved / peak, 'frac_step': frac_step, 'frac_chip': frac_chip,
+                'frac_definitions': 'frac_kernel: evaluator flops / evaluator launch time of ONE trace run serially (HIP '
+                                    'events, an extra un-timed step); frac_chip: the same flops / ms_per_step of the timed '
+                                    'steps (traces overlapped); frac_step: SURVEY 8(d) A x rays/s / peak (whole step, dead '
+                                    'min-SDF search excluded)',
                 'traffic': traffic, 'traffic_source': traffic_source,
                 'arithmetic': ('split precision: 3x v_mfma_f32_16x16x32_f16 per k-step on fp16 hi/lo operand pairs, fp32 '
                                'accumulate; coarse pass (bracket / min-SDF searches): 1x, decisive samples re-evaluated in '
@@ -319,6 +334,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
         'metric': 'training rays/sec (Step-2 material opt)', 'value': value, 'unit': 'rays/s',
         'n_gpus': world, 'steps': steps, 'warmup': warmup, 'graph_priming_steps': priming,
         'ms_per_step': ms_per_step,
+        'ms_per_step_repeats': [e / steps * 1e3 for e in reps],
         'ms_per_step_without_dead_min_sdf_search': ms_skip,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f16x3' if split else 'f32', 'data': 'synthetic',
@@ -332,7 +348,10 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                    'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
                    'step_graph': bool(use_graph),
                    'rank_param_spread': param_spread,
-                   'nonfinite_steps': int(step.nonfinite_steps.item()),     # steps cancelled by TrainStep's NaN guard
+                   # steps cancelled by TrainStep's NaN guard: in warm-up + timed repetitions / in the whole run.  Any
+                   # cancelled step makes the line INVALID (main() flags it and exits non-zero)
+                   'nonfinite_steps_timed': nonfinite_timed,
+                   'nonfinite_steps': int(step.nonfinite_steps.item()),
                    'trace_prefetch': len(nxt) if nxt is not None else 0,   # batches traced ahead, beside the tail of batch i
                    # MC workloads: does the secondary trace also fill the outputs of rays that MISS (min-SDF search,
                    # argmin fallback)?  Nothing reads them (idr_train.py:819 masks secondary_points with the hit mask);
@@ -357,6 +376,7 @@ def main():
                     help='skip the untimed side loop without the min-SDF search (profiling runs: nearly every step of the\n'
                          'process is then the headline step, so rocprofv3 per-kernel averages compare directly)')
     ap.add_argument('--cpu-sample-pixels', type=int, default=512)
+    ap.add_argument('--repeats', type=int, default=3, help='repetitions of the timed K-step region (median reported)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -392,12 +412,20 @@ def main():
         dist.destroy_process_group()        # nothing below communicates (rank 0 alone runs the CPU baseline)
     if rank == 0:
         if nested is not None:
-            result['cfg3'] = {k: nested[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config',
-                                                     'roofline')}
+            result['cfg3'] = {k: nested[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step',
+                                                     'ms_per_step_repeats', 'dtype', 'config', 'roofline')}
         if not args.no_cpu_baseline:
             result['cpu_baseline'], result['parity_vs_cpu_oracle'] = cpu_baseline(
                 headline, args.cpu_sample_pixels, steps=3, warmup=1, device=dev)
+        # a step the NaN guard cancelled costs the same time as a good one but did not train: a throughput of such steps
+        # is not a measurement of the metric (round 2's nested config 3 had one in seven)
+        cancelled = result['config']['nonfinite_steps'] + (nested['config']['nonfinite_steps'] if nested else 0)
+        result['invalid'] = cancelled > 0
+        if cancelled:
+            result['invalid_reason'] = '%d training step(s) produced a non-finite loss or gradient and were cancelled' % cancelled
         print(json.dumps(result), flush=True)
+        if cancelled:
+            sys.exit(3)
 
 
 if __name__ == '__main__':

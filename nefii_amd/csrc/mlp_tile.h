@@ -23,6 +23,22 @@ namespace nefii {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// A kernel that may run BESIDE other streams' work (the tracer's evaluators: TrainStep traces the coming batches on side
+// streams while the current batch's tail runs) claims its SIMDs' whole vector register file, so that no wave of another
+// kernel is ever placed on a SIMD that hosts its MFMA waves.  Found in round 3 (tools/concurrency_probe.py, DESIGN.md
+// "Packed fp32 beside MFMA waves"): on gfx950 a wave executing packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 /
+// v_pk_fma_f32 - hipcc forms them from adjacent scalar float operations, e.g. a cross product) computes WRONG results in
+// one half of the pair, silently and rarely (1e-5 of the threads), while it shares a SIMD with waves that stream
+// v_mfma_f32_16x16x32_f16 - alone, or beside MFMA kernels that fill the register file, it is exact.  A 209-register
+// evaluator wave left room for one 80-register wave of the MC sampler: config 3 got non-finite pdfs in a third of its steps.
+// The claim costs the kernel nothing (LDS already limits it to these waves); other kernels get CUs that host none of its
+// workgroups.  The library itself is compiled without packed-fp32 instructions (nefii_amd/build.py), so its own VALU code
+// is never the victim; the claim protects the kernels it does not compile (torch's).
+//   NEFII_CLAIM_SIMD_2: two waves of this kernel per SIMD (8-wave workgroups, one per CU) - 256 registers each;
+//   NEFII_CLAIM_SIMD_1: one wave per SIMD (4-wave workgroups) - all 512 (256 architectural + 256 accumulation).
+#define NEFII_CLAIM_SIMD_2() asm volatile("" ::: "v255")
+#define NEFII_CLAIM_SIMD_1() asm volatile("" ::: "v255", "a255")
+
 constexpr int TILE = NEFII_TILE_ROWS;   // 32 rows
 constexpr int XS = 516;                 // X row stride (floats): 4*129
 constexpr int ES = 100;                 // E row stride (floats): 4*25

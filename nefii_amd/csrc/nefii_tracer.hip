@@ -635,7 +635,8 @@ __device__ __forceinline__ void decode_tile_coarse(const Params &P, int64_t tile
     rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
 }
 
-__global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int round) {
+__global__ __launch_bounds__(256, 1) void eval_kernel(Params P, nefii_mlp m, int round) {
+    NEFII_CLAIM_SIMD_1();
     __shared__ Lds lds;
     __shared__ float raw[TILE * 9];
     __shared__ float *dest[TILE];
@@ -670,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void eval_kernel(Params P, nefii_mlp m, int
 
 // split-precision variant (3 x fp16 MFMA per k-step, mlp_tile.h)
 __global__ __launch_bounds__(256, 1) void eval_kernel16(Params P, nefii_mlp m, int round) {    // 81 KB of LDS: one workgroup per CU anyway
+    NEFII_CLAIM_SIMD_1();
     __shared__ Lds16 lds;
     __shared__ float raw[TILE * 9];
     __shared__ float *dest[TILE];
@@ -749,6 +751,7 @@ __device__ __forceinline__ void sdf_tile16w(const nefii_mlp &m, Lds16w &lds, con
 }
 
 __global__ __launch_bounds__(512, 2) void eval_kernel16w(Params P, nefii_mlp m, int round) {
+    NEFII_CLAIM_SIMD_2();
     __shared__ Lds16w lds;
     __shared__ float raw[TILE_W * 9];
     __shared__ float *dest[TILE_W];
@@ -776,6 +779,8 @@ constexpr int64_t SMALL_ROUND = 64 * 128;
 __device__ __forceinline__ int64_t small_round(const Params &P) { return P.p.small_round > 0 ? P.p.small_round : SMALL_ROUND; }
 template <int NW, int RT>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void eval_kernel16p(Params P, nefii_mlp m, int round) {
+    static_assert(NW == 8, "register claim below: two waves per SIMD");
+    NEFII_CLAIM_SIMD_2();
     __shared__ Lds16p lds;
     __shared__ float raw[TILE_W * 9];
     __shared__ float *dest[TILE_W];
@@ -811,6 +816,7 @@ __device__ __forceinline__ void zero_lds(LdsQ<FT> &lds) {
 // 64- / 32-query tiles; FT = 2: 256-wide hidden layers (conf_neus.conf), 96- / 32-query tiles.
 template <int QT, int FT, bool DEEP = false>
 __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, int round) {
+    NEFII_CLAIM_SIMD_2();
     constexpr int RMAX = QGeo<FT>::ROWS;
     __shared__ LdsQ<FT> lds;
     __shared__ float raw[RMAX * 9];
@@ -872,6 +878,7 @@ __device__ __forceinline__ void zero_lds_any(LDS &lds) {
 
 template <int QT, int FT, bool DB = true>
 __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, int round) {
+    NEFII_CLAIM_SIMD_2();
     constexpr int ROWS = 16 * QT, RMAX = ROWS;
     __shared__ LdsSx<FT, ROWS, DB> lds;
     __shared__ float raw[RMAX * 9];

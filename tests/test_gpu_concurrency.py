@@ -1,0 +1,131 @@
+"""Kernels that run BESIDE other streams' work (TrainStep traces the coming batches on side streams while the current
+batch's tail runs) must not change anybody's results - round 2's config 3 lost a third of its steps to non-finite
+gradients that appeared only under trace prefetch (DESIGN.md "Packed fp32 beside MFMA waves").
+
+Two pins:
+  * the mechanism: a canary build of the shading kernels WITH packed-fp32 instructions (libnefii_canary.so: test
+    infrastructure, nefii_amd/build.py:build_canary) gives bit-identical results beside every tracer evaluator of the product
+    library - on gfx950 it does not when an evaluator leaves room for a foreign wave on its SIMDs (mlp_tile.h, NEFII_CLAIM_SIMD);
+  * the symptom: config 3 at full width, 30 steps with three batches of lookahead - no step cancelled, same losses and
+    parameters as the serial schedule."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from nefii_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(name, scene='bowl', seed=0):
+    from nefii_amd import conf
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    mc = syn.model_conf(name)
+    m = IDRNetwork(conf.from_dict(mc))
+    m.load_state_dict(syn.make_state_dict(mc, seed=seed, scene=scene), strict=True)
+    m = m.to(DEV)
+    m.freeze_geometry()
+    m.train()
+    return mc, m
+
+
+def test_packed_fp32_canary_beside_the_evaluators():
+    from nefii_amd import build, ops
+    from nefii_amd.ops import _ptr
+    build.build_canary(verbose=False)
+    canary = ctypes.CDLL(build.CANARY_OUT)
+    P, I, I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    canary.nefii_mis_sample.restype = I
+    canary.nefii_mis_sample.argtypes = [P, I, P, P, P, P, I64, P, P, P, P]
+    _, m512 = _model('conf')
+    _, m256 = _model('neus')
+    pm512, pm256 = (m.implicit_network.packed(f16x3=True) for m in (m512, m256))
+    g = torch.Generator().manual_seed(3)
+    n = 114891
+    normal = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1).to(DEV)
+    view = torch.nn.functional.normalize(torch.randn(n, 3, generator=g) * 0.2 + torch.tensor([0., 0., 1.]), dim=-1).to(DEV)
+    rough = (torch.rand(n, generator=g) * 0.8 + 0.15).to(DEV)
+    uni = torch.rand(n, 7, generator=g).to(DEV)
+    lgt = m512.envmap_material_network.get_lgtSGs().detach().clone().contiguous()
+    xs = (torch.randn(1 << 19, 3, generator=g) * 0.45).to(DEV)
+    xsmall = (torch.randn(6000, 3, generator=g) * 0.45).to(DEV)
+
+    def victim():
+        wi = torch.empty(3, n, 3, device=DEV)
+        own = torch.empty(3, n, device=DEV)
+        tab = torch.empty(3, n, 3, device=DEV)
+        rc = canary.nefii_mis_sample(_ptr(lgt), lgt.shape[0], _ptr(rough), _ptr(normal), _ptr(view), _ptr(uni), n, _ptr(wi),
+                                     _ptr(own), _ptr(tab), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return torch.cat([wi.reshape(-1), own.reshape(-1), tab.reshape(-1)])
+
+    loads = {
+        '512-wide single pass': lambda: ops.sdf_eval(pm512, xs, coarse=True),
+        '512-wide split': lambda: ops.sdf_eval(pm512, xs),
+        '256-wide single pass': lambda: ops.sdf_eval(pm256, xs, coarse=True),
+        '256-wide split': lambda: ops.sdf_eval(pm256, xs),
+        'tracer rounds (all evaluator instances of a 512-wide trace)': None,
+    }
+    ref = victim()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(victim()), torch.nan_to_num(ref))
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    inp, _ = syn.make_inputs(4096, (800, 800), 1111.0, (0., 0., 2.4), 16, seed=1)
+    inp = {k: v.to(DEV) for k, v in inp.items()}
+    for name, load in loads.items():
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sb):
+            if load is None:
+                for _ in range(4):
+                    m512.trace_points(inp)          # eval_kernel16q / 16s instances, 64- and 32-query tiles, as the step runs them
+                    ops.sdf_eval(pm512, xsmall)
+            else:
+                for _ in range(10):
+                    load()
+        outs = []
+        with torch.cuda.stream(sa):
+            for _ in range(30):
+                outs.append(victim())
+        torch.cuda.synchronize()
+        bad = [int((torch.nan_to_num(o) != torch.nan_to_num(ref)).sum()) for o in outs]
+        assert max(bad) == 0, '%s: %d of %d runs of the packed-fp32 canary differ (worst: %d elements)' % (
+            name, sum(b > 0 for b in bad), len(bad), max(bad))
+
+
+def test_config3_prefetch_trajectory_equals_the_serial_schedule():
+    """BASELINE config 3 (conf.conf at full width, 4096 px x 64 rays, MC direct + indirect, secondary-consistency step every
+    10 iterations) for 30 steps: with three batches traced ahead beside the tail no step is cancelled by the NaN guard, and
+    losses and parameters follow the serial schedule's (same seeds: the min-SDF draws and the MC uniforms come in the same
+    order; the float atomics of the weight-gradient kernels make the two runs differ in the last bits only)."""
+    from nefii_amd.training.step import TrainStep
+    w = dict(syn.WORKLOADS['cfg3'])
+    runs = []
+    for lookahead in (0, 3):
+        torch.manual_seed(77)
+        mc, m = _model(w['model'], w['scene'])
+        inp, gt = syn.make_inputs(w['num_pixels'], w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
+        inp = {k: v.to(DEV) for k, v in inp.items()}
+        gt = {'rgb': gt.to(DEV)}
+        st = TrainStep(m, syn.loss_conf(w['model']), secondary_train_interval=10, secondary_batch_size=1024,
+                       num_rays=w['num_rays'])
+        nxt = [inp] * lookahead if lookahead else None
+        losses = []
+        for _ in range(30):
+            out, lo = st(inp, gt, nxt)
+            losses.append(lo['loss'].detach())
+        torch.cuda.synchronize()
+        runs.append((torch.stack(losses).cpu(), int(st.nonfinite_steps.item()),
+                     {k: v.detach().clone() for k, v in m.state_dict().items()}))
+    (l0, bad0, p0), (l1, bad1, p1) = runs
+    assert bad0 == 0 and bad1 == 0, (bad0, bad1)
+    assert torch.isfinite(l0).all() and torch.isfinite(l1).all()
+    assert ((l0 - l1).abs() / l0.abs()).max().item() < 2e-3, (l0, l1)
+    assert l1[-5:].mean() < l1[:5].mean()            # and it trains
+    for k in p0:
+        if p0[k].dtype.is_floating_point and p0[k].numel() > 0:
+            d = (p1[k] - p0[k]).norm().item() / (p0[k].norm().item() + 1e-12)
+            assert d < 5e-3, (k, d)

@@ -66,6 +66,80 @@ def main():
         'torch matmul 2048^3': lambda: a_mat @ a_mat,
         'torch elementwise': lambda: torch.sin(big) * torch.cos(big),
     }
+    if os.environ.get('PROBE_LOADS', '') == 'wide':
+        # which of the MFMA kernels of this library disturb a packed-fp32 victim (mis_sample is the canary)?
+        victims = {k: v for k, v in victims.items() if k in ('mis_sample', 'env_radiance')}
+        mc2 = syn.model_conf('neus')
+        m2 = IDRNetwork(conf.from_dict(mc2))
+        m2.load_state_dict(syn.make_state_dict(mc2, seed=0, scene='bowl'), strict=True)
+        m2 = m2.to(dev)
+        m2.freeze_geometry()
+        pm2 = m2.implicit_network.packed(f16x3=True)
+        mat = model.envmap_material_network
+        feat_b = (torch.randn(200000, mc['feature_vector_size'], generator=g) * 0.3).to(dev)
+        p_b = (torch.randn(200000, 3, generator=g) * 0.4).to(dev)
+        n_b = torch.nn.functional.normalize(torch.randn(200000, 3, generator=g), dim=-1).to(dev)
+        h_a = torch.randn(4096, 4096, generator=g).to(dev).half()
+
+        def rad_train():
+            out = rad(p_b, n_b, n_b, feat_b)
+            out.sum().backward()
+
+        def mat_fwd():
+            with torch.no_grad():
+                return mat(p_b, feat_b, n_b)
+
+        loads = {
+            'idle': None,
+            'conf coarse 16s<4,4> (512k)': lambda: ops.sdf_eval(pm, xs, coarse=True),
+            'conf split 16q<4,4> (512k)': lambda: ops.sdf_eval(pm, xs),
+            'neus coarse 16s<6,2> (512k)': lambda: ops.sdf_eval(pm2, xs, coarse=True),
+            'neus split 16q<2> (512k)': lambda: ops.sdf_eval(pm2, xs),
+            'neus value_grad (512k)': lambda: ops.sdf_value_grad(pm2, xs, want_feat=False),
+            'radiance fwd+bwd+wgrad (200k)': rad_train,
+            'material fwd (200k)': mat_fwd,
+            'torch half matmul 4096^3': lambda: h_a @ h_a,
+        }
+    if os.environ.get('PROBE_LOADS', '') == 'torch':
+        # are torch's own kernels (the step's glue: weight-norm, normalisations, Adam's arithmetic) disturbed beside the
+        # single-pass evaluator?  (run with a library built WITHOUT the register claim: NEFII_LIB_PATH)
+        b1, b2, b3 = (torch.randn(1 << 21, generator=g).to(dev) for _ in range(3))
+        v_w = torch.randn(512, 512, generator=g).to(dev)
+        g_w = torch.rand(512, 1, generator=g).to(dev) + 0.5
+        x3 = torch.randn(200000, 3, generator=g).to(dev)
+        params = [torch.randn(512, 512, generator=g).to(dev) for _ in range(12)]
+        grads = [torch.randn(512, 512, generator=g).to(dev) * 1e-3 for _ in range(12)]
+
+        def adam_like():
+            m = torch._foreach_lerp([torch.zeros_like(p_) for p_ in params], grads, 0.1)
+            vv = torch._foreach_addcmul([torch.zeros_like(p_) for p_ in params], grads, grads, 0.001)
+            den = torch._foreach_sqrt(vv)
+            torch._foreach_add_(den, 1e-8)
+            out = torch._foreach_addcdiv(params, m, den, -5e-4)
+            return torch.cat([o.reshape(-1) for o in out])
+
+        def fused_adam():
+            ps = [p_.clone().requires_grad_(True) for p_ in params]
+            for p_, g_ in zip(ps, grads):
+                p_.grad = g_.clone()
+            opt = torch.optim.Adam(ps, lr=5e-4, fused=True)
+            opt.step()
+            opt.step()
+            return torch.cat([p_.detach().reshape(-1) for p_ in ps])
+
+        victims = {
+            'addcmul': lambda: torch.addcmul(b1, b2, b3, value=0.5),
+            'lerp': lambda: torch.lerp(b1, b2, 0.3),
+            'a*b+c*a (fused by nothing: 3 kernels)': lambda: b1 * b2 + b3 * b1,
+            'normalize rows [n,3]': lambda: x3 / (x3.norm(dim=-1, keepdim=True) + 1e-6),
+            'weight_norm 512x512': lambda: torch._weight_norm(v_w, g_w, 0),
+            'sigmoid * (1-0.089) + 0.089': lambda: torch.sigmoid(b1) * (1 - 0.089) + 0.089,
+            'foreach Adam arithmetic': adam_like,
+            'torch.optim.Adam(fused=True) x2': fused_adam,
+            'mis_sample (this library)': victims['mis_sample'],
+        }
+        loads = {'idle': None, 'conf coarse 16s<4,4> (512k)': lambda: ops.sdf_eval(pm, xs, coarse=True),
+                 'conf split 16q<4,4> (512k)': lambda: ops.sdf_eval(pm, xs)}
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     print('victim x load: runs that differ from the idle-chip result / runs   (elements that differ in the worst run)')
     for vname, vf in victims.items():
