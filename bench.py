@@ -146,12 +146,19 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     model = model.to(dev)
     model.freeze_geometry()
     model.train()
-    # weak scaling: global batch = num_pixels * world, contiguous per-rank slice of the patch list
-    inp, gt = syn.make_inputs(w['num_pixels'] * world, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'],
-                              seed=1, rank=rank, world_size=world)
+    # weak scaling (default): global batch = num_pixels * world; --scaling strong: the config's own global batch (config 4:
+    # 8192 pixels) - either way the contiguous per-rank slice of the global patch list (scene_dataset.py:268-279)
+    strong = getattr(args, 'scaling', 'weak') == 'strong'
+    inp, gt = syn.make_inputs(w['num_pixels'] * (1 if strong else world), w['image_hw'], w['focal'], w['cam_pos'],
+                              w['num_rays'], seed=1, rank=rank, world_size=world)
     inp = {k: v.to(dev) for k, v in inp.items()}
     gt = {'rgb': gt.to(dev)}
     rays_per_rank = inp['uv'].shape[1] * (w['num_rays'] if w['num_rays'] > 0 else 1)
+    rays_all_ranks = rays_per_rank * world
+    if strong and world > 1:        # the last rank takes the remainder of the patch list
+        t = torch.tensor([float(rays_per_rank)], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        dist.all_reduce(t)
+        rays_all_ranks = int(t.item())
     indirect = mc.get('render_type', 'sg') != 'sg'
     # conf.conf runs: secondary-consistency step every 10 iterations on 1024/world points (robot/run_s2.sh:25-26)
     # closed-form shading: the step's tail replays as a hipGraph after 3 eager iterations (NEFII_BENCH_GRAPH=0: eager)
@@ -192,7 +199,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
         reps.append(elapsed)
     elapsed = sorted(reps)[len(reps) // 2]
     ms_per_step = elapsed / steps * 1e3
-    value = rays_per_rank * world / (elapsed / steps)
+    value = rays_all_ranks / (elapsed / steps)
     nonfinite_timed = int(step.nonfinite_steps.item())      # steps the NaN guard cancelled so far (warm-up + timed)
 
     # ---- un-timed side measurements (every rank runs the steps: they contain the gradient all-reduce)
@@ -336,11 +343,12 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
         'ms_per_step': ms_per_step,
         'ms_per_step_repeats': [e / steps * 1e3 for e in reps],
         'ms_per_step_without_dead_min_sdf_search': ms_skip,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f16x3' if split else 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %s, %s model, num_pixels=%d per GPU%s, 128 SG lobes, %s, frozen geometry, '
                                'fwd+IDRLoss+bwd+2xAdam'
-                               % (name, 'robot-like synthetic scene (geometric-init SDF sphere)' if not w.get('scene') else
+                               % (name + (' (strong scaling: global batch split over the ranks)' if strong else ''),
+                                  'robot-like synthetic scene (geometric-init SDF sphere)' if not w.get('scene') else
                                   'non-convex synthetic scene (fitted ball-in-bowl SDF embedded at full width)',
                                   {'physg': 'physg.conf', 'conf': 'conf.conf', 'neus': 'conf_neus.conf'}[w['model']],
                                   w['num_pixels'], (' x %d rays/pixel' % w['num_rays']) if w['num_rays'] > 0 else '',
@@ -364,6 +372,67 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     }
 
 
+def syn_is_render(name):
+    from nefii_amd import synthetic as syn
+    return bool(syn.WORKLOADS[name].get('eval'))
+
+
+def run_render(name, args, frames, rank, world, dev, backend):
+    """BASELINE config 5: eval-mode full-frame render, the frame's chunks dealt round-robin over the ranks and gathered on
+    rank 0 (training/render.py:render_frame <-> scripts/render.py:267-360).  One "step" = one 800 x 800 frame at 256 rays per
+    pixel; strong scaling by definition (the frame is the unit).  --frame-rows R renders the first R rows only (a
+    bounded run: a whole frame takes ~1.5 minutes on one GPU)."""
+    import torch.distributed as dist
+    from nefii_amd import conf, synthetic as syn
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from nefii_amd.training.render import render_frame
+    w = dict(syn.WORKLOADS[name])
+    mc, sd = syn.workload_state_dict(name, seed=0)
+    model = IDRNetwork(conf.from_dict(mc))
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    model.freeze_geometry()
+    H, W = w['image_hw']
+    rows = min(H, args.frame_rows) if args.frame_rows > 0 else H
+    inp = syn.frame_inputs(w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], rows=(0, rows))
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    n_pix = rows * W
+    warm = {'uv': inp['uv'][:, :1024 * world].contiguous(), 'object_mask': inp['object_mask'][:, :1024 * world].contiguous(),
+            'pose': inp['pose'], 'intrinsics': inp['intrinsics']}
+    render_frame(model, warm, warm['uv'].shape[1], num_rays=w['num_rays'], memory_capacity_level=w['memory_capacity_level'],
+                 rank=rank, world_size=world)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        out = render_frame(model, inp, n_pix, num_rays=w['num_rays'], memory_capacity_level=w['memory_capacity_level'],
+                           rank=rank, world_size=world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    if rank != 0:
+        return None
+    rays = n_pix * w['num_rays']
+    level = w['memory_capacity_level'] - int(math.floor(math.log2(world)))
+    return {'metric': 'render rays/sec (full-frame novel-view render, eval mode)', 'value': rays * frames / elapsed,
+            'unit': 'rays/s', 'n_gpus': world, 'steps': frames, 'warmup': 0, 'ms_per_step': elapsed / frames * 1e3,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f16x3', 'data': 'synthetic',
+            'config': {'workload': '%s: conf.conf model at full width on the non-convex stand-in, %d x %d pixels x %d rays per '
+                                   'pixel, chunks of %d pixels dealt round-robin over %d rank(s) and gathered on rank 0'
+                                   % (name, rows, W, w['num_rays'], (1 << level) // w['num_rays'], world),
+                       'primary_rays_per_frame': rays, 'seconds_per_800x800_frame': elapsed / frames * (H / rows),
+                       'hit_pixel_fraction': out['network_object_mask'].float().mean().item(),
+                       'finite': bool(all(torch.isfinite(v).all() for v in out.values() if v.dtype.is_floating_point)),
+                       'parallelism': 'pixel chunks x %d' % world},
+            'invalid': False}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -377,6 +446,10 @@ def main():
                          'process is then the headline step, so rocprofv3 per-kernel averages compare directly)')
     ap.add_argument('--cpu-sample-pixels', type=int, default=512)
     ap.add_argument('--repeats', type=int, default=3, help='repetitions of the timed K-step region (median reported)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='N > 1: weak = every rank its own num_pixels (default); strong = the workload\'s global batch split '
+                         'over the ranks as the dataset does (config 4: 8192 pixels); cfg5 (one frame) is always strong')
+    ap.add_argument('--frame-rows', type=int, default=0, help='cfg5: render only the first R rows of the frame (0: all 800)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -401,6 +474,14 @@ def main():
     from nefii_amd import _lib
     lib = _lib.lib()
     headline = args.workload or 'cfg2'
+    if syn_is_render(headline):
+        result = run_render(headline, args, max(1, args.steps if args.steps != 20 else 1), rank, world, dev, backend)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        return
     result = run_workload(headline, args, args.steps, args.warmup, rank, world, dev, backend, lib,
                           side=not args.no_side_measurement)
     nested = None

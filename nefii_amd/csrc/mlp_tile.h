@@ -23,9 +23,12 @@ namespace nefii {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// A kernel that may run BESIDE other streams' work (the tracer's evaluators: TrainStep traces the coming batches on side
-// streams while the current batch's tail runs) claims its SIMDs' whole vector register file, so that no wave of another
-// kernel is ever placed on a SIMD that hosts its MFMA waves.  Found in round 3 (tools/concurrency_probe.py, DESIGN.md
+// The 8-wave streaming kernels (the tracer's evaluators, which TrainStep runs on side streams beside the current batch's
+// tail, and the tail's own tile kernels) claim their SIMDs' whole vector register file, so that no wave of another
+// kernel is ever placed on a SIMD that hosts their MFMA waves.  (The 4-wave kernels - blocked weight gradients, the 32-row
+// f32 / fp16 MLP kernels - do not: two of their workgroups share a CU by design and a lone one leaves registers free;
+// they only ever run on the caller's stream, beside nothing but the tracer's kernels, which are compiled without
+// packed-fp32 instructions.)  Found in round 3 (tools/concurrency_probe.py, DESIGN.md
 // "Packed fp32 beside MFMA waves"): on gfx950 a wave executing packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 /
 // v_pk_fma_f32 - hipcc forms them from adjacent scalar float operations, e.g. a cross product) computes WRONG results in
 // one half of the pair, silently and rarely (1e-5 of the threads), while it shares a SIMD with waves that stream

@@ -713,6 +713,7 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, con
                                                                float *__restrict__ out, int out_stride,
                                                                float *__restrict__ hidden_out, int hid_stride,
                                                                float *__restrict__ stash, int stash_stride, int G) {
+    NEFII_CLAIM_SIMD_2();
     constexpr int ROWS = 16 * QT, XP = LdsM<QT, EW>::XP, EP = 512, NW = 8, NJ = 4 * QT, RT = (QT + 1) / 2;
     __shared__ LdsM<QT, EW> lds;
     __shared__ float raw[ROWS * 9];
@@ -1067,6 +1068,7 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16s_kernel(nefii_mlp m, co
                                                                 const float *__restrict__ stash, int stash_stride, int64_t n,
                                                                 float *__restrict__ dz, int dz_stride,
                                                                 const float *__restrict__ scale, size_t stream_off, int G) {
+    NEFII_CLAIM_SIMD_2();
     constexpr int QT = 4, FT = 4, ROWS = 64, XP = QGeo<4>::XP, NJ = FT * QT;
     __shared__ LdsS<4, ROWS> lds;
     const int tid = threadIdx.x;

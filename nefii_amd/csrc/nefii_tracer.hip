@@ -903,6 +903,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, 
 template <int QT, int FT, bool DB = true>
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
+    NEFII_CLAIM_SIMD_2();
     constexpr int ROWS = 16 * QT, RMAX = ROWS;
     __shared__ LdsSx<FT, ROWS, DB> lds;
     __shared__ float raw[RMAX * 9];
@@ -937,6 +938,7 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, cons
 template <int FT>
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16q(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
+    NEFII_CLAIM_SIMD_2();
     constexpr int ROWS = QGeo<FT>::ROWS, QT = ROWS / 16;
     __shared__ LdsQ<FT> lds;
     __shared__ float raw[ROWS * 9];
@@ -964,6 +966,7 @@ template <int NW>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void sdf_points_kernel16p(nefii_mlp m,
                                                                                 const float *__restrict__ x,
                                                                                 int64_t n, float *__restrict__ out) {
+    NEFII_CLAIM_SIMD_2();
     __shared__ Lds16p lds;
     __shared__ float raw[TILE_W * 9];
     __shared__ float *dest[TILE_W];
@@ -1206,6 +1209,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
                                                                   float *__restrict__ feat_out, int feat_stride,
                                                                   float *__restrict__ grad_out, float4v *__restrict__ ws,
                                                                   size_t vg_off, int Gw) {
+    NEFII_CLAIM_SIMD_2();
     constexpr int ROWS = 16 * QT, NW = 8, RT = QT / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, NJ = FT * QT;
     static_assert(ROWS <= QGeo<FT>::ROWS, "rows of the LDS image");
     __shared__ LdsQ<FT> lds;
@@ -1488,6 +1492,7 @@ __global__ __launch_bounds__(512, 2) void sdf_value_grad16q_kernel(nefii_mlp m, 
 // the same tile evaluator over an explicit point list (nefii_sdf_eval)
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16w(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
+    NEFII_CLAIM_SIMD_2();
     __shared__ Lds16w lds;
     __shared__ float raw[TILE_W * 9];
     __shared__ float *dest[TILE_W];

@@ -1,0 +1,116 @@
+"""BASELINE config 5 at its REAL size, once: the 800 x 800 frame, 256 sub-pixel rays per pixel, eval mode, conf.conf model at
+full width on the non-convex stand-in, chunks of 2^18 // 256 = 1024 pixels through training/render.py:render_frame
+(reference scripts/render.py:267-360) - timed, written out as the files render.py writes (EXR buffers + panel PNG), and
+checked against the CPU oracle on scattered pixels.
+
+    python tools/render_full_frame.py [out_dir] [n_check_pixels=256]
+
+The oracle comparison runs the scattered pixels ray by ray with injected sampler draws (tests/parity.py: north-star
+tolerance on RGB / albedo, hit masks, points); the frame itself is then compared with that per-ray result on everything
+that does not pass through the sampler (hit mask, points, normals, albedo, roughness, radiance) and on the mean level of
+the MC-shaded colour (fresh draws per chunk)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import torch
+
+from nefii_amd import conf, synthetic as syn
+from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+from nefii_amd.training import render as RR
+
+
+def main():
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'gpurun_out', 'render_cfg5')
+    n_check = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    os.makedirs(out_dir, exist_ok=True)
+    dev = 'cuda:0'
+    w = syn.WORKLOADS['cfg5']
+    mc, sd = syn.workload_state_dict('cfg5', seed=0)
+    m = IDRNetwork(conf.from_dict(mc))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dev).eval()
+    m.freeze_geometry()
+    H, W = w['image_hw']
+    full = syn.frame_inputs(w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'])
+    inp = {k: v.to(dev) for k, v in full.items()}
+    n_pix = H * W
+    # warm-up on one chunk's worth of pixels (packing, coarse-pass calibration, allocator)
+    warm = {'uv': inp['uv'][:, :2048].contiguous(), 'object_mask': inp['object_mask'][:, :2048].contiguous(),
+            'pose': inp['pose'], 'intrinsics': inp['intrinsics']}
+    RR.render_frame(m, warm, 2048, num_rays=w['num_rays'], memory_capacity_level=w['memory_capacity_level'])
+    torch.cuda.synchronize()
+    torch.manual_seed(11)
+    t0 = time.perf_counter()
+    frame = RR.render_frame(m, inp, n_pix, num_rays=w['num_rays'], memory_capacity_level=w['memory_capacity_level'])
+    torch.cuda.synchronize()
+    seconds = time.perf_counter() - t0
+    res = {'workload': 'cfg5: eval render, conf.conf model, %d x %d pixels x %d rays, chunks of %d pixels (level %d), 1 GPU' % (
+               H, W, w['num_rays'], (1 << w['memory_capacity_level']) // w['num_rays'], w['memory_capacity_level']),
+           'seconds_per_frame': seconds, 'primary_rays_per_s': n_pix * w['num_rays'] / seconds,
+           'pixels_per_s': n_pix / seconds, 'hit_pixel_fraction': frame['network_object_mask'].float().mean().item(),
+           'finite': bool(all(torch.isfinite(v).all() for v in frame.values() if v.dtype.is_floating_point))}
+    gt = torch.zeros(1, n_pix, 3)
+    t1 = time.perf_counter()
+    RR.write_frame(m, frame, gt, inp['pose'], [H, W], out_dir, 0)
+    RR.write_envmap(m, out_dir, coordinate_type='blender')
+    res['write_seconds'] = time.perf_counter() - t1
+    res['files'] = sorted(os.listdir(out_dir))
+
+    # ---- scattered pixels against the oracle, ray by ray
+    if n_check > 0:
+        from oracle import renderer as orr
+        from parity import compare_outputs, rel_l2
+        from test_gpu_configs import gpu_forward_with_per_ray_draws, per_ray_layout
+        g = torch.Generator().manual_seed(5)
+        hitpx = frame['network_object_mask'].reshape(-1).cpu()
+        # half of the sample on the object (where shading happens), half anywhere (silhouette, background)
+        on = torch.nonzero(hitpx).flatten()
+        pick = torch.cat([on[torch.randperm(on.numel(), generator=g)[:n_check // 2]],
+                          torch.randperm(n_pix, generator=g)[:n_check - n_check // 2]]).sort().values
+        sub = {'uv': full['uv'][:, pick].contiguous(), 'object_mask': full['object_mask'][:, pick].contiguous(),
+               'pose': full['pose'], 'intrinsics': full['intrinsics']}
+        flat, _, R = per_ray_layout(sub)
+        n_ray = flat['uv'].shape[1]
+        uniforms = torch.rand(n_ray, 7, generator=g)
+        Ro = orr.Renderer({k: v.clone() for k, v in sd.items()}, mc, training=False)
+        Ro.dead_work = False
+        t2 = time.perf_counter()
+        with torch.no_grad():
+            ref = Ro.forward(flat, None, uniforms, None)
+        res['oracle_seconds'] = time.perf_counter() - t2
+        with torch.no_grad():
+            out = gpu_forward_with_per_ray_draws(m, {k: v.to(dev) for k, v in flat.items()}, uniforms)
+        stats = compare_outputs(out, ref, max_flips=max(4, n_ray // 2000), what='cfg5 frame sample', rays_per_pixel=1,
+                                ray_hit=m.last_ray_hit, ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02)
+        both = (out['network_object_mask'].cpu() == ref['network_object_mask'])
+        res['oracle_check'] = {'pixels': int(pick.numel()), 'rays': n_ray, 'hit_ray_fraction': ref['_ray_hit'].float().mean().item(),
+                               'rgb_rel_l2': rel_l2(out['sg_rgb_values'][both.to(dev)], ref['sg_rgb_values'][both]),
+                               'albedo_rel_l2': rel_l2(out['sg_diffuse_albedo_values'][both.to(dev)],
+                                                       ref['sg_diffuse_albedo_values'][both]),
+                               'tolerance_rel_l2': 1e-3, **stats}
+        # the frame at these pixels against the per-ray result reduced per pixel (what does not depend on the draws)
+        per_px = lambda k: out[k].reshape(pick.numel(), R, -1)
+        fr = {k: v[pick.to(v.device)] for k, v in frame.items()}
+        assert torch.equal(fr['network_object_mask'].cpu(), out['network_object_mask'].reshape(pick.numel(), R).all(1).cpu())
+        chk = {}
+        for k in ('points', 'sg_diffuse_albedo_values', 'sg_roughness_values', 'idr_rgb_values'):
+            chk[k] = rel_l2(fr[k], per_px(k).mean(1))
+            assert chk[k] < 1e-5, (k, chk[k])
+        chk['normal_values'] = rel_l2(fr['normal_values'], per_px('normal_values')[:, 0])
+        assert chk['normal_values'] < 1e-5
+        a, b = fr['sg_rgb_values'].mean().item(), per_px('sg_rgb_values').mean().item()
+        chk['sg_rgb_mean_frame_vs_per_ray'] = [a, b]
+        assert abs(a - b) < 0.03 * abs(b), (a, b)
+        res['frame_vs_per_ray_forward'] = chk
+    print(json.dumps(res))
+    with open(os.path.join(out_dir, 'render_cfg5_full_frame.json'), 'w') as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
