@@ -981,9 +981,14 @@ __device__ __forceinline__ void qstep(P16<8>::Stage (&b)[4], QAct<QT> (&a)[2], P
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             f32x4 &c = acc[(2 * HALF + f) * QT + qt];
+#ifdef NEFII_STREAM_ONLY
+            asm volatile("" ::"v"(b[J].f[2 * f]), "v"(b[J].f[2 * f + 1]), "v"(a[ABUF].h[qt]), "v"(a[ABUF].l[qt]));
+            (void)c;
+#else
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 * f], a[ABUF].h[qt], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 * f + 1], a[ABUF].h[qt], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 * f], a[ABUF].l[qt], c, 0, 0, 0);
+#endif
         }
     // MFMAs lead, the memory instructions are spread between them (see pstep)
 #pragma unroll
@@ -1289,7 +1294,12 @@ __device__ __forceinline__ void sstep(SStage<FT> (&b)[4], SAct<QT> (&a)[DB ? 2 :
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             f32x4 &c = acc[ft * QT + qt];
+#ifdef NEFII_STREAM_ONLY    /* experiment: the tile without its matrix work - fragments and activation reads stay */
+            asm volatile("" ::"v"(b[J].f[ft]), "v"(a[DB ? (J & 1) : 0].h[qt]));
+            (void)c;
+#else
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[ft], a[DB ? (J & 1) : 0].h[qt], c, 0, 0, 0);
+#endif
         }
     if constexpr (DB) {
         // MFMAs lead; the unit's FT fragment loads and QT activation reads are spread between them (see pstep)

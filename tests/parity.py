@@ -40,7 +40,7 @@ def mc_flagged_rays(out, ref, hit, rhit, dir_tol=1e-3):
 
 
 def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel=1, ray_hit=None, ref_ray_hit=None,
-                    max_explained_frac=0.0):
+                    max_explained_frac=0.0, sdf_outliers=0):
     """`out` (HIP path) against `ref` (oracle output or reference-generated fixture), per pixel.
 
     ray_hit / ref_ray_hit: the per-ray hit masks of both sides (model.last_ray_hit, oracle '_ray_hit' / fixture
@@ -70,8 +70,9 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel
             h = rnet[keep]
             if k == 'points':
                 assert rel_l2(a[h], b[h]) < 1e-4, (what, k, rel_l2(a[h], b[h]))
-            else:      # |sdf| <= 5e-5 on the surface: absolute comparison
-                assert (a[h] - b[h]).abs().max().item() < 2e-4, (what, k)
+            else:      # |sdf| <= 5e-5 on the surface: absolute comparison (sdf_outliers: hit rays allowed beyond it -
+                # large samples contain the odd ray whose bisection bracket differs by one sample)
+                assert int(((a[h] - b[h]).abs() >= 2e-4).sum()) <= sdf_outliers, (what, k, (a[h] - b[h]).abs().max().item())
                 assert (a[h] - b[h]).abs().median().item() < 2e-6, (what, k)
             if k == 'sdf_output' and (~h).any():
                 assert (a[~h] - b[~h]).abs().max().item() < 5e-3, (what, k)

@@ -116,7 +116,9 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
         if gref is not None and gref.norm() > 0:
             assert p.grad is not None, name
             worst = max(worst, rel_l2(p.grad, gref))
-            assert rel_l2(p.grad, gref) < (5e-2 if mc_shading else 2e-2), (name, rel_l2(p.grad, gref))
+            # 3 x the worst value measured in round 3 (5.1e-4 / 9.3e-4 / 1.9e-3): a regression of the one-pass fp16
+            # backward or the weight-gradient GEMM no longer hides inside a 5e-2 bound
+            assert rel_l2(p.grad, gref) < {'cfg2': 1.5e-3, 'cfg3': 3e-3, 'cfg4': 6e-3}[wl], (name, rel_l2(p.grad, gref))
     print('[%s] worst parameter-gradient rel-L2 %.2e' % (wl, worst))
     # ---- algorithmic SDF evaluations: tracer counters (primary + secondary traces) = the oracle's evaluation counts
     cnt = m.ray_tracer.counter_sum.cpu().long()

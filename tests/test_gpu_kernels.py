@@ -266,7 +266,9 @@ def test_radiance_and_material_mlp(name, hidden, n, half):
     gradients with their tiny magnitudes carried by nefii_mlp_grad_scale (3e-2: weight-norm's projection amplifies the
     ~1e-3 error of a one-pass GEMM).  'f16': the forward in one pass too (outputs within 1e-3)."""
     from nefii_amd import ops
-    tol_out, tol_grad = {False: (2e-5, 2e-4), 'f16x3': (2e-5, 3e-2), 'f16': (1e-3, 6e-2)}[half]
+    # gradient bounds = ~3 x the worst value measured in round 3 over the five cases (f32 1.0e-6, f16x3 7.7e-4, f16 3.1e-2):
+    # round 2's 3e-2 for the default arithmetic would have hidden a 40-fold regression
+    tol_out, tol_grad = {False: (2e-5, 5e-6), 'f16x3': (2e-5, 2.5e-3), 'f16': (1e-3, 9e-2)}[half]
     mc = syn.model_conf(name, hidden=hidden)
     sd = syn.make_state_dict(mc, seed=1)
     F = mc['feature_vector_size']

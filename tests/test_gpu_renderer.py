@@ -971,3 +971,49 @@ def test_distributed_data_parallel_wraps_the_model_unchanged(tmp_path):
             assert torch.isfinite(g).all(), k
             n_grad += g.abs().sum().item() > 0
     assert n_grad > 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('graph', [False, True])
+def test_nonfinite_step_is_skipped_not_run_on_zero_gradients(graph):
+    """TrainStep's NaN guard on the GPU (fused Adam, `found_inf`): a step whose loss is not finite leaves parameters, both
+    moments and the step counters exactly as they were (reference: the runner stops before backward / step,
+    idr_train.py:754-757), is counted, and the next step trains again - eager and with the tail replayed as a hipGraph."""
+    from nefii_amd.training.step import TrainStep
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=4, bumpy=0.02)
+    lc = syn.loss_conf('physg')
+    lc['idr_rgb_weight'] = 1.0
+    m = build_model(mc, sd, True)
+    st = TrainStep(m, lc, graph=graph, graph_bucket=64, graph_after=2)
+    inp, gt = syn.make_inputs(256, (64, 64), 100.0, (0.2, 0.1, 2.0), -1, seed=31)
+    inp, good = to_dev(inp), {'rgb': gt.to(DEV)}
+    bad = {'rgb': good['rgb'].clone()}
+    bad['rgb'][0, ::7] = float('nan')
+
+    def snapshot():
+        opt_state = []
+        for opt in (st.idr_optimizer, st.sg_optimizer):
+            for p in opt.param_groups[0]['params']:
+                s = opt.state.get(p, {})
+                opt_state.append({k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in s.items()})
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}, opt_state
+
+    for _ in range(4):                      # past graph_after: the captured tail is what replays below
+        st(inp, good)
+    p0, o0 = snapshot()
+    out, lo = st(inp, bad)
+    assert not torch.isfinite(lo['loss']).item()
+    p1, o1 = snapshot()
+    assert int(st.nonfinite_steps.item()) == 1
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    for a, b in zip(o0, o1):
+        for k in a:
+            if torch.is_tensor(a[k]):
+                assert torch.equal(a[k], b[k]), k
+    st(inp, good)
+    p2, _ = snapshot()
+    assert any(not torch.equal(p1[k], p2[k]) for k in p1 if p1[k].dtype.is_floating_point)
+    assert all(torch.isfinite(v).all() for v in p2.values() if v.dtype.is_floating_point)
+    assert int(st.nonfinite_steps.item()) == 1
