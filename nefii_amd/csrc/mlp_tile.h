@@ -1654,316 +1654,6 @@ __device__ __forceinline__ void sdf_tile16s2(const nefii_mlp &m, LdsS2<FT, 16 * 
     }
 }
 
-// ================================================================================================
-// "16s3" (round 3): the single-pass evaluator with its EPILOGUE PIPELINED INTO THE K-LOOPS (512-wide nets, 64-query tiles).
-// In "16s2" a layer is k-loop -> epilogue -> barrier: the two waves of a SIMD share one matrix pipe, the older wave's
-// epilogue hides behind the younger one's k-loop, the younger one's (4.2 k of a 16 k-cycle layer) is exposed, and the
-// matrix pipe is busy 51 % of the time although neither the L2 stream (the tile without its MFMAs: 39.6 us against 60.6)
-// nor the matrix work (32 us) fills the tile.  Here every wave owns two feature tiles in EACH half of the feature space -
-// group a: features [32 w, 32 w + 32), group b: 256 + the same - and a layer's K is split the same way (K1 = image columns
-// [0, 256) = everybody's group a, K2 = [256, 512) = group b), so that a layer is three MFMA blocks
-//     A : all four tiles over K1 (+ the encoding / pad k-steps of the skip layer)   beside the epilogue of the PREVIOUS
-//         layer's group b (its accumulators stay parked in 32 registers)  -> barrier (b columns of this layer's input)
-//     B1: group a's tiles over K2
-//     B2: group b's tiles over K2   beside this layer's group-a epilogue          -> barrier (a columns of the next input)
-// and the only epilogue work outside a k-loop is layer 0's first half and the last hidden layer's second.  The stream
-// ("sp2" copy, nefii_pack_sdf_stream) carries the units in exactly this order: A units = one 32-deep k-step of the four
-// tiles, B units = two k-steps of two tiles; unit counts per layer are those of "16s" (K padded to 128: multiples of the
-// four register stages).  Two activation images as in "16s2": layer l reads image l & 1 and writes the other.
-// ================================================================================================
-__host__ __device__ __forceinline__ int s3_feature(int wave, int j, int r) {
-    return (j < 2 ? 32 * wave + 16 * j : 256 + 32 * wave + 16 * (j - 2)) + r;
-}
-// does the net take the pipelined evaluator?  layer 0 on the encoding alone, every other hidden layer on 512 features
-__host__ __device__ __forceinline__ bool s3_shape(const nefii_mlp &m) {
-    const int NH = m.n_layers - 1;
-    if (NH < 2 || m.layer[0].k_x != 0 || m.layer[0].n_pad != 512) return false;
-    for (int l = 1; l < NH; ++l)
-        if (m.layer[l].k_x != 512 || m.layer[l].n_pad != 512 || (m.layer[l].k_e != 0 && m.layer[l].k_e != 64)) return false;
-    return m.layer[NH].k_x == 512 && m.layer[NH].k_e == 0;
-}
-
-// one epilogue slice: the four values of accumulator tile `av` (feature tile j of the wave, query tile qt) -> bias,
-// softplus, packed halves, one ds_write_b64 into the output image
-__device__ __forceinline__ void s3_slice(const f32x4 &av, const float4v &bs, float k16, _Float16 *dst) {
-    *reinterpret_cast<half4 *>(dst) = softplus100_s16_pk4(av, k16, bs);
-}
-__device__ __forceinline__ float4v s3_bias(int bsrc, int j, int lane) {
-    float4v bs;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        bs[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * j + 4 * (lane >> 4) + k), bsrc));
-    return bs;
-}
-
-// A unit: k-step `s` of all four tiles (stage J); prefetches the stage three units ahead and the activation fragments of
-// k-step `snext` (the next unit's); PAR = which activation buffer holds `s`
-template <int J, int PAR>
-__device__ __forceinline__ void s3_unit_all(SStage<4> (&b)[4], SAct<4> (&a)[2], PCursor &cur, const _Float16 *ah, int snext,
-                                            f32x4 (&acc)[16]) {
-    constexpr int XP = QGeo<4>::XP;
-    sload<4>(b[(J + 3) % 4], cur);
-    sload_a<4, XP>(a[PAR ^ 1], ah, snext);
-#pragma unroll
-    for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-            acc[ft * 4 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[ft], a[PAR].h[qt], acc[ft * 4 + qt], 0, 0, 0);
-}
-// B unit: k-steps s, s + 1 of tiles T0, T0 + 1 (stage J: fragments (s, T0), (s, T0 + 1), (s + 1, T0), (s + 1, T0 + 1));
-// a[0] holds k-step s on entry and k-step s + 2 on exit
-template <int J, int T0>
-__device__ __forceinline__ void s3_unit_pair(SStage<4> (&b)[4], SAct<4> (&a)[2], PCursor &cur, const _Float16 *ah, int s,
-                                             f32x4 (&acc)[16]) {
-    constexpr int XP = QGeo<4>::XP;
-    sload<4>(b[(J + 3) % 4], cur);
-    sload_a<4, XP>(a[1], ah, s + 1);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-            acc[(T0 + t) * 4 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[t], a[0].h[qt], acc[(T0 + t) * 4 + qt], 0, 0, 0);
-    sload_a<4, XP>(a[0], ah, s + 2);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt)
-            acc[(T0 + t) * 4 + qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[2 + t], a[1].h[qt], acc[(T0 + t) * 4 + qt], 0, 0, 0);
-}
-
-// interleave request for a unit that carries epilogue slices: matrix instructions lead, a few VALU / transcendental
-// instructions of the slice behind each (the partner wave of the SIMD does the same: the two then alternate on the pipe)
-#ifndef NEFII_S3_MIXMODE
-#define NEFII_S3_MIXMODE 1
-#endif
-#if NEFII_S3_MIXMODE == 0          /* the compiler's own order */
-#define NEFII_S3_MIX(n_mfma, valu_per)
-#elif NEFII_S3_MIXMODE == 2        /* two matrix instructions per group */
-#define NEFII_S3_MIX(n_mfma, valu_per)                                                            \
-    _Pragma("unroll") for (int _i = 0; _i < (n_mfma) / 2; ++_i) {                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, 2 * (valu_per), 0);                   \
-    }
-#elif NEFII_S3_MIXMODE == 3        /* the slice first, then the matrix instructions back to back */
-#define NEFII_S3_MIX(n_mfma, valu_per)                                                            \
-    __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, (n_mfma) * (valu_per), 0);                \
-    __builtin_amdgcn_sched_group_barrier(0x008, (n_mfma), 0);
-#else
-#define NEFII_S3_MIX(n_mfma, valu_per)                                                            \
-    _Pragma("unroll") for (int _i = 0; _i < (n_mfma); ++_i) {                                     \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                        \
-        __builtin_amdgcn_sched_group_barrier(0x002 | 0x400, (valu_per), 0);                       \
-    }
-#endif
-
-template <int QT>
-__device__ __forceinline__ void sdf_tile16s3(const nefii_mlp &m, LdsS2<4, 16 * QT> &lds, float *raw, float *const *dest,
-                                             SStage<4> (&b)[4], PCursor &cur) {
-    static_assert(QT == 4, "64-query tiles");
-    constexpr int NW = 8, RT = 2, XP = QGeo<4>::XP, EP = QGeo<4>::HW, EW = QGeo<4>::EW, RMAX = 16 * QT;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int NH = m.n_layers - 1;
-    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
-    const float k16 = inv_scale * A16_SCALE;
-    const int boff = s3_feature(wave, lane >> 4, lane & 15);
-    float bnext = m.layer[0].bias[boff];        // biases run one layer ahead (see sdf_tile16q)
-    {
-        const int w0 = enc_width(m.enc_freqs[0]);
-        for (int i = threadIdx.x; i < RMAX * EW; i += 512) {
-            const int p = i / EW, c = i - p * EW;
-            const _Float16 v = (_Float16)((c < w0 ? enc_value(raw + p * 9, c) : 0.f) * A16_SCALE);
-            lds.X[0][p * XP + EP + c] = v;
-            lds.X[1][p * XP + EP + c] = v;
-        }
-    }
-    __syncthreads();
-    const int qoff = (lane & 15) * XP + 8 * (lane >> 4);
-    // where this lane's four values of (tile j, query tile qt) go in an image: row 16 qt + (lane & 15), column
-    // s3_feature(wave, j, 4 (lane >> 4))
-    const int soff = (lane & 15) * XP + 4 * (lane >> 4);
-    const int col_a = 32 * wave, col_b = 256 + 32 * wave;
-    f32x4 acc[16], pend[8];
-    float bprev = 0.f;
-    // ---------------- layer 0: the encoding columns only, no pipelining ahead of it
-    {
-        const nefii_layer &L = m.layer[0];
-        const int units = s_units(L);
-        const _Float16 *ah = lds.X[0] + qoff + EP;
-        const float *bp = m.layer[1].bias + boff;
-        asm volatile("" ::"s"(units), "v"(ah), "v"(bp));
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        __builtin_amdgcn_sched_barrier(0);
-        const float bvec = bnext;
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
-        SAct<4> a[2];
-        sload_a<4, XP>(a[0], ah, 0);
-        for (int s = 0; s < units; s += 4) {
-            s3_unit_all<0, 0>(b, a, cur, ah, s + 1, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            s3_unit_all<1, 1>(b, a, cur, ah, s + 2, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            s3_unit_all<2, 0>(b, a, cur, ah, s + 3, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            s3_unit_all<3, 1>(b, a, cur, ah, s + 4, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        bnext = *bp;
-        __builtin_amdgcn_sched_barrier(0);
-        const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
-        _Float16 *xo = lds.X[1] + soff;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const float4v bs = s3_bias(bsrc, j, lane);
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) s3_slice(acc[j * 4 + qt], bs, k16, xo + 16 * qt * XP + col_a + 16 * j);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pend[j] = acc[8 + j];
-        bprev = bvec;
-        __syncthreads();
-    }
-    // ---------------- layers 1 .. NH-1
-    for (int l = 1; l < NH; ++l) {
-        const nefii_layer &L = m.layer[l];
-        const bool skip = L.k_e != 0;
-        const _Float16 *ah = lds.X[l & 1] + qoff;                   // k_x = 512: column 0
-        _Float16 *xin = lds.X[l & 1] + soff;                        // the previous layer's group b lands in THIS layer's input
-        _Float16 *xo = lds.X[(l & 1) ^ 1] + soff;
-        const float *bp = m.layer[l + 1 < NH ? l + 1 : l].bias + boff;
-        asm volatile("" ::"v"(ah), "v"(xin), "v"(xo), "v"(bp));
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        __builtin_amdgcn_sched_barrier(0);
-        const float bvec = bnext;
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
-        SAct<4> a[2];
-        const int pb = __builtin_bit_cast(int, bprev * A16_SCALE);
-        NEFII_STAMP(0);
-        // ---- block A: K1 (and the skip layer's encoding / pad k-steps first) beside the previous layer's group-b epilogue
-        if (skip) {
-            sload_a<4, XP>(a[0], ah, 16);
-            s3_unit_all<0, 0>(b, a, cur, ah, 17, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            s3_unit_all<1, 1>(b, a, cur, ah, 18, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            s3_unit_all<2, 0>(b, a, cur, ah, 19, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            s3_unit_all<3, 1>(b, a, cur, ah, 0, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            sload_a<4, XP>(a[0], ah, 0);
-        }
-        {
-            const float4v bs2 = s3_bias(pb, 2, lane), bs3 = s3_bias(pb, 3, lane);
-#define NEFII_S3_A(J, PAR, S, TILE, QTI, BS)                                                                     \
-    s3_unit_all<J, PAR>(b, a, cur, ah, (S) + 1, acc);                                                            \
-    s3_slice(pend[((TILE) - 2) * 4 + (QTI)], BS, k16, xin + 16 * (QTI) * XP + col_b + 16 * ((TILE) - 2));        \
-    NEFII_S3_MIX(16, 3)                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);
-            NEFII_S3_A(0, 0, 0, 2, 0, bs2)
-            NEFII_S3_A(1, 1, 1, 2, 1, bs2)
-            NEFII_S3_A(2, 0, 2, 2, 2, bs2)
-            NEFII_S3_A(3, 1, 3, 2, 3, bs2)
-            NEFII_S3_A(0, 0, 4, 3, 0, bs3)
-            NEFII_S3_A(1, 1, 5, 3, 1, bs3)
-            NEFII_S3_A(2, 0, 6, 3, 2, bs3)
-            NEFII_S3_A(3, 1, 7, 3, 3, bs3)
-#undef NEFII_S3_A
-        }
-        bnext = *bp;
-        NEFII_STAMP(1);
-        __syncthreads();                // the previous layer's group b is in place: K2 may be read
-        NEFII_STAMP(2);
-        // ---- block B1: group a over K2 (read k-step 8 NOW: what the last A unit prefetched predates the barrier)
-        sload_a<4, XP>(a[0], ah, 8);
-        s3_unit_pair<0, 0>(b, a, cur, ah, 8, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        s3_unit_pair<1, 0>(b, a, cur, ah, 10, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        s3_unit_pair<2, 0>(b, a, cur, ah, 12, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        s3_unit_pair<3, 0>(b, a, cur, ah, 14, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        NEFII_STAMP(3);
-        // ---- block B2: group b over K2 beside this layer's group-a epilogue
-        {
-            const int cb = __builtin_bit_cast(int, bvec * A16_SCALE);
-            const float4v bs0 = s3_bias(cb, 0, lane), bs1 = s3_bias(cb, 1, lane);
-            // (k-steps 8 .. 15 again: a[0] must hold k-step 8 - B1's last unit left k-step 16 there)
-            sload_a<4, XP>(a[0], ah, 8);
-#define NEFII_S3_B(J, S, TILE, BS)                                                                               \
-    s3_unit_pair<J, 2>(b, a, cur, ah, S, acc);                                                                   \
-    s3_slice(acc[(TILE) * 4 + 0 + 2 * (((S) >> 1) & 1)], BS, k16, xo + 16 * (0 + 2 * (((S) >> 1) & 1)) * XP + col_a + 16 * (TILE)); \
-    s3_slice(acc[(TILE) * 4 + 1 + 2 * (((S) >> 1) & 1)], BS, k16, xo + 16 * (1 + 2 * (((S) >> 1) & 1)) * XP + col_a + 16 * (TILE)); \
-    NEFII_S3_MIX(16, 5)                                                                                          \
-    __builtin_amdgcn_sched_barrier(0);
-            NEFII_S3_B(0, 8, 0, bs0)        // tile 0, query tiles 0, 1
-            NEFII_S3_B(1, 10, 0, bs0)       // tile 0, query tiles 2, 3
-            NEFII_S3_B(2, 12, 1, bs1)       // tile 1, query tiles 0, 1
-            NEFII_S3_B(3, 14, 1, bs1)       // tile 1, query tiles 2, 3
-#undef NEFII_S3_B
-        }
-        NEFII_STAMP(4);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pend[j] = acc[8 + j];
-        bprev = bvec;
-        __syncthreads();                // group a of this layer is in place: the next layer's K1
-    }
-    // ---------------- the last hidden layer's group b (nothing left to hide it behind)
-    {
-        const int pb = __builtin_bit_cast(int, bprev * A16_SCALE);
-        _Float16 *xin = lds.X[NH & 1] + soff;
-#pragma unroll
-        for (int j = 2; j < 4; ++j) {
-            const float4v bs = s3_bias(pb, j, lane);
-#pragma unroll
-            for (int qt = 0; qt < 4; ++qt) s3_slice(pend[(j - 2) * 4 + qt], bs, k16, xin + 16 * qt * XP + col_b + 16 * (j - 2));
-        }
-        __syncthreads();
-    }
-    // last layer, column 0 only: hi fragments of the layer's own w_f16x3 (32x32x16), K split over the waves
-    {
-        const int r = lane & 31, h = lane >> 5;
-        const nefii_layer &L = m.layer[NH];
-        const int NT = L.n_pad >> 5;
-        const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
-        const _Float16 *ah = lds.X[NH & 1] + r * XP + 8 * h + (EP - L.k_x);
-        const int ksw = (L.k_x >> 4) / NW;
-        f32x16 acc2[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
-        for (int u = 0; u < ksw; ++u) {
-            const int s = wave * ksw + u;
-            const half8 wh = wl[(size_t)s * NT * 128];
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                const half8 xh8 = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP + 16 * s);
-                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh8, acc2[rt], 0, 0, 0);
-            }
-        }
-        if (h == 0) {
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) raw[wave * RMAX + 32 * rt + r] = acc2[rt][0];
-        }
-        __syncthreads();
-        if (threadIdx.x < 16 * QT) {
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) sum += raw[w * RMAX + threadIdx.x];
-            float *d = dest[threadIdx.x];
-            if (d) *d = sum * inv_scale + L.bias[0];
-        }
-        __syncthreads();
-    }
-}
-
 // accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
 #define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \

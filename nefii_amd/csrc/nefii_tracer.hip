@@ -935,67 +935,6 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, cons
     }
 }
 
-// the pipelined single-pass evaluator (mlp_tile.h "16s3"): its own copy of the stream (sp2_off: half8 offset, G units)
-__device__ __forceinline__ void prime16s3(const nefii_mlp &m, SStage<4> (&b)[4], PCursor &cur, size_t sp2_off, int G) {
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    cur.bytes = (unsigned)G * 4096;
-    cur.base = reinterpret_cast<const half8 *>(m.w_stream) + sp2_off + (size_t)wave * G * 256 + lane;
-    cur.off = 0;
-#pragma unroll
-    for (int u = 0; u < 3; ++u) sload<4>(b[u], cur);
-}
-
-__global__ __launch_bounds__(512, 2) void eval_kernel16s3(Params P, nefii_mlp m, int round, size_t sp2_off, int G) {
-    NEFII_CLAIM_SIMD_2();
-    constexpr int ROWS = 64;
-    __shared__ LdsS2<4, ROWS> lds;
-    __shared__ float raw[ROWS * 9];
-    __shared__ float *dest[ROWS];
-    const int64_t total = (int64_t)P.counters[round * NCNT + 5] * P.p.n_steps;
-    const int64_t n_tiles = (total + ROWS - 1) / ROWS;
-    if (blockIdx.x >= n_tiles) return;
-    zero_lds_any(lds);
-    SStage<4> b[4];
-    PCursor cur;
-    prime16s3(m, b, cur, sp2_off, G);
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile_coarse<ROWS>(P, tile, total, raw, dest);
-        __syncthreads();
-        sdf_tile16s3<4>(m, lds, raw, dest, b, cur);
-    }
-}
-
-__global__ __launch_bounds__(512, 2) void sdf_points_kernel16s3(nefii_mlp m, const float *__restrict__ x, int64_t n,
-                                                               float *__restrict__ out, size_t sp2_off, int G) {
-    NEFII_CLAIM_SIMD_2();
-    constexpr int ROWS = 64;
-    __shared__ LdsS2<4, ROWS> lds;
-    __shared__ float raw[ROWS * 9];
-    __shared__ float *dest[ROWS];
-    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
-    zero_lds_any(lds);
-    SStage<4> b[4];
-    PCursor cur;
-    prime16s3(m, b, cur, sp2_off, G);
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int tid = threadIdx.x;
-        if (tid < ROWS) {
-            const int64_t q = tile * ROWS + tid;
-            float *rw = raw + tid * 9;
-            const bool live = q < n;
-            rw[0] = live ? x[q * 3] : 0.f, rw[1] = live ? x[q * 3 + 1] : 0.f, rw[2] = live ? x[q * 3 + 2] : 0.f;
-            rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
-            dest[tid] = live ? out + q : nullptr;
-        }
-        __syncthreads();
-        sdf_tile16s3<4>(m, lds, raw, dest, b, cur);
-#ifdef NEFII_STAMPS
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_stamp_tile = g_stamp_tile + 1;
-        __syncthreads();
-#endif
-    }
-}
-
 template <int FT>
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16q(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
@@ -1167,44 +1106,6 @@ int stream_steps_sp(const nefii_mlp *m) {
     int G = 0;
     for (int l = 0; l < m->n_layers - 1; ++l) G += s_units(m->layer[l]);
     return G;
-}
-
-// fifth copy ("sp2", behind the value + gradient copy): the single-pass stream in the order the PIPELINED evaluator consumes
-// it (mlp_tile.h "16s3"; 512-wide nets of s3_shape()).  Same unit count per layer as the third copy.  Layer 0: unit s =
-// k-step s of the wave's four tiles.  Layers with 512 hidden inputs: first the k-steps past column 512 (skip layer:
-// encoding + pad, 4 units), then k-steps 0..7 - four tiles each - then for tile pair (0, 1) and again for (2, 3) four
-// units of two k-steps: (8 + 2 j, T0), (8 + 2 j, T0 + 1), (9 + 2 j, T0), (9 + 2 j, T0 + 1).  Tile j of wave w holds the
-// features s3_feature(w, j, 0..15).
-int stream_steps_sp2(const nefii_mlp *m) {
-    if (shape16p(m) != 4 || m->reserved != 1 || !s3_shape(*m)) return 0;
-    return stream_steps_sp(m);
-}
-__global__ void pack_sdf_stream_sp2_kernel(nefii_mlp m, half8 *__restrict__ dst, int G) {
-    const int g = blockIdx.x, wave = blockIdx.y;
-    int l = 0, u = g;
-    while (u >= s_units(m.layer[l])) u -= s_units(m.layer[l]), ++l;
-    const nefii_layer &L = m.layer[l];
-    const int frag = threadIdx.x >> 6, lane = threadIdx.x & 63, kg = lane >> 4;
-    int s, tile;                                    // 32-deep k-step and tile of this fragment
-    if (L.k_x == 0) {
-        s = u, tile = frag;
-    } else {
-        const int nE = s_units(L) - 16;             // k-steps past the 512 hidden columns
-        if (u < nE) s = 16 + u, tile = frag;
-        else if (u < nE + 8) s = u - nE, tile = frag;
-        else {
-            const int v = u - nE - 8, pair = v >> 2, j = v & 3;
-            s = 8 + 2 * j + (frag >> 1), tile = 2 * pair + (frag & 1);
-        }
-    }
-    const half8 *w = reinterpret_cast<const half8 *>(L.w_f16x3);
-    const int n = s3_feature(wave, tile, lane & 15);
-    const int s16 = 2 * s + (kg >> 1), t = n >> 5, lane_src = (n & 31) + 32 * (kg & 1);
-    const int NT = L.n_pad >> 5;
-    half8 v;
-    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
-    if (s16 < ((L.k_x + L.k_e) >> 4)) v = w[(((size_t)s16 * NT + t) * 2) * 64 + lane_src];
-    dst[((size_t)wave * G + g) * 256 + threadIdx.x] = v;
 }
 
 // ---- fourth copy: the value + gradient kernel's stream (sdf_value_grad16q_kernel) ------------------------------------------
@@ -1703,16 +1604,12 @@ extern "C" int nefii_trace_profile_launches(float *h_ms, int cap) {
     return n;
 }
 
-// half8 offset of the fifth copy in w_stream (behind the value + gradient copy)
-size_t sp2_stream_offset(const nefii_mlp *m) {
-    size_t units_vg = 0;
-    if (vg_shape(m)) units_vg = (size_t)stream_steps(m) + vg_units_bwd(m);
-    return vg_stream_offset(m) + (size_t)8 * units_vg * 256;
-}
-
 extern "C" size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf) {
     if (!h_sdf || h_sdf->n_layers < 2 || h_sdf->n_layers > NEFII_MAX_LAYERS || !shape16p(h_sdf)) return 0;
-    return (sp2_stream_offset(h_sdf) + (size_t)8 * stream_steps_sp2(h_sdf) * 256) * sizeof(half8);
+    size_t units_vg = 0;
+    if (vg_shape(h_sdf)) units_vg = (size_t)stream_steps(h_sdf) + vg_units_bwd(h_sdf);
+    return (size_t)8 * (stream_steps(h_sdf) + stream_steps8(h_sdf) + units_vg) * 256 * sizeof(half8) +
+           (size_t)8 * stream_steps_sp(h_sdf) * shape16p(h_sdf) * 64 * sizeof(half8);
 }
 
 extern "C" int nefii_sdf_coarse_supported(const nefii_mlp *h_sdf) {
@@ -1748,11 +1645,6 @@ extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, voi
         hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, ft, 0);
         HIP_CHECK_LAUNCH();
         hipLaunchKernelGGL(pack_sdf_stream_bwd_kernel, dim3(Gb, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, G, ft);
-        HIP_CHECK_LAUNCH();
-    }
-    if (const int G2 = stream_steps_sp2(h_sdf)) {
-        hipLaunchKernelGGL(pack_sdf_stream_sp2_kernel, dim3(G2, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf,
-                           (half8 *)w_stream + sp2_stream_offset(h_sdf), G2);
         HIP_CHECK_LAUNCH();
     }
     return 0;
@@ -1827,15 +1719,6 @@ static int coarse_rows(int ft) {
             hipLaunchKernelGGL((KERNEL<8, 4, false>), grid, dim3(512), 0, st, __VA_ARGS__);                         \
     } while (0)
 
-// NEFII_COARSE_PIPE=0: the single-pass evaluator without the pipelined epilogue ("16s2": A/B measurements)
-static bool coarse_pipe(const nefii_mlp *m) {
-    static const bool on = [] {
-        const char *e = getenv("NEFII_COARSE_PIPE");
-        return !(e && atoi(e) == 0);
-    }();
-    return on && coarse_qt() == 0 && stream_steps_sp2(m) > 0;
-}
-
 extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream) {
     if (!h_sdf || h_sdf->n_layers < 1 || h_sdf->n_layers > NEFII_MAX_LAYERS) return NEFII_E_ARG;
     if (!nefii_sdf_coarse_supported(h_sdf)) return NEFII_E_UNSUPPORTED;
@@ -1848,11 +1731,7 @@ extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int
     const int rows = coarse_rows(ft);
     const int64_t n_tiles = (n + rows - 1) / rows;
     const dim3 grid((int)(n_tiles < 512 ? n_tiles : 512));
-    if (coarse_pipe(h_sdf))
-        hipLaunchKernelGGL(sdf_points_kernel16s3, grid, dim3(512), 0, (hipStream_t)stream, *h_sdf, x, n, sdf_out,
-                           sp2_stream_offset(h_sdf), stream_steps_sp2(h_sdf));
-    else
-        NEFII_COARSE_LAUNCH(sdf_points_kernel16s, ft, grid, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    NEFII_COARSE_LAUNCH(sdf_points_kernel16s, ft, grid, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
     HIP_CHECK_LAUNCH();
     return 0;
 }
@@ -2042,11 +1921,7 @@ int launch_round(const TraceJob &J, int r, bool profile) {
             const int ft = J.pipelined == 2 ? 2 : 4, rows = coarse_rows(ft);
             const int64_t t = (J.P.n * (int64_t)J.P.p.n_steps + rows - 1) / rows;
             const dim3 grid((int)(t < J.eval_blocks_w ? t : J.eval_blocks_w));
-            if (ft == 4 && coarse_pipe(J.sdf))
-                hipLaunchKernelGGL(eval_kernel16s3, grid, dim3(512), 0, st, J.P, *J.sdf, r, sp2_stream_offset(J.sdf),
-                                   stream_steps_sp2(J.sdf));
-            else
-                NEFII_COARSE_LAUNCH(eval_kernel16s, ft, grid, st, J.P, *J.sdf, r);
+            NEFII_COARSE_LAUNCH(eval_kernel16s, ft, grid, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();
         }
         if (profile) (void)hipEventRecord(e1, st);
