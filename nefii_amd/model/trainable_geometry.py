@@ -10,8 +10,9 @@ kernels of the frozen path deliberately are not.  What runs where:
     tracer re-packs the SDF weights whenever they changed);
   * the SDF network, its input gradient (create_graph), SampleNetwork, the radiance and material MLPs and the
     closed-form SG shading are torch ops on the GPU (autograd owns the second-order graph);
-  * render types other than 'sg' are refused here (their Monte-Carlo shading has no input-differentiable form in this
-    package).
+  * the Monte-Carlo render type (pt_render_indirect_mlp, round 3): sampler and secondary trace on the HIP kernels under
+    no_grad, everything that carries a gradient - the SDF value of the light points, the radiance at secondary hits,
+    the light sum and the MIS shading sum - as torch ops (mc_render_torch).
 
 Pinned by a reference-generated fixture (tests/golden/make_golden.py:golden_trainable_geometry): outputs, grad_theta,
 all loss terms incl. the eikonal one, and the gradients of every parameter - the SDF network's included."""
@@ -199,6 +200,76 @@ def render_with_sg_torch(lgtSGs, specular_reflectance, roughness, diffuse_albedo
             'sg_diffuse_albedo': diffuse_albedo}
 
 
+# ---- Monte-Carlo direct + near-field indirect shading (path_tracing_render.py:1265-1487, diff_geo=False) -----------------
+def _light_along(lgt, wi):
+    """sum of the light SGs along directions wi [n, 3] (:1406-1414)"""
+    axis = lgt[:, :3] / (torch.norm(lgt[:, :3], dim=-1, keepdim=True) + TINY_NUMBER)
+    lam, mu = torch.abs(lgt[:, 3:4]), torch.abs(lgt[:, -3:])
+    dots = wi @ axis.t()                                                        # [n, M]
+    return torch.exp(lam.reshape(1, -1) * (dots - 1.0)) @ mu
+
+
+def mc_render_torch(model, mat, normals, view_dirs, points):
+    """pt_render_indirect_mlp with every input differentiable: the sampler (nefii_mis_sample) and the secondary trace (the
+    HIP tracer) run under no_grad as in the reference (:1283-1354); the SDF value of ALL light points (:2112: its feature
+    columns feed the radiance network at the secondary hits, attached to the SDF weights), the normals there
+    (gradient(no_grad=True): detached), the radiance network, the light sum and the three-sample MIS sum are torch ops."""
+    from .. import ops
+    from .path_tracing_render import draw_uniforms
+    net = model.implicit_network
+    lgt, spec = mat['sg_lgtSGs'], mat['sg_specular_reflectance']
+    albedo = mat['sg_diffuse_albedo']
+    n = normals.shape[0]
+    dev = normals.device
+    rough = mat['sg_roughness'].expand(n, 1)
+    with torch.no_grad():
+        uniforms = getattr(model, 'uniforms_override', None)
+        uniforms = draw_uniforms(n, dev) if uniforms is None else uniforms.to(dev)
+        wi, own, tab = ops.mis_sample(lgt, rough, normals, view_dirs, uniforms)      # [3,n,3], [3,n], [3,n,3]
+        origins = points.detach().unsqueeze(0).expand(3, n, 3).reshape(-1, 3)
+        sec_pts, sec_hit, sec_dist = model.ray_tracer(sdf=net, cam_loc=origins,
+                                                      object_mask=torch.ones(3 * n, dtype=torch.bool, device=dev),
+                                                      ray_directions=wi.reshape(-1, 1, 3))
+        hidx = torch.nonzero(sec_hit).flatten()
+    light_out = sdf_torch(net, sec_pts)                                         # (:2112) all 3 n light points, with grad
+    indirect = torch.zeros(3 * n, 3, device=dev)
+    if hidx.numel() > 0:
+        lp = sec_pts.index_select(0, hidx)
+        g = sdf_gradient_torch(net, lp.clone(), create_graph=False)[:, 0, :].detach()
+        nrm = g / (torch.norm(g, dim=-1, keepdim=True) + 1e-6)
+        vd = -wi.reshape(-1, 3).index_select(0, hidx)
+        vd = vd / (torch.norm(vd, dim=-1, keepdim=True) + 1e-6)
+        feats = light_out.index_select(0, hidx)[:, 1:] if model.feature_vector_size > 0 else None
+        indirect = indirect.index_put((hidx,), radiance_torch(model.rendering_network, lp, nrm, vd, feats))
+    vis = (1.0 - sec_hit.to(torch.float32)).reshape(3, n, 1)
+    indirect = indirect.reshape(3, n, 3)
+    spec_rgb, diff_rgb = 0.0, 0.0
+    r4 = (rough * rough) * (rough * rough)
+    for i in range(3):
+        w = wi[i]
+        light = _light_along(lgt, w)
+        half = w + view_dirs
+        half = half / (torch.norm(half, dim=-1, keepdim=True) + TINY_NUMBER)
+        n_h = torch.clamp(torch.sum(normals * half, dim=-1, keepdim=True), min=0.0)
+        root = n_h * n_h + (1.0 - n_h * n_h) / r4
+        D = 1.0 / (math.pi * r4 * root * root)
+        v_h = torch.clamp(torch.sum(view_dirs * half, dim=-1, keepdim=True), min=0.0)
+        fres = spec + (1.0 - spec) * torch.pow(2.0, -(5.55473 * v_h + 6.8316) * v_h)
+        d1 = torch.clamp(torch.sum(view_dirs * normals, dim=-1, keepdim=True), min=0.0)
+        d2 = torch.clamp(torch.sum(w * normals, dim=-1, keepdim=True), min=0.0)
+        k = (rough + 1.0) * (rough + 1.0) / 8.0
+        G = (d1 / (d1 * (1 - k) + k + TINY_NUMBER)) * (d2 / (d2 * (1 - k) + k + TINY_NUMBER))
+        fs = fres * D * G / (4 * d1 * d2 + TINY_NUMBER)
+        pdf = own[i].unsqueeze(-1)
+        weight = pdf * pdf / torch.clamp((tab[i] * tab[i]).sum(-1, keepdim=True), min=TINY_NUMBER)   # power heuristic (:390-401)
+        l_all = light * vis[i] + (1.0 - vis[i]) * indirect[i]
+        spec_rgb = spec_rgb + torch.clamp(weight * l_all * fs * d2 / pdf, min=0.0)
+        diff_rgb = diff_rgb + torch.clamp(weight * l_all * (albedo / math.pi) * d2 / pdf, min=0.0)
+    return {'sg_rgb': spec_rgb + diff_rgb, 'sg_specular_rgb': spec_rgb, 'sg_diffuse_rgb': diff_rgb,
+            'sg_diffuse_albedo': albedo, 'secondary_points': sec_pts.reshape(3, n, 3),
+            'secondary_mask': sec_hit.reshape(3, n, 1), 'secondary_dir': wi}
+
+
 def get_rgb_value(model, points, view_dirs):
     """IDRNetwork.get_rbg_value (:529-599) with geometry trainable: three SDF passes like the reference (features,
     gradient with create_graph), torch radiance / material networks, torch closed-form shading."""
@@ -212,8 +283,11 @@ def get_rgb_value(model, points, view_dirs):
     ret = {'normals': normals,
            'idr_rgb': radiance_torch(model.rendering_network, points, normals, view_dirs, feats)}
     mat = material_torch(model.envmap_material_network, points, feats)
-    ret.update(render_with_sg_torch(mat['sg_lgtSGs'], mat['sg_specular_reflectance'], mat['sg_roughness'],
-                                    mat['sg_diffuse_albedo'], normals, view_dirs))
+    if model.render_type == 'sg':
+        ret.update(render_with_sg_torch(mat['sg_lgtSGs'], mat['sg_specular_reflectance'], mat['sg_roughness'],
+                                        mat['sg_diffuse_albedo'], normals, view_dirs))
+    else:
+        ret.update(mc_render_torch(model, mat, normals, view_dirs, points))
     ret.update({'sg_roughness': mat['sg_roughness'], 'sg_specular_reflectance': mat['sg_specular_reflectance']})
     return ret
 
@@ -221,9 +295,8 @@ def get_rgb_value(model, points, view_dirs):
 def forward_with_uv(model, input):
     """forward_with_uv (:312-501) when `model.training and not model.state_freeze_geo`."""
     from ..utils import rend_util
-    if model.render_type != 'sg':
-        raise NotImplementedError('trainable geometry (torch slow path) is built for render_type "sg"; the Monte-Carlo '
-                                  'shading of %r has no input-differentiable form here - freeze_geometry()' % model.render_type)
+    if model.render_type not in ('sg', 'pt_render_indirect_mlp', 'pt_render_indirect_mlp_memsave'):
+        raise NotImplementedError('trainable geometry (torch slow path): render_type %r' % model.render_type)
     uv = input['uv']
     object_mask = input['object_mask'].reshape(-1)
     multi = None
@@ -285,8 +358,10 @@ def forward_with_uv(model, input):
             bg = model.get_background_rgb(ray_dirs.index_select(0, bidx))
             out['sg_rgb_values'] = out['sg_rgb_values'].index_put((bidx,), bg)
     output = {'points': points, 'sdf_output': sdf_output, 'network_object_mask': network_object_mask,
-              'object_mask': object_mask, 'grad_theta': grad_theta, 'secondary_points': None, 'secondary_mask': None,
-              'secondary_dir': None}
+              'object_mask': object_mask, 'grad_theta': grad_theta,
+              'secondary_points': ret.get('secondary_points') if N > 0 else None,
+              'secondary_mask': ret.get('secondary_mask') if N > 0 else None,
+              'secondary_dir': ret.get('secondary_dir') if N > 0 else None}
     output.update(out)
     if multi is not None:
         B, S, R = multi

@@ -227,6 +227,7 @@ def run_forward(m, inp, train, seed):
     finally:
         hook.remove()
     cap.ray_hit = traces[0][1] if traces else None      # per-RAY hit mask (the output dict only has the per-pixel `all`)
+    cap.traces = traces
     return out, cap
 
 
@@ -352,9 +353,53 @@ def golden_trainable_geometry():
              in_object_mask=inp['object_mask'], rgb_gt=gt, **rec)
 
 
+def golden_trainable_geometry_mc():
+    """The same branch with the Monte-Carlo render type (conf.conf's pt_render_indirect_mlp, diff_geo=False): sampler draws,
+    secondary trace, indirect radiance at secondary hits whose FEATURES stay attached to the SDF network
+    (path_tracing_render.py:2109-2166), MIS shading differentiable with respect to the trainable normals."""
+    mc = syn.model_conf('conf', hidden=64)
+    sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
+    lc = syn.loss_conf('conf')
+    m = build_ref(mc, sd, freeze=False)
+    inp, gt = syn.make_inputs(48, image_hw=(64, 64), focal=100.0, cam_pos=(0.2, 0.1, 2.0), num_rays=2, seed=6, mask_all=False)
+    out, cap = run_forward(m, inp, True, 43)
+    assert out['grad_theta'] is not None and len(cap.rand) == 7 and len(cap.traces) == 2
+    rec = {k: v for k, v in out.items() if v is not None}
+    rec['ray_hit'] = cap.ray_hit
+    # uniform_ draws ahead of the sampler: [primary min-SDF steps (if any ray needed them)], eikonal points; behind it:
+    # [secondary min-SDF steps]
+    rec['eikonal_points'] = cap.unif_pre[-1]
+    if len(cap.unif_pre) == 2:
+        rec['minsdf_steps'] = cap.unif_pre[0]
+    if cap.unif_post:
+        rec['minsdf_steps2'] = cap.unif_post[0]
+    rec['uniforms'] = torch.cat([r.reshape(-1, 1) for r in cap.rand], dim=1)
+    rec['sec_points'], rec['sec_hit'], rec['sec_dists'] = cap.traces[1]
+    rec['prim_points'], _, rec['prim_dists'] = cap.traces[0]         # per RAY (`points` is the per-pixel mean)
+    with contextlib.redirect_stdout(io.StringIO()):
+        lossf = IDRLoss(**lc)
+    lo = lossf(out, {'rgb': gt})
+    m.zero_grad()
+    lo['loss'].backward()
+    for k, v in lo.items():
+        rec['loss.' + k] = v
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            rec['gnorm.' + k] = p.grad.norm()
+            if p.numel() <= 4096:
+                rec['grad.' + k] = p.grad.clone()
+    assert any(k.startswith('gnorm.implicit_network') and v > 0 for k, v in rec.items())
+    save('forward_trainable_conf_mc', uv=inp['uv'], pose=inp['pose'], intrinsics=inp['intrinsics'],
+         in_object_mask=inp['object_mask'], rgb_gt=gt, **rec)
+
+
 if __name__ == '__main__':
     if sys.argv[1:] == ['trainable']:
         golden_trainable_geometry()
+        golden_trainable_geometry_mc()
+        sys.exit(0)
+    if sys.argv[1:] == ['trainable_mc']:
+        golden_trainable_geometry_mc()
         sys.exit(0)
     if sys.argv[1:] == ['full_width']:
         golden_forward_full_width()
@@ -371,3 +416,4 @@ if __name__ == '__main__':
     golden_forward_and_step()
     golden_forward_full_width()
     golden_trainable_geometry()
+    golden_trainable_geometry_mc()

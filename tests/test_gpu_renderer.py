@@ -151,7 +151,7 @@ def test_state_dict_roundtrip_and_eval_mode():
         assert torch.equal(o1[k], o2[k]), k      # deterministic (no atomics on the forward path)
 
 
-@pytest.mark.parametrize('tag', ['physg', 'physg_multi'])
+@pytest.mark.parametrize('tag', ['physg', 'physg_multi', 'conf_mc'])
 def test_trainable_geometry_golden(golden, tag):
     """geometry NOT frozen (implicit_differentiable_renderer.py:357-393, SampleNetwork,
     eikonal points, grad_theta) - HIP camera rays and tracer in front of the torch slow path
@@ -161,55 +161,75 @@ def test_trainable_geometry_golden(golden, tag):
     from nefii_amd.model.loss import IDRLoss
     from nefii_amd.training.step import TrainStep
     g = golden('forward_trainable_' + tag)
-    mc = syn.model_conf('physg', hidden=64)
+    mcs = tag == 'conf_mc'        # the Monte-Carlo render type (pt_render_indirect_mlp) on the same branch, round 3
+    name = 'conf' if mcs else 'physg'
+    mc = syn.model_conf(name, hidden=64)
     sd = syn.make_state_dict(mc, seed=0, bumpy=0.02)
     m = IDRNetwork(conf.from_dict(mc))
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).train()
-    m.ray_tracer.minsdf_steps_override = g['minsdf_steps']
+    zeros = torch.zeros(100)
+    m.ray_tracer.minsdf_steps_override = [g.get('minsdf_steps', zeros), g.get('minsdf_steps2', zeros)] if mcs else g['minsdf_steps']
     m.eikonal_points_override = g['eikonal_points']
     inp = to_dev({'uv': g['uv'], 'pose': g['pose'], 'intrinsics': g['intrinsics'], 'object_mask': g['in_object_mask']})
+    if mcs:
+        m.uniforms_override = g['uniforms'].to(DEV)
     out = m(inp)
     flips = (out['network_object_mask'].cpu() != g['network_object_mask']).sum().item()
     assert flips <= 1, flips
     agree = out['network_object_mask'].cpu() == g['network_object_mask']
     hit = g['network_object_mask'] & agree
+    mc_keys = ('sg_rgb_values', 'sg_diffuse_rgb_values', 'sg_specular_rgb_values')
+    if mcs:
+        # pixels containing a ray whose sampled direction or secondary hit flag differs DISCRETELY from the reference's
+        # (tests/parity.py: a lobe pick at a CDF boundary, a grazing re-hit) are compared apart - counted and bounded
+        assert torch.equal(m.last_ray_hit.cpu(), g['ray_hit'])
+        from parity import mc_flagged_rays
+        flagged, n_dir, n_vis = mc_flagged_rays(out, g, m.last_ray_hit, g['ray_hit'])
+        R = g['uv'].shape[2] if g['uv'].dim() == 4 else 1
+        flagged_px = flagged.reshape(-1, R).any(1)
+        print('[trainable conf_mc] rays with a differing direction %d / secondary hit flag %d' % (n_dir, n_vis))
+        assert flagged_px.float().mean().item() <= 0.1
+        assert (out['secondary_mask'].cpu() != g['secondary_mask']).float().mean().item() < 0.02
     for k in FLOAT_KEYS:
         a, b = out[k].detach().cpu(), g[k]
         sel = hit if k in ('points', 'sdf_output') else agree
+        if mcs and k in mc_keys:
+            sel = sel & ~flagged_px
         tol = 2e-4 if k == 'points' else (5e-2 if k == 'sdf_output' else 1e-3)
+        if mcs and k == 'sg_specular_rgb_values':
+            tol = 1e-2                      # a component of the colour: see tests/parity.py
         if k == 'sdf_output':
             assert (a[sel] - b[sel]).abs().max().item() < 2e-4
         else:
             assert rel_l2(a[sel], b[sel]) < tol, (tag, k, rel_l2(a[sel], b[sel]))
     n_eik = g['eikonal_points'].shape[0]
     assert rel_l2(out['grad_theta'][:n_eik], g['grad_theta'][:n_eik]) < 1e-4
-    lc = syn.loss_conf('physg')
+    lc = syn.loss_conf(name)
     lc['idr_rgb_weight'] = 1.0
     lo = IDRLoss(**lc)(out, {'rgb': g['rgb_gt'].to(DEV)})
+    ltol = 3e-2 if mcs else 5e-3            # (the MC colour sums include the few discretely different rays)
     for k in ('loss', 'idr_rgb_loss', 'sg_rgb_loss', 'eikonal_loss', 'mask_loss', 'normalsmooth_loss'):
-        assert abs(lo[k].item() - g['loss.' + k].item()) <= 5e-3 * abs(g['loss.' + k].item()) + 1e-6, k
+        assert abs(lo[k].item() - g['loss.' + k].item()) <= ltol * abs(g['loss.' + k].item()) + 1e-6, k
     lo['loss'].backward()
     sdf_grads = 0
-    for name, p in m.named_parameters():
-        key = 'gnorm.' + name
+    gtol = 0.15 if mcs else 3e-2
+    for pname, p in m.named_parameters():
+        key = 'gnorm.' + pname
         if key in g and g[key].item() > 0:
-            assert p.grad is not None, name
-            assert abs(p.grad.norm().item() - g[key].item()) <= 3e-2 * g[key].item() + 1e-7, name
-            if 'grad.' + name in g:
-                assert rel_l2(p.grad, g['grad.' + name]) < 3e-2, (name, rel_l2(p.grad, g['grad.' + name]))
-            sdf_grads += name.startswith('implicit_network')
+            assert p.grad is not None, pname
+            assert abs(p.grad.norm().item() - g[key].item()) <= gtol * g[key].item() + 1e-7, pname
+            if 'grad.' + pname in g:
+                assert rel_l2(p.grad, g['grad.' + pname]) < gtol, (pname, rel_l2(p.grad, g['grad.' + pname]))
+            sdf_grads += pname.startswith('implicit_network')
     assert sdf_grads >= 20
+    m.uniforms_override = None
     # the whole step with trainable geometry: the SDF network is in the idr optimizer (idr_train.py:188-191) and moves
     before = {k: v.detach().clone() for k, v in m.implicit_network.state_dict().items()}
     st = TrainStep(m, lc)
     _, lo2 = st(inp, {'rgb': g['rgb_gt'].to(DEV)})
     assert all(torch.isfinite(v).all() for v in m.state_dict().values() if v.dtype.is_floating_point)
     assert any(not torch.equal(before[k], v) for k, v in m.implicit_network.state_dict().items())
-    # Monte-Carlo shading has no input-differentiable form here: refused, loudly
-    m2 = IDRNetwork(conf.from_dict(syn.model_conf('conf', hidden=64))).to(DEV).train()
-    with pytest.raises(NotImplementedError):
-        m2(inp)
 
 
 @pytest.mark.parametrize('name,mode', [('conf', 'train'), ('conf', 'eval'), ('neus', 'train'), ('neus', 'eval'),

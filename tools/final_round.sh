@@ -2,7 +2,7 @@
 # Everything profiles/rNN/ holds for a round, in one gpurun call:  tools/final_round.sh <tag>
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-T=${1:-r02j}; O=gpurun_out/$T
+T=${1:-r03}; O=gpurun_out/$T
 mkdir -p $O
 for w in cfg2 cfg3 cfg4; do
     bash tools/profile_round.sh $T $w eval_kernel16 $([ $w = cfg2 ] && echo 20 || echo 10) > $O/log_$w.txt 2>&1
