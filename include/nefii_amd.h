@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 6
+#define NEFII_ABI_VERSION 7
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -89,6 +89,20 @@ int nefii_pack_linear(const float *W, const float *bias, int n_out, int k_in,
  * the lo halves of typical |w| ~ 0.05 stay normal fp16 numbers; the kernel scales accumulators by 1/64. */
 int nefii_pack_linear_f16x3(const float *W, int n_out, int k_in, int x_src0, int x_len, int e_src0, int e_len,
                             float scale, void *w_f16x3, void *stream);
+
+/* The packings above (nefii_pack_linear, and - for the layers whose w_f16x3 / w_bwd_f16x3 pointers are set -
+ * nefii_pack_linear_f16x3 / _f16x3_bwd) for EVERY layer of h_mlp in ONE launch: the radiance / material weights train
+ * (idr_train.py:771-775 steps both optimizers every iteration), so they are re-packed every step.  h_layers: host array
+ * [n_layers] of the sources; the destinations are the device pointers in h_mlp->layer[l] (bias always; w_fwd / w_bwd
+ * unless skip_f32, which the fp16-MFMA kernels never read).  (ABI v7) */
+typedef struct nefii_pack_source {
+    const float *W;          /* [n_out][k_in], PyTorch nn.Linear layout, after weight-norm */
+    const float *bias;       /* [n_out] or NULL */
+    int32_t n_out, k_in, x_src0, x_len, e_src0, e_len;     /* as nefii_pack_linear */
+    float scale;
+    int32_t skip_f32;        /* 1: leave w_fwd / w_bwd alone */
+} nefii_pack_source;
+int nefii_pack_mlp(const nefii_mlp *h_mlp, const nefii_pack_source *h_layers, void *stream);
 
 /* Fused MLP forward over n points (replaces ImplicitNetwork.forward :85-108, RenderingNetwork.forward
  * :196-241 and EnvmapMaterialNetwork's diffuse_albedo_layers sg_envmap_material.py:369).

@@ -14,7 +14,7 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 6
+ABI_VERSION = 7
 TRACE_COUNTERS = 8          # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
@@ -44,6 +44,12 @@ class TracerParams(ctypes.Structure):
                 ('minsdf_group', ctypes.c_int32), ('small_round', ctypes.c_int32)]
 
 
+class PackSource(ctypes.Structure):
+    _fields_ = [('W', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('n_out', ctypes.c_int32), ('k_in', ctypes.c_int32),
+                ('x_src0', ctypes.c_int32), ('x_len', ctypes.c_int32), ('e_src0', ctypes.c_int32), ('e_len', ctypes.c_int32),
+                ('scale', ctypes.c_float), ('skip_f32', ctypes.c_int32)]
+
+
 class LossParams(ctypes.Structure):
     _fields_ = [('idr_rgb_weight', ctypes.c_float), ('sg_rgb_weight', ctypes.c_float), ('mask_weight', ctypes.c_float),
                 ('alpha', ctypes.c_float), ('normalsmooth_weight', ctypes.c_float),
@@ -63,6 +69,7 @@ SIGNATURES = {
     'nefii_pack_linear': (I, [P, P, I, I, I, I, I, I, F, P, P, P, P]),
     'nefii_pack_linear_f16x3': (I, [P, I, I, I, I, I, I, F, P, P]),
     'nefii_pack_linear_f16x3_bwd': (I, [P, I, I, I, I, I, I, F, P, P]),
+    'nefii_pack_mlp': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(PackSource), P]),
     'nefii_mlp_forward': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P]),
     'nefii_mlp_backward': (I, [ctypes.POINTER(Mlp), P, I, P, I, I64, P, I, P]),
     'nefii_mlp_wgrad': (I, [P, I, P, I, I64, I, I, F, P, P, P]),

@@ -147,6 +147,96 @@ extern "C" int nefii_pack_linear_f16x3_bwd(const float *W, int n_out, int k_in, 
     return 0;
 }
 
+// ---- the three packings above for EVERY layer of a net in one launch (blockIdx.y = layer) -------------------------------
+// The radiance / material weights train, so they are re-packed every step: layer by layer that was 3 launches x 5 layers
+// x 2 nets of ~4 us each at the head of the step's tail.
+struct PackSources {
+    nefii_pack_source l[NEFII_MAX_LAYERS];
+};
+__global__ void pack_mlp_kernel(nefii_mlp m, PackSources src) {
+    const int l = blockIdx.y;
+    const nefii_layer &L = m.layer[l];
+    const nefii_pack_source &S = src.l[l];
+    const float *__restrict__ W = S.W;
+    const int kx = L.k_x, ke = L.k_e, n_pad = L.n_pad, K = kx + ke, n_out = S.n_out, k_in = S.k_in;
+    const int NT = n_pad >> 5, KT = K >> 5;
+    const float scale = S.scale;
+    const int stride = gridDim.x * blockDim.x, first = blockIdx.x * blockDim.x + threadIdx.x;
+    float *w_fwd = S.skip_f32 ? nullptr : const_cast<float *>(L.w_fwd);
+    float *w_bwd = S.skip_f32 ? nullptr : const_cast<float *>(L.w_bwd);
+    float *bias_pad = const_cast<float *>(L.bias);
+    for (int idx = first; idx < n_pad; idx += stride) bias_pad[idx] = (S.bias && idx < n_out) ? S.bias[idx] : 0.f;
+    if (w_fwd) {
+        const int total = K * n_pad;
+        for (int idx = first; idx < total; idx += stride) {
+            const int s = idx & 3, lane = (idx >> 2) & 63, blk = idx >> 8;
+            {
+                const int t = blk % NT, g = blk / NT;
+                const int n = 32 * t + (lane & 31), kk = 8 * g + 4 * (lane >> 5) + s;
+                const int c = src_col(kk, kx, S.x_src0, S.x_len, S.e_src0, S.e_len);
+                w_fwd[idx] = (n < n_out && c >= 0) ? W[(size_t)n * k_in + c] * scale : 0.f;
+            }
+            if (w_bwd) {
+                const int t = blk % KT, g = blk / KT;
+                const int kk = 32 * t + (lane & 31), n = 8 * g + 4 * (lane >> 5) + s;
+                const int c = src_col(kk, kx, S.x_src0, S.x_len, S.e_src0, S.e_len);
+                w_bwd[idx] = (n < n_out && c >= 0) ? W[(size_t)n * k_in + c] * scale : 0.f;
+            }
+        }
+    }
+    if (L.w_f16x3) {
+        _Float16 *out = reinterpret_cast<_Float16 *>(const_cast<void *>(L.w_f16x3));
+        const int total = (K >> 4) * NT * 64;
+        for (int idx = first; idx < total; idx += stride) {
+            const int lane = idx & 63, blk = idx >> 6;
+            const int t = blk % NT, st = blk / NT;
+            const int n = 32 * t + (lane & 31);
+            _Float16 *hi = out + (((size_t)blk * 2) * 64 + lane) * 8, *lo = out + (((size_t)blk * 2 + 1) * 64 + lane) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = 16 * st + 8 * (lane >> 5) + j;
+                const int c = src_col(kk, kx, S.x_src0, S.x_len, S.e_src0, S.e_len);
+                const float w = (n < n_out && c >= 0) ? W[(size_t)n * k_in + c] * scale * W16_SCALE : 0.f;
+                split16(w, hi[j], lo[j]);
+            }
+        }
+    }
+    if (L.w_bwd_f16x3) {
+        _Float16 *out = reinterpret_cast<_Float16 *>(const_cast<void *>(L.w_bwd_f16x3));
+        const int total = (n_pad >> 4) * KT * 64;
+        for (int idx = first; idx < total; idx += stride) {
+            const int lane = idx & 63, blk = idx >> 6;
+            const int t = blk % KT, st = blk / KT;
+            const int kk = 32 * t + (lane & 31);
+            const int c = src_col(kk, kx, S.x_src0, S.x_len, S.e_src0, S.e_len);
+            _Float16 *hi = out + (((size_t)blk * 2) * 64 + lane) * 8, *lo = out + (((size_t)blk * 2 + 1) * 64 + lane) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int nn = 16 * st + 8 * (lane >> 5) + j;
+                const float w = (nn < n_out && c >= 0) ? W[(size_t)nn * k_in + c] * scale * W16_SCALE : 0.f;
+                split16(w, hi[j], lo[j]);
+            }
+        }
+    }
+}
+
+extern "C" int nefii_pack_mlp(const nefii_mlp *h_mlp, const nefii_pack_source *h_layers, void *stream) {
+    if (!h_mlp || !h_layers || h_mlp->n_layers < 1 || h_mlp->n_layers > NEFII_MAX_LAYERS) return NEFII_E_ARG;
+    PackSources src;
+    for (int l = 0; l < h_mlp->n_layers; ++l) {
+        const nefii_layer &L = h_mlp->layer[l];
+        const nefii_pack_source &S = h_layers[l];
+        if (!S.W || !L.bias || (!S.skip_f32 && !L.w_fwd) || S.n_out <= 0 || S.k_in <= 0) return NEFII_E_ARG;
+        if (L.k_x != pad_hidden(S.x_len) || L.k_e != round32(S.e_len) || L.n_pad != pad_hidden(S.n_out)) return NEFII_E_SHAPE;
+        if (L.n_pad > NEFII_MAX_WIDTH || L.k_x > NEFII_MAX_WIDTH || L.k_e > NEFII_MAX_ENC || L.k_x + L.k_e == 0) return NEFII_E_SHAPE;
+        if (S.x_src0 + S.x_len > S.k_in || S.e_src0 + S.e_len > S.k_in) return NEFII_E_SHAPE;
+        src.l[l] = S;
+    }
+    hipLaunchKernelGGL(pack_mlp_kernel, dim3(64, h_mlp->n_layers), dim3(256), 0, (hipStream_t)stream, *h_mlp, src);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // shared prologue: stage raw inputs + features of one 32-point tile, encode into E
 // ------------------------------------------------------------------------------------------------
@@ -437,9 +527,11 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(const float *__restrict_
     }
 }
 
-__global__ void zero_fill_kernel(float *__restrict__ p, size_t n) {
+// zeroes dW [nw] and, behind it in the same grid, db [nb] (may be NULL): one launch ahead of an accumulating wgrad kernel
+__global__ void zero_fill_kernel(float *__restrict__ p, size_t n, float *__restrict__ q, size_t nq) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.f;
+    else if (q && i - n < nq) q[i - n] = 0.f;
 }
 
 extern "C" int nefii_mlp_wgrad(const float *dz, int dz_stride, const float *x, int x_stride, int64_t n, int n_out,
@@ -453,12 +545,9 @@ extern "C" int nefii_mlp_wgrad(const float *dz, int dz_stride, const float *x, i
         // a kernel, not hipMemsetAsync: inside a captured hipGraph (TrainStep(graph=True)) the memset node did not
         // reliably precede the accumulating kernel on replay - weight gradients picked up non-finite garbage
         const size_t nw = (size_t)n_out * k_in;
-        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, dW, nw);
+        const size_t nz = nw + (db ? (size_t)n_out : 0);
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, dW, nw, db, (size_t)n_out);
         HIP_CHECK_LAUNCH();
-        if (db) {
-            hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, db, (size_t)n_out);
-            HIP_CHECK_LAUNCH();
-        }
     }
     if (n <= 0) return 0;
     dim3 grid((n_out + 63) / 64, (k_in + 255) / 256, split);
@@ -1435,12 +1524,9 @@ extern "C" int nefii_mlp_wgrad_f16(const float *dz, int dz_stride, const float *
     if (split > 64) split = 64;
     if (split > 1 || n <= 0) {
         const size_t nw = (size_t)n_out * k_in;
-        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, dW, nw);
+        const size_t nz = nw + (db ? (size_t)n_out : 0);
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, dW, nw, db, (size_t)n_out);
         HIP_CHECK_LAUNCH();
-        if (db) {
-            hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, st, db, (size_t)n_out);
-            HIP_CHECK_LAUNCH();
-        }
     }
     if (n <= 0) return 0;
     if (wgrad_tr_enabled() && n_out >= 64 && k_in >= 64 && n >= 1024 && (dz_stride & 3) == 0 &&

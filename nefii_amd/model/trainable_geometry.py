@@ -311,6 +311,7 @@ def forward_with_uv(model, input):
     with torch.no_grad():
         _, network_object_mask, dists = model.ray_tracer(sdf=net, cam_loc=cam_loc, object_mask=object_mask,
                                                         ray_directions=ray_dirs)
+    model.last_ray_hit = network_object_mask       # per-RAY mask of this forward (diagnostics, as in shade_tail)
     points = (cam_loc.unsqueeze(1) + dists.reshape(batch_size, num_pixels, 1) * ray_dirs).reshape(-1, 3)
     sdf_output = sdf_torch(net, points)[:, 0:1]
     ray_dirs = ray_dirs.reshape(-1, 3)

@@ -128,21 +128,20 @@ class PackedMLP:
         """weights[l]: effective [n_out, k_in] fp32 GPU tensors (after weight-norm), biases[l]: [n_out]."""
         lib = _lib.lib()
         st = _stream()
+        # every layer and every form in ONE launch (nefii_pack_mlp); the fp16-MFMA kernels (self.half) never read the
+        # f32 fragments, so those are skipped there
+        src = (_lib.PackSource * len(self.specs))()
+        keep = []                               # converted copies must outlive the launch call
         for l, s in enumerate(self.specs):
             w = _f32(weights[l])
             b = _f32(biases[l])
+            keep += [w, b]
             assert tuple(w.shape) == (s.n_out, s.k_in), (tuple(w.shape), s.n_out, s.k_in)
-            _lib.check(lib.nefii_pack_linear(_ptr(w), _ptr(b), s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0, s.e_len,
-                                             s.scale, _ptr(self.w_fwd[l]),
-                                             _ptr(self.w_bwd[l]) if self.need_bwd else None, _ptr(self.bias[l]), st),
-                       'nefii_pack_linear')
-            if self.f16x3:
-                _lib.check(lib.nefii_pack_linear_f16x3(_ptr(w), s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0, s.e_len,
-                                                       s.scale, _ptr(self.w_f16[l]), st), 'nefii_pack_linear_f16x3')
-                if self.w_f16b[l] is not None:
-                    _lib.check(lib.nefii_pack_linear_f16x3_bwd(_ptr(w), s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0,
-                                                               s.e_len, s.scale, _ptr(self.w_f16b[l]), st),
-                               'nefii_pack_linear_f16x3_bwd')
+            e = src[l]
+            e.W, e.bias = _ptr(w), _ptr(b)
+            e.n_out, e.k_in, e.x_src0, e.x_len, e.e_src0, e.e_len = s.n_out, s.k_in, s.x_src0, s.x_len, s.e_src0, s.e_len
+            e.scale, e.skip_f32 = s.scale, 1 if self.half else 0
+        _lib.check(lib.nefii_pack_mlp(ctypes.byref(self.struct), src, st), 'nefii_pack_mlp')
         if self.mlp_stream:
             _lib.check(lib.nefii_pack_mlp_stream(ctypes.byref(self.struct), _ptr(self.w_stream), st),
                        'nefii_pack_mlp_stream')
