@@ -555,6 +555,45 @@ def test_bench_two_processes_share_one_gpu():
     assert d['cfg3']['roofline']['secondary_hit_fraction'] > 0.2 and 0 < d['roofline']['frac_step'] < d['roofline']['frac_kernel']
 
 
+def _run_bench(args, nproc, port, timeout=600):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NEFII_BENCH_BACKEND='gloo')
+    if nproc > 1:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr',
+               '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(nproc)] + args
+    else:
+        cmd = [sys.executable, os.path.join(root, 'bench.py')] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+
+
+def test_bench_strong_scaling_modes():
+    """bench.py --scaling strong (BASELINE config 4's own definition: the GLOBAL 8192-pixel batch cut into contiguous per-rank
+    slices, scene_dataset.py:268-279) and --workload cfg5 (one full-frame eval render as the step, chunks dealt round-robin
+    and gathered on rank 0, render.py:284-336) on two ranks sharing this box's GPU over gloo, against the one-rank run: the
+    same global work, the same hit statistics."""
+    one = _run_bench(['--workload', 'cfg4', '--scaling', 'strong', '--steps', '2', '--warmup', '1', '--repeats', '1',
+                      '--no-cpu-baseline', '--no-side-measurement'], 1, 0)
+    two = _run_bench(['--workload', 'cfg4', '--scaling', 'strong', '--steps', '2', '--warmup', '1', '--repeats', '1',
+                      '--no-cpu-baseline', '--no-side-measurement'], 2, 29531)
+    assert one['scaling'] == two['scaling'] == 'strong' and two['n_gpus'] == 2
+    assert one['config']['primary_rays_per_step_per_gpu'] == 8192 * 64
+    assert two['config']['primary_rays_per_step_per_gpu'] == 4096 * 64          # half of the global batch per rank
+    # value counts the GLOBAL rays of a step over the step's time on both sides
+    assert abs(one['value'] * one['ms_per_step'] - two['value'] * two['ms_per_step']) < 1e-6 * one['value'] * one['ms_per_step']
+    assert not one['invalid'] and not two['invalid'] and two['config']['rank_param_spread'] < 1e-9
+    f1 = _run_bench(['--workload', 'cfg5', '--frame-rows', '8', '--steps', '1'], 1, 0)
+    f2 = _run_bench(['--workload', 'cfg5', '--frame-rows', '8', '--steps', '1'], 2, 29533)
+    for f in (f1, f2):
+        assert f['scaling'] == 'strong' and f['config']['finite'] and f['config']['primary_rays_per_frame'] == 8 * 800 * 256
+    assert f2['n_gpus'] == 2 and abs(f1['config']['hit_pixel_fraction'] - f2['config']['hit_pixel_fraction']) < 1e-6
+
+
 @pytest.mark.parametrize('lookahead', [2, 5])
 @pytest.mark.parametrize('graph', [False, True])
 def test_prefetched_trace_gives_the_same_steps(graph, lookahead):
