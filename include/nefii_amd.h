@@ -184,7 +184,10 @@ typedef struct nefii_tracer_params {
                                 Only samples whose coarse value cannot decide - within coarse_tau of zero where the
                                 first sign change is looked for, within 2 coarse_tau of the minimum where the argmin
                                 is - are re-evaluated in split precision, so every decision (and the outputs) is the
-                                split evaluator's.  0 = off.  nefii_sdf_eval_coarse measures the bound for a net. */
+                                split evaluator's PROVIDED the bound holds for every sample taken: it is the CALLER'S
+                                claim about this net, measured (nefii_sdf_eval_coarse against nefii_sdf_eval, with a
+                                safety factor), not proven - a sample whose true difference exceeded it could decide
+                                differently.  0 = off. */
     int32_t coarse_cap;      /* most samples of one ray re-evaluated individually; a ray with more takes all n_steps
                                 in split precision instead.  <= 0: 64.  At most 100. */
     int32_t minsdf_group;    /* > 0: minsdf_steps holds one row of n_steps uniform draws per minsdf_group consecutive rays

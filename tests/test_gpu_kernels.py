@@ -528,6 +528,40 @@ def test_sdf_eval_coarse_stays_within_its_bound():
         assert 2e-5 < err < 0.5 * tau
 
 
+@pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg4'])
+def test_coarse_bound_holds_where_the_tracer_samples(wl):
+    """The coarse pass's identical-decisions argument rests on |single pass - split| < tau for every sample it takes; tau is
+    MEASURED (3 x the largest difference over 65 536 points of the bounding ball), not proven.  Here the bound is
+    checked where the tracer actually evaluates: 100 samples between the bounding-sphere entry and exit of the bench
+    workloads' own camera rays - 1.6 M points per workload, the near-surface stretch of every hitting ray among them - on the
+    workloads' own geometry stand-ins.  The largest difference must leave a factor 1.5 to tau."""
+    from nefii_amd.utils import rend_util
+    w = syn.WORKLOADS[wl]
+    mc, sd = syn.workload_state_dict(wl, seed=0)
+    pm = build_sdf(mc, sd, f16x3=True)
+    tau = ops.calibrate_coarse_tau(pm)
+    inp, _ = syn.make_inputs(4096, w['image_hw'], w['focal'], w['cam_pos'], 4, seed=1)
+    uv = inp['uv'].reshape(1, -1, 2).to(DEV)
+    dirs, cam = rend_util.get_camera_params(uv, inp['pose'].to(DEV), inp['intrinsics'].to(DEV))
+    d, o = dirs.reshape(-1, 3), cam.reshape(1, 3)
+    b = (d * o).sum(-1)
+    disc = b * b - ((o * o).sum() - 1.0)
+    ok = disc > 0
+    d, b, disc = d[ok], b[ok], disc[ok]
+    t0, t1 = (-b - disc.sqrt()).clamp_min(0.01), (-b + disc.sqrt()).clamp_min(0.01)
+    lin = torch.linspace(0, 1, 100, device=DEV)
+    t = t0[:, None] + lin[None, :] * (t1 - t0)[:, None]
+    x = (o[None] + t[..., None] * d[:, None, :]).reshape(-1, 3).contiguous()
+    a = ops.sdf_eval(pm, x, coarse=True)
+    e = ops.sdf_eval(pm, x)
+    err = (a - e).abs()
+    near = e.abs() < 0.02
+    print('[coarse bound %s] %d points on %d rays: max |single pass - split| %.2e (near the surface, %d points: %.2e), tau %.2e'
+          % (wl, x.shape[0], d.shape[0], err.max().item(), int(near.sum()), err[near].max().item(), tau))
+    assert x.shape[0] > 500000 and near.sum() > 1000
+    assert err.max().item() < tau / 1.5, (err.max().item(), tau)
+
+
 @pytest.mark.parametrize('n', [300, 6000])
 def test_tracer_256_wide_net_vs_oracle(monkeypatch, n):
     """conf_neus.conf's SDF net (8 x 256) runs on the pipelined evaluator's 256-wide shape (96- and 32-query tiles:
