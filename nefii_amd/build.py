@@ -60,12 +60,14 @@ def build_canary(force=False, verbose=True):
     tests/test_gpu_concurrency.py runs it beside every evaluator of the product library and demands bit-identical results:
     it fails on gfx950 if an evaluator stops claiming its SIMDs."""
     src = os.path.join(CSRC, 'nefii_shading.hip')
+    forms = os.path.join(HERE, '..', 'tests', 'canary', 'pk_forms.hip')       # packed-fp32 instruction forms, one kernel each
+    srcs = [src] + ([forms] if os.path.exists(forms) else [])
     if not force and os.path.exists(CANARY_OUT) and os.path.getmtime(CANARY_OUT) >= max(
-            os.path.getmtime(src), os.path.getmtime(os.path.abspath(__file__))):
+            [os.path.getmtime(f) for f in srcs] + [os.path.getmtime(os.path.abspath(__file__))]):
         return CANARY_OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc] + [f for f in FLAGS if f not in ('-Xclang', '-target-feature', '-packed-fp32-ops')] + \
-        ['-shared', src, '-o', CANARY_OUT]
+        ['-shared'] + srcs + ['-o', CANARY_OUT]
     if verbose:
         print(' '.join(cmd), flush=True)
     _run_quietly(cmd)

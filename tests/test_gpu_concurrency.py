@@ -2,7 +2,8 @@
 batch's tail runs) must not change anybody's results - round 2's config 3 lost a third of its steps to non-finite
 gradients that appeared only under trace prefetch (DESIGN.md "Packed fp32 beside MFMA waves").
 
-Two pins:
+Three pins:
+  * the instruction form: packed fp32 with op_sel on src1, in inline assembly, beside every evaluator (bit-identical);
   * the mechanism: a canary build of the shading kernels WITH packed-fp32 instructions (libnefii_canary.so: test
     infrastructure, nefii_amd/build.py:build_canary) gives bit-identical results beside every tracer evaluator of the product
     library - on gfx950 it does not when an evaluator leaves room for a foreign wave on its SIMDs (mlp_tile.h, NEFII_CLAIM_SIMD);
@@ -94,6 +95,55 @@ def test_packed_fp32_canary_beside_the_evaluators():
         bad = [int((torch.nan_to_num(o) != torch.nan_to_num(ref)).sum()) for o in outs]
         assert max(bad) == 0, '%s: %d of %d runs of the packed-fp32 canary differ (worst: %d elements)' % (
             name, sum(b > 0 for b in bad), len(bad), max(bad))
+
+
+def test_op_sel_canary_beside_the_evaluators():
+    """The instruction form itself (tests/canary/pk_forms.hip, inline assembly): a packed-fp32 instruction with op_sel set on
+    src1 - both result lanes read src1's HIGH register.  Beside an evaluator that leaves 80 registers of its SIMDs free, lanes
+    48-63 of such a wave get ZERO for the low result lane's src1 in 40 of 40 runs (profiles/r03/nan_hunt/13, 17); beside the
+    product's evaluators, which claim their SIMDs, every run must be bit-identical to the idle-chip result."""
+    from nefii_amd import build, ops
+    from nefii_amd.ops import _ptr
+    build.build_canary(verbose=False)
+    canary = ctypes.CDLL(build.CANARY_OUT)
+    P, I, I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    canary.nefii_canary_pk_form.restype = I
+    canary.nefii_canary_pk_form.argtypes = [I, P, P, I64, I, P]
+    _, m512 = _model('conf')
+    _, m256 = _model('neus')
+    pm512, pm256 = (m.implicit_network.packed(f16x3=True) for m in (m512, m256))
+    g = torch.Generator().manual_seed(3)
+    n = 114891
+    vin = torch.empty(n, 6)
+    vin[:, 0:2] = 0.9 + 0.09 * torch.rand(n, 2, generator=g)
+    vin[:, 2:4] = 0.1 * torch.randn(n, 2, generator=g)
+    vin[:, 4:6] = torch.randn(n, 2, generator=g)
+    vin = vin.to(DEV)
+    xs = (torch.randn(1 << 19, 3, generator=g) * 0.45).to(DEV)
+
+    def victim(form):
+        out = torch.empty(n, 2, device=DEV)
+        assert canary.nefii_canary_pk_form(form, _ptr(vin), _ptr(out), n, 100, torch.cuda.current_stream().cuda_stream) == 0
+        return out
+    forms = {10: 'v_pk_mul_f32 op_sel:[0,1]', 12: 'v_pk_fma_f32 op_sel:[0,1,0]', 13: 'v_pk_add_f32 op_sel:[0,1]'}
+    refs = {f: victim(f) for f in forms}
+    torch.cuda.synchronize()
+    loads = {'512-wide single pass': lambda: ops.sdf_eval(pm512, xs, coarse=True), '512-wide split': lambda: ops.sdf_eval(pm512, xs),
+             '256-wide single pass': lambda: ops.sdf_eval(pm256, xs, coarse=True), '256-wide split': lambda: ops.sdf_eval(pm256, xs),
+             'value + gradient': lambda: ops.sdf_value_grad(pm512, xs, want_feat=True)}
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for name, load in loads.items():
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sb):
+            for _ in range(10):
+                load()
+        outs = []
+        with torch.cuda.stream(sa):
+            for _ in range(10):
+                outs += [(f, victim(f)) for f in forms]
+        torch.cuda.synchronize()
+        bad = [(forms[f], int((o != refs[f]).sum())) for f, o in outs if not torch.equal(o, refs[f])]
+        assert not bad, 'beside %s: %d of %d runs differ, e.g. %s' % (name, len(bad), len(outs), bad[:3])
 
 
 def test_config3_prefetch_trajectory_equals_the_serial_schedule():

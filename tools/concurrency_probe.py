@@ -140,6 +140,97 @@ def main():
         }
         loads = {'idle': None, 'conf coarse 16s<4,4> (512k)': lambda: ops.sdf_eval(pm, xs, coarse=True),
                  'conf split 16q<4,4> (512k)': lambda: ops.sdf_eval(pm, xs)}
+    if os.environ.get('PROBE_LOADS', '') == 'forms':
+        # WHICH packed-fp32 instruction forms are victims?  (libnefii_canary.so: tests/canary/pk_forms.hip, one form per
+        # kernel in inline assembly, launch shape of mis_sample; run with NEFII_LIB_PATH = a build WITHOUT the register claim)
+        import ctypes
+        from nefii_amd import build
+        from nefii_amd.ops import _ptr
+        build.build_canary(verbose=False)
+        can = ctypes.CDLL(build.CANARY_OUT)
+        P, I, I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        can.nefii_canary_pk_form.restype = I
+        can.nefii_canary_pk_form.argtypes = [I, P, P, I64, I, P]
+        can.nefii_mis_sample.restype = I
+        can.nefii_mis_sample.argtypes = [P, I, P, P, P, P, I64, P, P, P, P]
+        vin = torch.empty(n, 6)
+        vin[:, 0:2] = 0.9 + 0.09 * torch.rand(n, 2, generator=g)        # |a| < 1
+        vin[:, 2:4] = 0.1 * torch.randn(n, 2, generator=g)
+        vin[:, 4:6] = torch.randn(n, 2, generator=g)
+        vin = vin.to(dev)
+        iters = int(os.environ.get('PROBE_ITERS', '400'))
+
+        def form(fi):
+            def run():
+                out = torch.empty(n, 2, device=dev)
+                assert can.nefii_canary_pk_form(fi, _ptr(vin), _ptr(out), n, iters, torch.cuda.current_stream().cuda_stream) == 0
+                return out.reshape(-1)
+            return run
+
+        def mis_pk():
+            wi = torch.empty(3, n, 3, device=dev)
+            own = torch.empty(3, n, device=dev)
+            tab = torch.empty(3, n, 3, device=dev)
+            r = rough.reshape(-1).contiguous()
+            assert can.nefii_mis_sample(_ptr(lgt), lgt.shape[0], _ptr(r), _ptr(normal), _ptr(view), _ptr(uni), n, _ptr(wi),
+                                        _ptr(own), _ptr(tab), torch.cuda.current_stream().cuda_stream) == 0
+            return torch.cat([wi.reshape(-1), own.reshape(-1), tab.reshape(-1)])
+        names = ['v_pk_fma_f32 (plain)', 'v_pk_fma_f32 op_sel_hi:[1,0,1] (broadcast)', 'v_pk_fma_f32 neg_lo/neg_hi',
+                 'v_pk_mul_f32 op_sel (swapped halves) + v_pk_add_f32', 'v_pk_mul_f32 neg + v_pk_add_f32 neg',
+                 'v_pk_mov_b32 op_sel + v_pk_fma_f32', 'scalar v_fma_f32 x 2 (control)',
+                 'compiler-formed: tangent frame + change of basis, rsq', 'compiler-formed: cross products, mul/add only',
+                 'compiler-formed: sin/cos directions + dots']
+        tnames = ['v_rsq_f32; v_pk_mul_f32 OVERWRITES the pair holding its source', 'v_rsq_f32; v_mul_f32 overwrites its source (control)',
+                  'v_rsq_f32; s_nop 0; v_pk_mul_f32 consumes the result', 'v_rsq_f32; v_pk_mul_f32 consumes the result (no wait state)',
+                  'v_rsq_f32; independent v_pk_fma_f32; v_pk_mul_f32 consumes', 'v_rsq_f32; s_nop 0; v_mul_f32 consumes (control)',
+                  'v_rsq_f32 v42; v_pk_mov_b32 v[42:43]; v_rsq_f32 v42',
+                  'cos, sin, sin, cos; v_pk_mul_f32 consumes three of the results', 'cos, sin, sin, cos; 2 x v_mul_f32 consume (control)',
+                  'cos, sin, sin, cos; 3 plain instructions; v_pk_mul_f32 consumes', 'cos, sin, sin, cos; v_pk_mul_f32 consumes the last pair']
+        victims = {}
+        which = os.environ.get('PROBE_FORMS', 'all')
+        for claim in (0, 16):
+            for i in range(10):
+                if which == 'all' or (which == 'trans' and claim == 0 and i in (7, 8, 9)):
+                    victims[names[i] + (' [74 VGPRs]' if claim else '')] = form(i + claim)
+        if which != 'opsel':
+            for i in range(len(tnames)):
+                victims[tnames[i]] = form(32 + i)
+        onames = ['v_pk_mul_f32 op_sel:[0,1] (src1 high half to both lanes) + v_pk_add_f32', 'v_pk_mul_f32 op_sel:[1,0] (src0 high half to both lanes) + v_pk_add_f32',
+                  'v_pk_fma_f32 op_sel:[0,1,0]', 'v_pk_mul_f32 + v_pk_add_f32 op_sel:[0,1]', 'v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (src1 halves swapped) + v_pk_add_f32',
+                  'v_pk_mul_f32 op_sel:[0,1], src1 = the running value']
+        for i in range(6):
+            victims[onames[i]] = form(10 + i)
+        victims['mis_sample compiled WITH packed fp32 (positive control)'] = mis_pk
+        bigm = big.reshape(4096, -1)
+        victims['torch.linalg.vector_norm(4096 x 1024 fp32, dim=1) (reduce_kernel<NormOps>: has the form)'] = lambda: torch.linalg.vector_norm(bigm, dim=1)
+        victims['torch.linalg.vector_norm(4096 x 1024 fp32, dim=0)'] = lambda: torch.linalg.vector_norm(bigm, dim=0)
+        victims['torch.linalg.vector_norm(4M fp32)'] = lambda: torch.linalg.vector_norm(big).reshape(1)
+        victims['torch.logaddexp2 (4M fp32) (has the form)'] = lambda: torch.logaddexp2(big, big * 0.5)
+        victims['mis_sample of the library under test (compiled WITHOUT packed fp32)'] = lambda: torch.cat(
+            [t.reshape(-1) for t in ops.mis_sample(lgt, rough, normal, view, uni)])
+        lgt = lgt.contiguous()
+        loads = {'idle': None, 'conf coarse 16s<4,4> (512k)': lambda: ops.sdf_eval(pm, xs, coarse=True),
+                 'conf split 16q<4,4> (512k)': lambda: ops.sdf_eval(pm, xs)}
+    if os.environ.get('PROBE_LOADS', '') == 'forms' and os.environ.get('PROBE_NEIGHBOURS'):
+        # WHAT in the neighbour disturbs the victim form?  Synthetic 8-wave / 216-VGPR neighbours, one instruction kind each
+        can.nefii_canary_neighbour.restype = I
+        can.nefii_canary_neighbour.argtypes = [I, P, I, I, P]
+        sink = torch.zeros(512, device=dev)
+        kinds = ['v_mfma_f32_16x16x32_f16', 'v_pk_fma_f16', 'v_pk_fma_f32', 'v_fma_f32', 'ds_read_b128', 'v_exp_f16', 's_nop only',
+                 'v_mfma + v_pk_fma_f16', 'v_pk_mul_f16 v, v, s op_sel_hi:[1,0]', 'v_pk_mul_f16 v, v, v op_sel_hi:[1,0]',
+                 'v_pk_fma_f16 v, v, v, s op_sel_hi:[1,1,0]', 'v_pk_max_f16 v, v, 0', 'ds_bpermute_b32', 'v_exp_f16_sdwa',
+                 'v_pack_b32_f16 + v_cvt_pk_f16_f32', 'v_pk_fma_f16 v, v, s, v op_sel_hi:[1,0,0]']
+        nit = [1000, 4000, 4000, 4000, 2000, 2000, 4000, 1000, 4000, 4000, 4000, 4000, 1000, 2000, 2000, 4000]
+
+        def neighbour(k):
+            def run():
+                assert can.nefii_canary_neighbour(k, _ptr(sink), nit[k], 2048, torch.cuda.current_stream().cuda_stream) == 0
+            return run
+        loads = {'idle': None}
+        for k in range(len(kinds)):
+            loads['beside ' + kinds[k]] = neighbour(k)
+        loads['beside the single-pass evaluator'] = lambda: ops.sdf_eval(pm, xs, coarse=True)
+        victims = {k: v for k, v in victims.items() if k.startswith('v_pk_mul_f32 op_sel:[0,1] (src1') or k.startswith('v_pk_mul_f32 op_sel:[1,0]')}
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
     print('victim x load: runs that differ from the idle-chip result / runs   (elements that differ in the worst run)')
     for vname, vf in victims.items():
