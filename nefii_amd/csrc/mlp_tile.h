@@ -1272,6 +1272,9 @@ __host__ __device__ __forceinline__ int s_units(const nefii_layer &L) { return (
 template <int FT>
 __device__ __forceinline__ void sload(SStage<FT> &st, PCursor &c) {
     const half8 *p = reinterpret_cast<const half8 *>(reinterpret_cast<const char *>(c.base) + c.off);
+#ifdef NEFII_X_NO_FRAGLOAD  /* experiment (what in the evaluator disturbs its SIMD neighbours) */
+    if (c.off == 0xffffffffu)
+#endif
 #pragma unroll
     for (int i = 0; i < FT; ++i) st.f[i] = p[64 * i];
     c.off += FT * 1024;
@@ -1280,6 +1283,9 @@ __device__ __forceinline__ void sload(SStage<FT> &st, PCursor &c) {
 
 template <int QT, int XP>
 __device__ __forceinline__ void sload_a(SAct<QT> &st, const _Float16 *ah, int s32) {
+#ifdef NEFII_X_NO_ACTLOAD
+    if (s32 == 0x7fffffff)
+#endif
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) st.h[qt] = *reinterpret_cast<const half8 *>(ah + qt * 16 * XP + 32 * s32);
 }
@@ -1359,7 +1365,11 @@ __device__ __forceinline__ void sepilogue(const f32x4 (&acc)[FT * QT], float bve
         for (int qt = 0; qt < QT; ++qt) {
             const f32x4 &av = acc[ft * QT + qt];
             if constexpr (FAST) {
+#ifdef NEFII_X_NO_EPILOGUE
+                phi[ft * QT + qt] = __builtin_convertvector(av * k16 + bs, half4);
+#else
                 phi[ft * QT + qt] = softplus100_s16_pk4(av, k16, bs);
+#endif
             } else {
                 float4v hs;
 #pragma unroll
