@@ -280,6 +280,11 @@ WORKLOADS = {
                  scene=None),
     'cfg2': dict(model='physg', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=-1,
                  scene=None),
+    # config 2 with the camera at 1.6 instead of 2.4: the geometric-init surface (radius 0.32-0.54, mean 0.41) then fills
+    # ~42 % of the frame - the hit fraction SURVEY.md section 8(d) planned for config 2 (at 2.4 it is 18 %, so 82 % of the
+    # rays go through the min-SDF search); a side measurement of bench.py, not a BASELINE config
+    'cfg2_near': dict(model='physg', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 1.6), num_rays=-1,
+                      scene=None),
     'cfg3': dict(model='conf', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64,
                  scene='bowl'),
     'cfg4': dict(model='neus', num_pixels=8192, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64,

@@ -63,7 +63,8 @@ def test_config2_trains_like_the_oracle_for_250_steps():
     (NEFII_MLP_PRECISION=f32, bit-exact fma chains) drifts from the oracle as far as the default fp16 one does (measured in
     round 3: 5-10 % pointwise at step 50 for both; summation-order noise of 1e-6 is amplified by Adam's normalised updates) -
     so the long-run statement is comparative and statistical: the default arithmetic stays as close to the oracle as the
-    exact one does (smoothed loss curves), and both end at the oracle's loss level and PSNR."""
+    exact one does (smoothed loss curves), and both end at the oracle's loss level and PSNR (median of the parameter states after
+    steps 229, 239 and 249: a single state may sit on one of Adam's loss spikes - seen once on the fp32 control: 23.4 vs 27.0 dB)."""
     import os
     from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
     from nefii_amd.training.step import TrainStep
@@ -90,7 +91,8 @@ def test_config2_trains_like_the_oracle_for_250_steps():
     opt = torch.optim.Adam(params, lr=5e-4)
     Ro = ReplayOracle(sdo, mc, training=True)
     Ro.dead_work = False
-    ref_curve = []
+    ref_curve, ref_snaps = [], []
+    CHECK = (STEPS - 21, STEPS - 11, STEPS - 1)
     for it in range(STEPS):
         b = it % NB
         Ro.key = b
@@ -100,16 +102,22 @@ def test_config2_trains_like_the_oracle_for_250_steps():
         lo['loss'].backward()
         opt.step()
         ref_curve.append((lo['sg_rgb_loss'].item(), lo['idr_rgb_loss'].item()))
-    with torch.no_grad():
-        ref_final = []
-        for b in range(NB):
-            Ro.key = b
-            ref_final.append(Ro.forward(batches[b][0], steps[b]))
+        if it in CHECK:
+            with torch.no_grad():
+                snap = []
+                for b2 in range(NB):
+                    Ro.key = b2
+                    snap.append(Ro.forward(batches[b2][0], steps[b2]))
+            ref_snaps.append(snap)
+    ref_final = ref_snaps[-1]
 
     def pooled_psnr(outs, key):
         a = torch.cat([o[key].cpu()[ref_final[b]['network_object_mask']] for b, o in enumerate(outs)])
         t = torch.cat([batches[b][1][0][ref_final[b]['network_object_mask']] for b in range(NB)])
         return psnr(a, t)
+
+    def median_psnr(snaps, key):        # a single parameter state may sit on one of Adam's loss spikes: median of three late ones
+        return sorted(pooled_psnr(sn, key) for sn in snaps)[len(snaps) // 2]
 
     # ---- HIP path: the default arithmetic, then the exact-fp32 MLP kernels as the control
     dev_batches = [({k: v.to(DEV) for k, v in inp.items()}, {'rgb': gt.to(DEV)}) for inp, gt in batches]
@@ -124,27 +132,32 @@ def test_config2_trains_like_the_oracle_for_250_steps():
             m.train()
             m.ray_tracer.minsdf_steps_override = [steps[i % NB] for i in range(NB)]
             st = TrainStep(m, lc, graph=True)
-            curve = []
+            curve, snaps = [], []
             for it in range(STEPS):
                 out, lo = st(*dev_batches[it % NB])
                 curve.append((lo['sg_rgb_loss'].detach().clone(), lo['idr_rgb_loss'].detach().clone()))   # (graph: static tensors)
+                if it in CHECK:
+                    calls = m.ray_tracer._calls
+                    with torch.no_grad():
+                        snap = []
+                        for b in range(NB):
+                            m.ray_tracer._calls = b
+                            snap.append({k: v.detach().clone() for k, v in m(dev_batches[b][0]).items() if torch.is_tensor(v)})
+                    m.ray_tracer._calls = calls
+                    m.train()
+                    snaps.append(snap)
             curve = [(a.item(), c.item()) for a, c in curve]
             assert int(st.nonfinite_steps.item()) == 0
-            finals = []
-            with torch.no_grad():
-                for b in range(NB):
-                    m.ray_tracer._calls = b
-                    finals.append(m(dev_batches[b][0]))
             for b in range(NB):
-                assert torch.equal(finals[b]['network_object_mask'].cpu(), ref_final[b]['network_object_mask'])
-            runs[prec] = (curve, {k: pooled_psnr(finals, k) for k in ('sg_rgb_values', 'idr_rgb_values')})
+                assert torch.equal(snaps[-1][b]['network_object_mask'].cpu(), ref_final[b]['network_object_mask'])
+            runs[prec] = (curve, {k: median_psnr(snaps, k) for k in ('sg_rgb_values', 'idr_rgb_values')})
         finally:
             os.environ.pop('NEFII_MLP_PRECISION', None)
 
     def smooth(curve, j):
         return torch.tensor([sum(x[j] for x in curve[i:i + WIN]) / WIN for i in range(0, STEPS, WIN)])
 
-    ref_psnr = {k: pooled_psnr(ref_final, k) for k in ('sg_rgb_values', 'idr_rgb_values')}
+    ref_psnr = {k: median_psnr(ref_snaps, k) for k in ('sg_rgb_values', 'idr_rgb_values')}
     dist = {}
     for prec, (curve, ps) in runs.items():
         early = max(abs(curve[it][j] - ref_curve[it][j]) / ref_curve[it][j] for it in range(3) for j in (0, 1))
