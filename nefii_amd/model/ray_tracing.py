@@ -132,7 +132,13 @@ class RayTracing(nn.Module):
                     # drawn on the host exactly like minimal_sdf_points (:316); always drawn (the reference draws only
                     # when some ray needs the search, a data-dependent host sync this build avoids)
                     drawn.append(torch.empty(self.n_steps).uniform_(0.0, 1.0))
-            steps = (drawn[0] if rows == 1 else torch.stack([d.cpu() for d in drawn])).to(dev).contiguous()
+            steps = drawn[0] if rows == 1 else torch.stack([d.cpu() for d in drawn])
+            if steps.device.type == 'cpu' and dev.type == 'cuda':
+                # pinned + non_blocking: a pageable host-to-device copy blocks the HOST until it has executed, and on a trace
+                # stream it executes behind the trace(s) enqueued before it
+                steps = steps.contiguous().pin_memory().to(dev, non_blocking=True)
+            else:
+                steps = steps.to(dev).contiguous()
             group = S if rows > 1 else 0
         n_rays = dirs.shape[0]
         levels = self.bisect_levels or self.auto_levels(n_rays, self.concurrent)

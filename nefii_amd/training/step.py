@@ -132,6 +132,25 @@ class _StepGraph:
             v.copy_(ground_truth[k])
 
 
+def _hit_index_ahead(ctx):
+    """On the trace stream, behind the trace: the hit rays' indices (padded to all rays) and their count in pinned host
+    memory - so that the step that consumes this trace needs no torch.nonzero, whose host sync would sit on the CALLER'S
+    stream behind the previous step's tail and keep the host from enqueueing one step while the GPU runs the other."""
+    mask = ctx['network_object_mask']
+    n_all = mask.shape[0]
+    ctx['hit_idx_all'] = torch.nonzero_static(mask, size=n_all, fill_value=n_all).flatten()
+    host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+    host.copy_(mask.sum(dtype=torch.int64).reshape(1), non_blocking=True)
+    ctx['hit_count_host'] = host
+
+
+def _hit_index(ctx):
+    """Indices of the hit rays: what _hit_index_ahead prepared (valid once the trace's event is done), else torch.nonzero."""
+    if 'hit_idx_all' in ctx:
+        return ctx['hit_idx_all'][:int(ctx['hit_count_host'].item())]
+    return torch.nonzero(ctx['network_object_mask']).flatten()
+
+
 class TrainStep:
     def __init__(self, model, loss_conf, idr_lr=5e-4, sg_lr=5e-4, world_size=1, secondary_train_interval=0,
                  secondary_batch_size=1024, num_rays=1, graph=False, graph_bucket=256, graph_after=3,
@@ -173,7 +192,13 @@ class TrainStep:
         self._prefetch, self._trace_stream, self._trace_pool = [], None, []   # traces enqueued ahead: (input, ctx, event, checks)
         # the SDF value/gradient pass at the traced points: on the trace stream it sits on the step's critical path; in the
         # tail (default) it runs beside the next trace (config 2: 5.2 vs 5.45 ms per step)
-        self.surface_in_tail = os.environ.get('NEFII_SURFACE_IN_TAIL', '1') == '1'
+        # - for batches traced one at a time.  Small batches traced in groups (trace_group_for) are bound by the serial chain of
+        # the tail on the caller's stream: their pass runs on the trace stream, with four groups in flight on four streams
+        # (config 1: 1.40 -> 1.08 ms per step together with the hit index computed ahead, _hit_index_ahead).
+        # NEFII_SURFACE_IN_TAIL = 0 / 1 overrides for both
+        env = os.environ.get('NEFII_SURFACE_IN_TAIL')
+        self.surface_in_tail = True if env is None else env == '1'
+        self.surface_in_tail_grouped = False if env is None else env == '1'
         kw = dict(fused=fused, capturable=True) if self.graph else dict(fused=fused)
         if self.graph:      # a captured Adam reads its learning rate from device memory: the schedulers fill it in place
             dev = next(model.parameters()).device
@@ -297,13 +322,14 @@ class TrainStep:
 
     def preferred_lookahead(self, model_input):
         """Upcoming batches a caller should hand to __call__ (next_input): three traces in flight for big batches; for
-        grouped traces two groups minus one, so that a group is enqueued while a whole traced group is still waiting."""
+        grouped traces four groups minus one: a group is enqueued while three whole traced groups are in flight or waiting (their
+        rounds are all latency; config 1: 1.25 ms per step with two groups, 1.08 with four)."""
         g = self.trace_group_for(model_input)
-        return 3 if g <= 1 else 2 * g - 1
+        return 3 if g <= 1 else 4 * g - 1
 
-    def _trace_stream_next(self, after):
+    def _trace_stream_next(self, after, grouped=False):
         if self._trace_stream is None:
-            n = max(1, int(os.environ.get('NEFII_TRACE_STREAMS', '3')))
+            n = max(1, int(os.environ.get('NEFII_TRACE_STREAMS', '4' if grouped else '3')))
             self._trace_pool = [torch.cuda.Stream() for _ in range(n)]
         self._trace_pool.append(self._trace_pool.pop(0))
         self._trace_stream = self._trace_pool[0]
@@ -317,16 +343,17 @@ class TrainStep:
             return self.prefetch_trace(inputs[0], after)
         if not (m.training and getattr(m, 'state_freeze_geo', False) and next(m.parameters()).is_cuda):
             return
-        st = self._trace_stream_next(after)
+        st = self._trace_stream_next(after, grouped=True)
         checks = []
         with torch.cuda.stream(st):
             m.ray_tracer.deferred_checks = checks
             m.ray_tracer.concurrent = True
             try:
                 ctxs = m.trace_points_group(inputs)
-                if not self.surface_in_tail:
-                    for c in ctxs:
+                for c in ctxs:
+                    if not self.surface_in_tail_grouped:
                         m.attach_surface(c)
+                    _hit_index_ahead(c)
             finally:
                 m.ray_tracer.deferred_checks = None
                 m.ray_tracer.concurrent = False
@@ -354,6 +381,7 @@ class TrainStep:
             m.ray_tracer.concurrent = True
             try:
                 ctx = m.trace_points(model_input) if self.surface_in_tail else m.trace_head(model_input)
+                _hit_index_ahead(ctx)
             finally:
                 m.ray_tracer.deferred_checks = None
                 m.ray_tracer.concurrent = False
@@ -381,17 +409,19 @@ class TrainStep:
                     for g, c in enumerate(group):
                         c['points'], c['network_object_mask'] = more[0][g * S:(g + 1) * S], more[1][g * S:(g + 1) * S]
                         c.pop('pre', None)
+                        c.pop('hit_idx_all', None)
             if grp is not None:
                 grp['done'] = True
         for v in list(ctx.values()) + list(ctx.get('pre') or ()):
-            if torch.is_tensor(v):
+            if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(cur)          # allocated on the trace stream, consumed here
         return ctx if 'pre' in ctx else self.model.attach_surface(ctx)
 
     def _graph_step(self, model_input, ground_truth, ctx=None):
         if ctx is None:
             ctx = self.model.trace_head(model_input)
-        idx = torch.nonzero(ctx['network_object_mask']).flatten()      # the step's one host sync
+        idx = _hit_index(ctx)      # no host sync for a trace enqueued ahead; torch.nonzero (the step's one sync) otherwise
+        ctx = {k: v for k, v in ctx.items() if k not in ('hit_idx_all', 'hit_count_host')}
         n_hit, n_all = idx.numel(), ctx['points'].shape[0]
         if n_hit == 0:
             return None
@@ -458,7 +488,7 @@ class TrainStep:
                 return res
         self._eager_steps += 1
         if ctx is not None:
-            out = self.model.shade_tail(ctx, torch.nonzero(ctx['network_object_mask']).flatten())
+            out = self.model.shade_tail(ctx, _hit_index(ctx))
         else:
             out = self.model(model_input)
         lo = self.loss(out, ground_truth)
