@@ -484,10 +484,18 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
             run(everyone, 0, guess)
             join()
             if deferred is not None:
+                # the counters travel to pinned host memory behind the enqueued rounds, on the stream of the trace: the
+                # check then reads them without a copy on the CALLER'S stream (which would wait for whatever that stream
+                # still has to run - the previous step's tail)
+                ahead = None
+                if os.environ.get('NEFII_COUNTERS_AHEAD', '1') != '0':
+                    ahead = torch.empty(counters.shape, dtype=counters.dtype, pin_memory=True)
+                    ahead.copy_(counters, non_blocking=True)
+
                 def check():
                     """call once the enqueued prefix has completed: None if it was the whole trace, else the remaining
                     rounds are run (same streams, same workspaces) and the refreshed (points, hit, dists) returned"""
-                    host = counters.cpu()
+                    host = ahead if ahead is not None else counters.cpu()
                     again = [g for g in everyone if guess < rounds and int(host[g, guess - 1, _WORK].sum()) > 0]
                     if again:
                         run(again, guess, 0)
