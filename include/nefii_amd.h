@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 7
+#define NEFII_ABI_VERSION 8
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -351,6 +351,27 @@ typedef struct nefii_loss_params {
 int nefii_idr_loss(const nefii_loss_params *h_params, const float *idr_rgb, const float *sg_rgb, const float *rgb_gt,
                    const uint8_t *network_object_mask, const uint8_t *object_mask, const float *sdf_output,
                    const float *normals, int64_t n, float *losses, float *d_idr_rgb, float *d_sg_rgb, void *stream);
+
+/* Assembly of the per-ray output buffers of IDRNetwork.forward (implicit_differentiable_renderer.py:441-501): the reference
+ * allocates eight [n_rays, C] buffers of ones / zeros and writes the shaded hit rays into them by boolean mask, one pair of
+ * launches per buffer.  Here: all buffers in two launches.  Block b: dst [rows, cols] is filled with `fill`, then row
+ * where[i] takes row i of src (src_row_stride floats apart: cols, or 0 for one row broadcast to every hit), i < n_src.
+ * Several i may name the same row (the graph step pads its hit list with a scratch row): any of them wins.
+ * nefii_gather_rows is the adjoint: dst [n_src, cols] <- src[where[i]] (src [rows, cols]: the gradient of an assembled
+ * buffer; a block with a NULL src or dst is skipped). */
+#define NEFII_MAX_ROW_BLOCKS 12
+typedef struct nefii_row_block {
+    const float *src;
+    float *dst;
+    int32_t cols;
+    int32_t src_row_stride;
+    float fill;
+    int32_t reserved;
+} nefii_row_block;
+int nefii_assemble_rows(const nefii_row_block *h_blocks, int n_blocks, const int64_t *where, int64_t n_src, int64_t rows,
+                        void *stream);
+int nefii_gather_rows(const nefii_row_block *h_blocks, int n_blocks, const int64_t *where, int64_t n_src, int64_t rows,
+                      void *stream);
 
 #ifdef __cplusplus
 }

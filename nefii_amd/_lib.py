@@ -14,7 +14,7 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 7
+ABI_VERSION = 8
 TRACE_COUNTERS = 8          # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
@@ -48,6 +48,14 @@ class PackSource(ctypes.Structure):
     _fields_ = [('W', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('n_out', ctypes.c_int32), ('k_in', ctypes.c_int32),
                 ('x_src0', ctypes.c_int32), ('x_len', ctypes.c_int32), ('e_src0', ctypes.c_int32), ('e_len', ctypes.c_int32),
                 ('scale', ctypes.c_float), ('skip_f32', ctypes.c_int32)]
+
+
+class RowBlock(ctypes.Structure):
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('cols', ctypes.c_int32), ('src_row_stride', ctypes.c_int32),
+                ('fill', ctypes.c_float), ('reserved', ctypes.c_int32)]
+
+
+MAX_ROW_BLOCKS = 12
 
 
 class LossParams(ctypes.Structure):
@@ -100,6 +108,8 @@ SIGNATURES = {
     'nefii_trace_profile_launches': (I, [ctypes.POINTER(ctypes.c_float), I]),
     'nefii_idr_loss': (I, [ctypes.POINTER(LossParams), P, P, P, P, P, P, P, I64, P, P, P, P]),
     'nefii_camera_rays': (I, [P, P, P, I, I64, P, P, P]),
+    'nefii_assemble_rows': (I, [ctypes.POINTER(RowBlock), I, P, I64, I64, P]),
+    'nefii_gather_rows': (I, [ctypes.POINTER(RowBlock), I, P, I64, I64, P]),
     'nefii_sg_render_forward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P]),
     'nefii_sg_render_backward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P, P, P, P, P]),
     'nefii_env_radiance_forward': (I, [P, I, P, I64, F, P, P]),

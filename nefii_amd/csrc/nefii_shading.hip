@@ -947,3 +947,91 @@ extern "C" int nefii_idr_loss(const nefii_loss_params *h_params, const float *id
     HIP_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ---- output assembly (include/nefii_amd.h: nefii_assemble_rows / nefii_gather_rows) ---------------------------------
+namespace {
+struct RowBlocks {
+    nefii_row_block b[NEFII_MAX_ROW_BLOCKS];
+};
+
+// blockIdx.y = block; grid.x strides over the elements of the block's destination
+__global__ __launch_bounds__(256) void fill_rows_kernel(RowBlocks blocks, int64_t rows) {
+    const nefii_row_block B = blocks.b[blockIdx.y];
+    if (!B.dst) return;
+    const int64_t total = rows * B.cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+        B.dst[i] = B.fill;
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(RowBlocks blocks, const int64_t *__restrict__ where, int64_t n_src,
+                                                           int64_t rows) {
+    const nefii_row_block B = blocks.b[blockIdx.y];
+    if (!B.dst || !B.src) return;
+    const int64_t total = n_src * B.cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / B.cols, c = i - r * B.cols, w = where[r];
+        if (w >= 0 && w < rows) B.dst[w * B.cols + c] = B.src[r * B.src_row_stride + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(RowBlocks blocks, const int64_t *__restrict__ where, int64_t n_src,
+                                                          int64_t rows) {
+    const nefii_row_block B = blocks.b[blockIdx.y];
+    if (!B.dst || !B.src) return;
+    const int64_t total = n_src * B.cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / B.cols, c = i - r * B.cols, w = where[r];
+        B.dst[i] = (w >= 0 && w < rows) ? B.src[w * B.cols + c] : 0.f;
+    }
+}
+
+int check_blocks(const nefii_row_block *h, int n_blocks, RowBlocks &out, int &max_cols) {
+    if (!h || n_blocks < 1 || n_blocks > NEFII_MAX_ROW_BLOCKS) return NEFII_E_ARG;
+    max_cols = 1;
+    for (int i = 0; i < NEFII_MAX_ROW_BLOCKS; ++i) {
+        if (i < n_blocks) {
+            if (h[i].cols < 1 || h[i].src_row_stride < 0) return NEFII_E_SHAPE;
+            out.b[i] = h[i];
+            max_cols = h[i].cols > max_cols ? h[i].cols : max_cols;
+        } else {
+            out.b[i] = nefii_row_block{nullptr, nullptr, 1, 0, 0.f, 0};
+        }
+    }
+    return 0;
+}
+
+unsigned grid_for(int64_t elems) {
+    const int64_t g = (elems + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > 1024 ? 1024 : g));
+}
+}  // namespace
+
+extern "C" int nefii_assemble_rows(const nefii_row_block *h_blocks, int n_blocks, const int64_t *where, int64_t n_src,
+                                   int64_t rows, void *stream) {
+    RowBlocks blocks;
+    int max_cols;
+    const int rc = check_blocks(h_blocks, n_blocks, blocks, max_cols);
+    if (rc) return rc;
+    if (rows < 1 || n_src < 0 || (n_src > 0 && !where)) return NEFII_E_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(grid_for(rows * max_cols), n_blocks), dim3(256), 0, st, blocks, rows);
+    if (n_src > 0)
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(n_src * max_cols), n_blocks), dim3(256), 0, st, blocks, where,
+                           n_src, rows);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nefii_gather_rows(const nefii_row_block *h_blocks, int n_blocks, const int64_t *where, int64_t n_src,
+                                 int64_t rows, void *stream) {
+    RowBlocks blocks;
+    int max_cols;
+    const int rc = check_blocks(h_blocks, n_blocks, blocks, max_cols);
+    if (rc) return rc;
+    if (rows < 1 || n_src < 1 || !where) return NEFII_E_SHAPE;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n_src * max_cols), n_blocks), dim3(256), 0, (hipStream_t)stream,
+                       blocks, where, n_src, rows);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}

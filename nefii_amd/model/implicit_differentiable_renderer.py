@@ -397,31 +397,23 @@ class IDRNetwork(nn.Module):
         n_all = points.shape[0]
         rows = n_all + (1 if dst is not None else 0)
         dev = points.device
-        def ones():
-            return torch.ones(rows, 3, device=dev)
-        out = {'idr_rgb_values': ones(), 'sg_rgb_values': ones(), 'normal_values': ones(),
-               'sg_diffuse_rgb_values': ones(), 'sg_diffuse_albedo_values': ones(),
-               'sg_specular_rgb_values': torch.zeros(rows, 3, device=dev),
-               'sg_roughness_values': torch.zeros(rows, 1, device=dev),
-               'sg_specular_reflection_values': torch.zeros(rows, 3, device=dev)}
+        # (output buffer, get_rbg_value's key, columns, value of the rays without a hit: :441-448)
+        layout = (('idr_rgb_values', 'idr_rgb', 3, 1.0), ('sg_rgb_values', 'sg_rgb', 3, 1.0), ('normal_values', 'normals', 3, 1.0),
+                  ('sg_diffuse_rgb_values', 'sg_diffuse_rgb', 3, 1.0), ('sg_diffuse_albedo_values', 'sg_diffuse_albedo', 3, 1.0),
+                  ('sg_specular_rgb_values', 'sg_specular_rgb', 3, 0.0), ('sg_roughness_values', 'sg_roughness', 1, 0.0),
+                  ('sg_specular_reflection_values', 'sg_specular_reflectance', 3, 0.0))
         ret = {}
         if idx.numel() > 0:
             if pre is not None:
                 pre = (None, pre[1].index_select(0, idx) if pre[1] is not None else None, pre[2].index_select(0, idx))
             ret = self.get_rbg_value(points.index_select(0, idx), -ray_dirs.index_select(0, idx), surface=pre)
             where = idx if dst is None else dst
-
-            def put(key, src):
-                src = src.expand(idx.shape[0], out[key].shape[1]).to(out[key].dtype)
-                out[key] = out[key].index_put((where,), src)
-            put('idr_rgb_values', ret['idr_rgb'])
-            put('sg_rgb_values', ret['sg_rgb'])
-            put('normal_values', ret['normals'])
-            put('sg_diffuse_rgb_values', ret['sg_diffuse_rgb'])
-            put('sg_diffuse_albedo_values', ret['sg_diffuse_albedo'])
-            put('sg_specular_rgb_values', ret['sg_specular_rgb'])
-            put('sg_roughness_values', ret['sg_roughness'])
-            put('sg_specular_reflection_values', ret['sg_specular_reflectance'])
+            # all eight buffers in two launches (+ one for all their gradients) instead of fill / expand / index_put each
+            bufs = ops.assemble_rows(where, rows, [f for _, _, _, f in layout], [c for _, _, c, _ in layout],
+                                     [ret[k] for _, k, _, _ in layout])
+            out = {name: b for (name, _, _, _), b in zip(layout, bufs)}
+        else:
+            out = {name: torch.full((rows, c), f, device=dev) for name, _, c, f in layout}
         if dst is not None:
             out = {k: v[:n_all] for k, v in out.items()}
         if self.render_background:

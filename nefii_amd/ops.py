@@ -232,11 +232,17 @@ class FusedMLPFn(torch.autograd.Function):
                               feat if feat is not None else in_a.new_empty(0),
                               stash if stash is not None else in_a.new_empty(0))
         ctx.has = (in_b is not None, in_c is not None, feat is not None)
+        # an output that nothing differentiable reads (physg.conf weights the radiance colour with 0 and the loss detaches it)
+        # may still be reachable in the autograd graph through a node it shares with other outputs (AssembleRowsFn): its
+        # backward then arrives with None and must not run on materialised zeros
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         pm = ctx.pm
+        if d_out is None:
+            return (None,) * (5 + 2 * pm.n_layers)
         in_a, in_b, in_c, feat, stash = ctx.saved_tensors
         in_b = in_b if ctx.has[0] else None
         in_c = in_c if ctx.has[1] else None
@@ -288,6 +294,7 @@ class FusedMLPHiddenFn(torch.autograd.Function):
         ctx.save_for_backward(in_a, empty, empty, empty, stash if stash is not None else empty)
         ctx.has = (False, False, False)
         ctx.mark_non_differentiable(hidden)
+        ctx.set_materialize_grads(False)
         return out, hidden
 
     @staticmethod
@@ -536,6 +543,68 @@ def camera_rays(uv, pose, intrinsics):
     return dirs, orig
 
 
+class AssembleRowsFn(torch.autograd.Function):
+    """Per-ray output buffers in two launches (include/nefii_amd.h: nefii_assemble_rows): output k is a [rows, cols[k]]
+    buffer of fills[k] whose rows where[i] take row i of srcs[k] ([n, cols[k]], or [1, cols[k]] / [n, 1] broadcast).
+    Backward: one launch gathers the rows of every output gradient that exists."""
+
+    @staticmethod
+    def forward(ctx, where, rows, fills, cols, *srcs):
+        lib = _lib.lib()
+        n = where.shape[0]
+        dev = where.device
+        blocks = (_lib.RowBlock * len(srcs))()
+        outs, keep, shapes = [], [], []
+        for k, src in enumerate(srcs):
+            shapes.append(tuple(src.shape))
+            s = _f32(src)
+            if s.shape[-1] != cols[k]:          # a column broadcast ([n, 1] -> [n, C]) is materialised; a row broadcast is a stride
+                s = s.expand(s.shape[0], cols[k]).contiguous()
+            keep.append(s)
+            out = torch.empty(rows, cols[k], device=dev, dtype=torch.float32)
+            outs.append(out)
+            blocks[k] = _lib.RowBlock(_ptr(s), _ptr(out), cols[k], 0 if s.shape[0] == 1 and n != 1 else cols[k], float(fills[k]), 0)
+        _lib.check(lib.nefii_assemble_rows(blocks, len(srcs), _ptr(where), n, rows, _stream()), 'nefii_assemble_rows')
+        ctx.save_for_backward(where)
+        ctx.meta = (rows, tuple(cols), shapes)
+        ctx.set_materialize_grads(False)        # a buffer the loss does not read sends None back, not zeros
+        # a buffer assembled from constants (normals, points of frozen geometry) is a constant: without this every output of
+        # the node would require grad because some other does
+        ctx.mark_non_differentiable(*[o for k, o in enumerate(outs) if not ctx.needs_input_grad[4 + k]])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.lib()
+        where, = ctx.saved_tensors
+        rows, cols, shapes = ctx.meta
+        n = where.shape[0]
+        blocks = (_lib.RowBlock * len(grads))()
+        res, keep = [], []
+        for k, g in enumerate(grads):
+            if g is None or not ctx.needs_input_grad[4 + k]:
+                blocks[k] = _lib.RowBlock(None, None, cols[k], cols[k], 0.0, 0)
+                res.append(None)
+                continue
+            gc = _f32(g)
+            keep.append(gc)
+            d = torch.empty(n, cols[k], device=where.device, dtype=torch.float32)
+            blocks[k] = _lib.RowBlock(_ptr(gc), _ptr(d), cols[k], cols[k], 0.0, 0)
+            res.append(d)
+        if any(r is not None for r in res) and n > 0:
+            _lib.check(lib.nefii_gather_rows(blocks, len(grads), _ptr(where), n, rows, _stream()), 'nefii_gather_rows')
+        for k, r in enumerate(res):             # undo the broadcasts of forward
+            if r is not None and tuple(r.shape) != shapes[k]:
+                r = r.sum(dim=0, keepdim=True) if shapes[k][0] == 1 and n != 1 else r
+                r = r.sum(dim=1, keepdim=True) if shapes[k][-1] == 1 and cols[k] != 1 else r
+                res[k] = r.reshape(shapes[k])
+        return (None, None, None, None) + tuple(res)
+
+
+def assemble_rows(where, rows, fills, cols, srcs):
+    return AssembleRowsFn.apply(where, int(rows), tuple(fills), tuple(cols), *srcs)
+
+
 class SGRenderFn(torch.autograd.Function):
     """render_with_sg for one base material; differentiable wrt lgtSGs, specular, roughness, albedo."""
 
@@ -552,6 +621,7 @@ class SGRenderFn(torch.autograd.Function):
                                                _stream()), 'nefii_sg_render_forward')
         ctx.save_for_backward(lgt_c, spec_c, rough_c, albedo_c, normal_c, view_c)
         ctx.spec_shape = tuple(spec.shape)
+        ctx.set_materialize_grads(False)        # the specular / diffuse parts usually take no part in the loss: NULL, not zeros
         return rgb, srgb, drgb
 
     @staticmethod
@@ -559,10 +629,13 @@ class SGRenderFn(torch.autograd.Function):
         lib = _lib.lib()
         lgt, spec, rough, albedo, normal, view = ctx.saved_tensors
         n = normal.shape[0]
+        if d_rgb is None and d_s is None and d_d is None:
+            return None, None, None, None, None, None
         g_alb = torch.empty_like(albedo)
-        g_rough = torch.zeros(1, 1, device=albedo.device, dtype=torch.float32)
-        g_spec = torch.zeros(1, 3, device=albedo.device, dtype=torch.float32)
-        g_lgt = torch.zeros_like(lgt)
+        acc = torch.zeros(4 + lgt.numel(), device=albedo.device, dtype=torch.float32)      # the accumulators: one fill
+        g_rough, g_spec, g_lgt = acc[0:1].view(1, 1), acc[1:4].view(1, 3), acc[4:].view_as(lgt)
+        if d_rgb is None:
+            d_rgb = torch.zeros(n, 3, device=albedo.device, dtype=torch.float32)
         d_rgb, d_s, d_d = _f32(d_rgb), _f32(d_s), _f32(d_d)     # keep converted copies alive across the launch call
         _lib.check(lib.nefii_sg_render_backward(_ptr(lgt), lgt.shape[0], _ptr(spec), _ptr(rough), _ptr(albedo),
                                                 _ptr(normal), _ptr(view), n, _ptr(d_rgb), _ptr(d_s),

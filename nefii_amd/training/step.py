@@ -119,17 +119,26 @@ class _StepGraph:
         self.lo = _detached(self.lo)
 
     def load(self, ctx, idx_pad, dst_pad, ground_truth):
+        dsts, srcs = [self.idx, self.dst], [idx_pad, dst_pad]
         for k, v in ctx.items():
             if k == 'pre' and v is not None:
                 for d, t in zip(self.static_ctx['pre'], v):
                     if t is not None:
-                        d.copy_(t)
+                        dsts.append(d), srcs.append(t)
             elif torch.is_tensor(v):
-                self.static_ctx[k].copy_(v)
-        self.idx.copy_(idx_pad)
-        self.dst.copy_(dst_pad)
+                dsts.append(self.static_ctx[k]), srcs.append(v)
         for k, v in self.gt.items():
-            v.copy_(ground_truth[k])
+            dsts.append(v), srcs.append(ground_truth[k])
+        # one multi-tensor launch per dtype instead of a dozen copies
+        by_type = {}
+        for d, t in zip(dsts, srcs):
+            if d.dtype == t.dtype and d.shape == t.shape and d.is_contiguous() and t.is_contiguous():
+                by_type.setdefault(d.dtype, ([], []))
+                by_type[d.dtype][0].append(d), by_type[d.dtype][1].append(t)
+            else:
+                d.copy_(t)
+        for ds, ts in by_type.values():
+            torch._foreach_copy_(ds, ts)
 
 
 def _hit_index_ahead(ctx):
@@ -139,6 +148,9 @@ def _hit_index_ahead(ctx):
     mask = ctx['network_object_mask']
     n_all = mask.shape[0]
     ctx['hit_idx_all'] = torch.nonzero_static(mask, size=n_all, fill_value=n_all).flatten()
+    # the same list with its padding pointing at a ray that exists: what the graph step gathers FROM (it scatters TO the list
+    # above, whose padding names the scratch row n_all)
+    ctx['hit_idx_src'] = ctx['hit_idx_all'].clamp(max=n_all - 1)
     host = torch.empty(1, dtype=torch.int64, pin_memory=True)
     host.copy_(mask.sum(dtype=torch.int64).reshape(1), non_blocking=True)
     ctx['hit_count_host'] = host
@@ -185,6 +197,7 @@ class TrainStep:
         # implementation of the identical update when the parameters live on the GPU
         fused = next(model.parameters()).is_cuda
         self._fused = fused
+        self._found = self._one = None
         self.graph = bool(graph) and fused and getattr(model, 'render_type', None) == 'sg'
         self.graph_bucket, self.graph_after = int(graph_bucket), int(graph_after)
         self._graphs = {}
@@ -225,26 +238,39 @@ class TrainStep:
         zeroes its gradients and both optimizers skip the step: parameters, moments and step counters are those of the
         last good iteration, so the emergency checkpoint the runner writes is the pre-NaN state.  The flag travels in
         the gradient all-reduce: one collective, no host sync."""
-        bad = (~torch.isfinite(loss.detach())).reshape(1).to(torch.float32)
         grads = [p.grad for p in self.trainable if p.grad is not None]
-        if grads:       # a finite loss can still come with a non-finite gradient (0 x inf in some backward): same treatment
-            norms = torch.stack(torch._foreach_norm(grads))
-            bad = bad + (~torch.isfinite(norms).all()).reshape(1).to(torch.float32)
+        if self._fused:
+            # one multi-tensor kernel (the one torch.amp.GradScaler unscales with; scale 1.0 leaves every value as it is)
+            # instead of isfinite(loss) + foreach_norm + isfinite(norms): 2 launches instead of ~25 in the step's tail
+            if self._found is None:
+                self._found = torch.zeros((), device=loss.device, dtype=torch.float32)
+                self._one = torch.ones((), device=loss.device, dtype=torch.float32)
+            self._found.zero_()
+            torch._amp_foreach_non_finite_check_and_unscale_(grads + [loss.detach().reshape(1).clone()], self._found, self._one)
+            bad = self._found.reshape(1)
+        else:
+            bad = (~torch.isfinite(loss.detach())).reshape(1).to(torch.float32)
+            if grads:   # a finite loss can still come with a non-finite gradient (0 x inf in some backward): same treatment
+                norms = torch.stack(torch._foreach_norm(grads))
+                bad = bad + (~torch.isfinite(norms).all()).reshape(1).to(torch.float32)
         if self.world_size > 1:
             _, bad = allreduce_mean_gradients(self.trainable, self.world_size, flags=bad)
-        bad = bad.reshape(()) > 0
-        if not self._fused:         # (the fused Adam below skips by flag: no need to touch the gradients, 13+ launches less)
-            for p in self.trainable:
+        if self._fused:             # the flag stays a float 0 / 1 on the device: no compare / cast launches
+            bad = bad.reshape(()).clamp(max=1.0) if self.world_size > 1 else bad.reshape(())
+            self.nonfinite_steps += bad
+        else:
+            bad = bad.reshape(()) > 0
+            for p in self.trainable:        # (the fused Adam skips by flag: no need to touch the gradients there)
                 if p.grad is not None:
                     p.grad.masked_fill_(bad, 0.0)
-        self.nonfinite_steps += bad.to(self.nonfinite_steps.dtype)
+            self.nonfinite_steps += bad.to(self.nonfinite_steps.dtype)
         # ... and the optimizers SKIP the step (zero gradients alone would still move the parameters by the first
         # moment, decay both moments and advance the step counters).  On the GPU the fused Adam takes the flag the way
         # torch.amp.GradScaler hands it over (optimizer.found_inf: the kernel leaves parameters and moments alone and
         # the step counter is taken back) - on the device, capturable; the CPU implementation (multi-process gloo tests)
         # has no such input, there the flag is read.
         if self._fused:
-            self.idr_optimizer.found_inf = self.sg_optimizer.found_inf = bad.to(torch.float32)
+            self.idr_optimizer.found_inf = self.sg_optimizer.found_inf = bad
             self.idr_optimizer.step()
             self.sg_optimizer.step()
         elif not bool(bad):
@@ -410,6 +436,7 @@ class TrainStep:
                         c['points'], c['network_object_mask'] = more[0][g * S:(g + 1) * S], more[1][g * S:(g + 1) * S]
                         c.pop('pre', None)
                         c.pop('hit_idx_all', None)
+                        c.pop('hit_idx_src', None)
             if grp is not None:
                 grp['done'] = True
         for v in list(ctx.values()) + list(ctx.get('pre') or ()):
@@ -421,14 +448,17 @@ class TrainStep:
         if ctx is None:
             ctx = self.model.trace_head(model_input)
         idx = _hit_index(ctx)      # no host sync for a trace enqueued ahead; torch.nonzero (the step's one sync) otherwise
-        ctx = {k: v for k, v in ctx.items() if k not in ('hit_idx_all', 'hit_count_host')}
         n_hit, n_all = idx.numel(), ctx['points'].shape[0]
         if n_hit == 0:
             return None
         P = -(-n_hit // self.graph_bucket) * self.graph_bucket
         pad = P - n_hit
-        idx_pad = torch.cat([idx, idx[:1].expand(pad)]) if pad else idx
-        dst_pad = torch.cat([idx, idx.new_full((pad,), n_all)]) if pad else idx
+        if 'hit_idx_all' in ctx and P <= n_all:      # padded lists prepared on the trace stream: views, no launch
+            idx_pad, dst_pad = ctx['hit_idx_src'][:P], ctx['hit_idx_all'][:P]
+        else:
+            idx_pad = torch.cat([idx, idx[:1].expand(pad)]) if pad else idx
+            dst_pad = torch.cat([idx, idx.new_full((pad,), n_all)]) if pad else idx
+        ctx = {k: v for k, v in ctx.items() if k not in ('hit_idx_all', 'hit_idx_src', 'hit_count_host')}
         mat = self.model.envmap_material_network
         # everything a capture bakes in: shapes, the python-side switches of the material network, the loss's alpha
         key = (P, n_all, bool(getattr(mat, 'fake_roughness', False)), bool(getattr(mat, 'fake_specular', False)),

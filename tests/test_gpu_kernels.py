@@ -905,3 +905,33 @@ def test_pipelined_evaluator_both_matrix_instructions(monkeypatch):
     same = (h0 == h1) & h0
     assert (d0[same] - d1[same]).abs().median().item() < 2e-6
     assert abs(int(c0.sum()) - int(c1.sum())) <= 0.01 * int(c0.sum())
+
+
+def test_assemble_rows_matches_index_put_forward_and_backward():
+    """nefii_assemble_rows / nefii_gather_rows against the fill + expand + index_put they replace (model: shade_tail), with a
+    row-broadcast source, a column-broadcast source, an output without gradient and a padded hit list (scratch row)."""
+    from nefii_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rows, n = 1001, 300
+    hit = torch.randperm(rows - 1, generator=g)[:n - 20].sort().values
+    where = torch.cat([hit, torch.full((20,), rows - 1)]).to(DEV)            # 20 padding entries -> the scratch row
+    fills, cols = [1.0, 0.0, 1.0, 0.0], [3, 1, 3, 3]
+    shapes = [(n, 3), (n, 1), (1, 3), (n, 1)]
+    srcs = [torch.randn(sh, generator=g).to(DEV).requires_grad_(True) for sh in shapes]
+    refs = [s.detach().clone().requires_grad_(True) for s in srcs]
+    outs = ops.assemble_rows(where, rows, fills, cols, srcs)
+    const = ops.assemble_rows(where, rows, fills[:2], cols[:2], [srcs[0], srcs[1].detach()])
+    assert const[0].requires_grad and not const[1].requires_grad        # a buffer of constants stays a constant
+    want = [torch.full((rows, c), f, device=DEV).index_put((where,), r.expand(n, c)) for r, c, f in zip(refs, cols, fills)]
+    for o, w in zip(outs, want):
+        assert torch.equal(o[:rows - 1], w[:rows - 1])
+    wts = [torch.randn(rows - 1, c, generator=g).to(DEV) for c in cols]
+    # output 1 takes no part in the loss: its gradient is None in backward
+    sum((o[:rows - 1] * w).sum() for k, (o, w) in enumerate(zip(outs, wts)) if k != 1).backward()
+    sum((o[:rows - 1] * w).sum() for k, (o, w) in enumerate(zip(want, wts)) if k != 1).backward()
+    assert srcs[1].grad is None
+    for k in (0, 2, 3):
+        assert srcs[k].grad.shape == refs[k].grad.shape
+        assert torch.allclose(srcs[k].grad, refs[k].grad, rtol=1e-6, atol=1e-6), k
+    empty = ops.assemble_rows(where[:0], 7, [2.0], [3], [torch.zeros(0, 3, device=DEV)])
+    assert torch.equal(empty[0], torch.full((7, 3), 2.0, device=DEV))

@@ -33,6 +33,8 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.Layer) == 16 + 5 * 8
     assert ctypes.sizeof(_lib.Mlp) == 40 + 12 * ctypes.sizeof(_lib.Layer)
     assert ctypes.sizeof(_lib.TracerParams) == 56         # 3 floats + 7 int32 + coarse_tau + coarse_cap + minsdf_group + small_round
+    assert ctypes.sizeof(_lib.RowBlock) == 32             # 2 pointers + cols + src_row_stride + fill + reserved
+    assert ctypes.sizeof(_lib.PackSource) == 48           # 2 pointers + 6 int32 + scale + skip_f32
 
 
 def test_host_side_argument_checks_need_no_gpu():
@@ -53,6 +55,10 @@ def test_host_side_argument_checks_need_no_gpu():
     assert lib.nefii_trace_rays_rounds(None, None, None, None, None, 0, None, None, None, None, None, None, 0, None, 0, 0,
                                        None) == -1
     assert lib.nefii_pack_linear(None, None, 1, 1, 0, 0, 0, 0, 1.0, None, None, None, None) == -1
+    assert lib.nefii_assemble_rows(None, 1, None, 0, 1, None) == -1 and lib.nefii_gather_rows(None, 1, None, 1, 1, None) == -1
+    blk = (_lib.RowBlock * 1)(_lib.RowBlock(None, None, 0, 0, 0.0, 0))
+    assert lib.nefii_assemble_rows(blk, 1, None, 0, 4, None) == -2          # zero columns
+    assert lib.nefii_assemble_rows(blk, _lib.MAX_ROW_BLOCKS + 1, None, 0, 4, None) == -1
 
 
 def test_ops_fail_loudly_without_gpu_tensor():
