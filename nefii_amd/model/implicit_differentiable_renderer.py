@@ -188,6 +188,10 @@ class RenderingNetwork(nn.Module):
                 lin = nn.utils.weight_norm(lin)
             setattr(self, 'lin' + str(l), lin)
         self._pm = None
+        # True: nothing differentiates this network's output in the current run (a training run whose loss weights the
+        # radiance colour with 0 - physg.conf - detaches it: training/step.py sets this) - forward then takes the no-grad path
+        self.outputs_detached = False
+        self._packed_for = None
 
     def packed(self, device):
         half = ops.mlp_precision() if ops.mlp_precision() in ('f16', 'f16x3') else False
@@ -196,12 +200,15 @@ class RenderingNetwork(nn.Module):
                                      half=half)
         return self._pm
 
-    def forward(self, points, normals, view_dirs, feature_vectors=None):
+    def _effective_weights(self):
         ws, bs = [], []
         for l in range(len(self.specs)):
             lin = getattr(self, 'lin' + str(l))
             ws.append(torch._weight_norm(lin.weight_v, lin.weight_g, 0) if self.weight_norm else lin.weight)
             bs.append(lin.bias)
+        return ws, bs
+
+    def forward(self, points, normals, view_dirs, feature_vectors=None):
         p, n, v = ops._f32(points), ops._f32(normals), ops._f32(view_dirs)
         if self.mode == 'idr':
             a, b, c = p, v, n
@@ -210,7 +217,19 @@ class RenderingNetwork(nn.Module):
         else:
             a, b, c = p, v, None
         feat = ops._f32(feature_vectors) if self.feature_vector_size > 0 else None
-        return ops.FusedMLPFn.apply(self.packed(p.device), a, b, c, feat, *ws, *bs)
+        pm = self.packed(p.device)
+        if self.outputs_detached or not torch.is_grad_enabled() or not any(q.requires_grad for q in self.parameters()):
+            # no gradient can reach the weights: weight norm and packing only when a parameter changed (never while the loss
+            # does not train this network; once per frame chunk in a render before) - 8 launches less per call
+            key = (_params_version(self), id(pm))
+            with torch.no_grad():
+                if self._packed_for != key:
+                    pm.pack(*self._effective_weights())
+                    self._packed_for = key
+                return ops.mlp_forward(pm, a, b, c, feat, want_stash=False)[0]
+        self._packed_for = None
+        ws, bs = self._effective_weights()
+        return ops.FusedMLPFn.apply(pm, a, b, c, feat, *ws, *bs)
 
 
 class IDRNetwork(nn.Module):

@@ -224,6 +224,12 @@ class TrainStep:
         self.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.sg_optimizer, list(sg_sched_milestones),
                                                                  gamma=sg_sched_factor)
         self.trainable = [p for p in model.parameters() if p.requires_grad]
+        # physg.conf weights the radiance colour with 0 and IDRLoss detaches it: the radiance network then runs without
+        # autograd, weight norm and repacking (its weights never change).  Not with the secondary-consistency step, whose own
+        # loss reads the radiance colour
+        rn = getattr(model, 'rendering_network', None)
+        if rn is not None and hasattr(rn, 'outputs_detached'):
+            rn.outputs_detached = bool(self.loss.idr_rgb_weight == 0 and secondary_train_interval == 0)
         # steps whose loss was not finite on some rank: their gradients were zeroed on every rank before Adam ran
         # (device counter: the runner reads it at its logging points only)
         self.nonfinite_steps = torch.zeros((), device=next(model.parameters()).device, dtype=torch.float32)
@@ -461,8 +467,12 @@ class TrainStep:
         ctx = {k: v for k, v in ctx.items() if k not in ('hit_idx_all', 'hit_idx_src', 'hit_count_host')}
         mat = self.model.envmap_material_network
         # everything a capture bakes in: shapes, the python-side switches of the material network, the loss's alpha
+        rn = self.model.rendering_network
+        # (a radiance network that runs without autograd is packed at capture time only: a capture is good for the parameter
+        # versions it saw - load_state_dict in the middle of a run gets a new one)
+        rver = sum(q._version for q in rn.parameters()) if getattr(rn, 'outputs_detached', False) else None
         key = (P, n_all, bool(getattr(mat, 'fake_roughness', False)), bool(getattr(mat, 'fake_specular', False)),
-               float(self.loss.alpha))
+               float(self.loss.alpha), rver)
         g = self._graphs.get(key)
         if g is None:
             g = self._graphs[key] = _StepGraph(self, ctx, idx_pad, dst_pad, ground_truth)
