@@ -12,7 +12,7 @@ all-reduce per step: weak scaling, `value` = all ranks' primary rays / max-over-
 
 Prints ONE JSON line (rank 0).  Beside the headline it carries, under "cfg3", the same measurement of BASELINE.json
 configs[2] (conf.conf model, 64 rays per pixel, MC direct + near-field indirect on the non-convex stand-in scene - what
-robot/run_s2.sh runs; it fills the chip where config 2 is launch-shaped) at min(K, 5) steps; --workload X measures X alone.
+robot/run_s2.sh runs; it fills the chip where config 2 is launch-shaped) at min(K, 10) steps (one secondary-consistency step - every 10th iteration - per timed repetition); --workload X measures X alone.
 
 `roofline` (recomputable from the numbers in the line): the tracer's SDF-evaluation kernels (eval_kernel16q: split
 precision, 3 fp16 MFMAs per product; eval_kernel16s: the single-pass coarse evaluator) against the dense fp16 MFMA peak
@@ -488,7 +488,7 @@ def main():
     if args.workload is None and not args.no_nested:
         near = run_workload('cfg2_near', args, max(1, min(args.steps, 20)), min(args.warmup, 3), rank, world, dev, backend, lib,
                             side=False)
-        nested = run_workload('cfg3', args, max(1, min(args.steps, 5)), min(args.warmup, 2), rank, world, dev, backend, lib,
+        nested = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 2), rank, world, dev, backend, lib,
                               side=False)
     if world > 1:
         dist.barrier()
