@@ -637,6 +637,37 @@ def test_prefetched_trace_gives_the_same_steps(graph, lookahead):
 
 
 @pytest.mark.gpu
+def test_steps_on_traces_enqueued_ahead_do_not_synchronise_the_callers_stream(monkeypatch):
+    """A graph step whose trace was enqueued ahead must not call torch.nonzero, Tensor.cpu or Tensor.item on the way (they
+    would wait for the previous step's tail on the caller's stream and keep the host from running ahead: round 3's config 1
+    spent half of its step there): hit lists, hit counts and the tracer's round counters arrive through pinned memory from
+    the trace stream.  Checked for config 1's shape (traces grouped three at a time) and config 2's (one at a time)."""
+    from nefii_amd.training.step import TrainStep
+    for name, pixels in (('cfg1', 512), ('cfg2', 4096)):
+        w = syn.WORKLOADS[name]
+        mc = syn.model_conf(w['model'])
+        m = build_model(mc, syn.make_state_dict(mc, seed=0), True)
+        inp, gt = syn.make_inputs(pixels, w['image_hw'], w['focal'], w['cam_pos'], -1, seed=1)
+        inp, gt = to_dev(inp), {'rgb': gt.to(DEV)}
+        st = TrainStep(m, syn.loss_conf(w['model']), graph=True)
+        nxt = [inp] * st.preferred_lookahead(inp)
+        for _ in range(12):                   # eager steps, the capture, the tracer's round guess settle
+            st(inp, gt, nxt)
+        torch.cuda.synchronize()
+        calls = []
+        real_nonzero, real_cpu, real_item = torch.nonzero, torch.Tensor.cpu, torch.Tensor.item
+        monkeypatch.setattr(torch, 'nonzero', lambda t, *a, **k: (calls.append('nonzero') if t.is_cuda else None, real_nonzero(t, *a, **k))[1])
+        monkeypatch.setattr(torch.Tensor, 'cpu', lambda t, *a, **k: (calls.append('cpu') if t.is_cuda else None, real_cpu(t, *a, **k))[1])
+        monkeypatch.setattr(torch.Tensor, 'item', lambda t: (calls.append('item') if t.is_cuda else None, real_item(t))[1])
+        for _ in range(9):
+            out, lo = st(inp, gt, nxt)
+        monkeypatch.undo()
+        torch.cuda.synchronize()
+        assert calls == [], (name, calls)
+        assert int(st.nonfinite_steps.item()) == 0 and torch.isfinite(lo['loss']).item()
+
+
+@pytest.mark.gpu
 def test_runner_on_a_scene_directory_with_exr_ground_truth(tmp_path):
     """The runner fed from an instance directory as the reference lays it out (cam_dict_norm.json, image/*.exr,
     mask/*.png) through `datasets.scene_dataset.SceneDataset`, the class name the reference's confs carry."""
