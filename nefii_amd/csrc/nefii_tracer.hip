@@ -28,7 +28,12 @@ namespace {
 
 // PH_SAMPLER_C / PH_MINSDF_C: the ray's n_steps samples are being evaluated by the single-pass (coarse) evaluator; the
 // exact phases PH_SAMPLER / PH_MINSDF follow once the samples that decide have been re-evaluated in split precision
-enum Phase : int { PH_DONE = 0, PH_TRACE = 1, PH_SAMPLER = 2, PH_BISECT = 3, PH_MINSDF = 4, PH_SAMPLER_C = 5, PH_MINSDF_C = 6 };
+// PH_SAMPLER_X: the bracket search's FIRST `chunk` samples are being evaluated in split precision (through the refine
+// list) before anything else: sphere tracing stops right in front of the surface, so the first negative sample is one of the
+// first few for most rays that have one (median index 1-3 of 100 on the bench scenes) - and the reference's decision then
+// depends on no later sample.  A ray without a negative sample among them goes on to PH_SAMPLER_C as before.
+enum Phase : int { PH_DONE = 0, PH_TRACE = 1, PH_SAMPLER = 2, PH_BISECT = 3, PH_MINSDF = 4, PH_SAMPLER_C = 5, PH_MINSDF_C = 6,
+                   PH_SAMPLER_X = 7 };
 constexpr int PH_POST = 100;      // local to advance_kernel: the stage behind tracing / sampler / bisection
 constexpr int NCNT = NEFII_TRACE_COUNTERS;
 enum Kind : int { Q_START = 0, Q_END = 1, Q_MID = 2 };
@@ -68,6 +73,7 @@ struct Params {
     int levels, tri_nodes;   // speculative bisection: levels per round, nodes = 2^levels - 1
     float tau;               // coarse pass: error bound of a coarse sample (0: coarse pass off)
     int cap;                 //              most samples of one ray refined individually
+    int chunk;               //              leading samples of a bracket search evaluated exactly first (0: off)
     RayState s;
 };
 
@@ -278,9 +284,17 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                     // coarse pass's error bound nearly every sample would have to be refined, and the samples go to the
                     // split evaluator directly (a performance choice only: either way decides from exact values)
                     const bool go_coarse = coarse && 0.5f * (cur_s + cur_e + (t_e - t_s)) > 3.f * P.tau;
-                    fl |= go_coarse ? PH_SAMPLER_C : PH_SAMPLER;
-                    qd = !go_coarse;
-                    qc = go_coarse;
+                    // inside the object mask (outside it the argmin over ALL samples is the result) the first `chunk`
+                    // samples go ahead in split precision: PH_SAMPLER_X
+                    if (go_coarse && P.chunk > 0 && P.obj[r] != 0) {
+                        fl |= PH_SAMPLER_X;
+                        n_ref = P.chunk;
+                        cmask[0] = (1u << P.chunk) - 1u;
+                    } else {
+                        fl |= go_coarse ? PH_SAMPLER_C : PH_SAMPLER;
+                        qd = !go_coarse;
+                        qc = go_coarse;
+                    }
                     n_alg = 1;
                     dense_which = 0;
                     P.s.flags[r] = fl;
@@ -318,6 +332,29 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             P.s.cur_e[r] = cur_e;
             P.s.nxt_s[r] = nxt_s;
             P.s.nxt_e[r] = nxt_e;
+            P.s.flags[r] = fl;
+            ph = -1;
+        }
+    }
+
+    if (valid && ph == PH_SAMPLER_X) {
+        // the first `chunk` samples hold EXACT values.  A negative one among them at index >= 1 (index 0 would pair with
+        // the LAST sample, ray_tracing.py:245-246) settles the search: `ind` is the first negative sample, the bracket is
+        // (ind - 1, ind), the ray has a hit inside the object mask, so neither the argmin nor any later sample is read -
+        // the exact stage below runs on these values with the rest of the row out of the way.  Otherwise: all n_steps
+        // samples through the coarse evaluator, as if this stage had not been.
+        const int ns = tp.n_steps;
+        float *v = P.s.big + (size_t)r * ns;
+        int ind = -1;
+        for (int i = 0; i < P.chunk; ++i)
+            if (v[i] < 0.f && ind < 0) ind = i;
+        if (ind >= 1) {
+            for (int i = P.chunk; i < ns; ++i) v[i] = 3.0e38f;
+            ph = PH_SAMPLER;
+        } else {
+            fl = (fl & ~F_PHASE) | PH_SAMPLER_C;
+            qc = true;
+            dense_which = 0;
             P.s.flags[r] = fl;
             ph = -1;
         }
@@ -1777,8 +1814,9 @@ extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     // initial eval + iters*(step + back-offs) -> sampler -> bisection (L levels per round) -> min-SDF -> bookkeeping
     // with the coarse pass each of the two dense searches takes one round more (coarse samples -> refined samples)
     const int L = p->bisect_levels >= 1 && p->bisect_levels <= 5 ? p->bisect_levels : 3;
+    // ... and the bracket search one more for the rays whose leading samples (evaluated exactly first) hold no negative one
     return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + (p->n_rootfind_steps + L - 1) / L + 1 + 2 +
-           (p->coarse_tau > 0.f ? 2 : 0);
+           (p->coarse_tau > 0.f ? 3 : 0);
 }
 
 extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *p) {
@@ -1848,6 +1886,12 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     if (h_params->coarse_tau < 0.f || h_params->coarse_tau > 1.f) return NEFII_E_ARG;
     P.tau = J.coarse ? h_params->coarse_tau : 0.f;
     P.cap = coarse_cap(h_params);
+    P.chunk = 0;
+    if (J.coarse) {       // NEFII_SAMPLER_CHUNK: leading samples of a bracket search evaluated exactly first (0: off; A/B switch)
+        const char *e = getenv("NEFII_SAMPLER_CHUNK");
+        const int c = e ? atoi(e) : 6;       // 4 / 6 / 8 / 16: 195.8 / 196.9 / 197.2 / 203.7 ms per step on config 3 (208.7 without), 2.82 / 2.79 / 2.79 / 2.81 on config 2
+        P.chunk = (c >= 2 && c <= 31 && c <= P.cap && c < h_params->n_steps) ? c : 0;
+    }
     size_t off = carve(P.s, (char *)workspace, n_rays, h_params->n_steps, P.cap);
     P.counters = (int *)((char *)workspace + off);
     P.levels = levels;

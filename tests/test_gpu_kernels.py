@@ -507,6 +507,35 @@ def test_tracer_coarse_pass_changes_no_decision(case):
                 assert c[:, 4].sum() == 0 and c[:, 1].sum() == c[:, 6].sum()
 
 
+@pytest.mark.parametrize('case', ['conf512-bowl', 'physg512-bumpy'])
+def test_tracer_leading_samples_first_changes_no_decision(case, monkeypatch):
+    """The bracket search's first few samples evaluated in split precision before anything else (NEFII_SAMPLER_CHUNK, default
+    6; sphere tracing stops right in front of the surface, so the first negative sample is usually among them and no later
+    sample is then read): points, hit mask and depths BIT-IDENTICAL to the trace without it (chunk 0) and to the trace without
+    the coarse pass, the same algorithmic work, fewer single-pass samples."""
+    name, geo = case.split('-')
+    mc = syn.model_conf({'physg512': 'physg', 'conf512': 'conf'}[name])
+    sd = syn.make_state_dict(mc, seed=2, bumpy=0.004 if geo == 'bumpy' else 0.0, scene='bowl' if geo == 'bowl' else None)
+    pm = build_sdf(mc, sd, f16x3=True)
+    tau = ops.calibrate_coarse_tau(pm)
+    o, d, om, steps = _trace_batch(6000, 31, spread=0.6 if geo == 'bowl' else 0.45)
+    for training in (False, True):
+        base = run_gpu_trace(mc, sd, o, d, om, training, steps, 'f16x3w', pm=pm)
+        runs = {}
+        for chunk in (0, 2, 6, 16, 31):
+            monkeypatch.setenv('NEFII_SAMPLER_CHUNK', str(chunk))
+            got = run_gpu_trace(mc, sd, o, d, om, training, steps, 'f16x3w', coarse_tau=tau, pm=pm)
+            for k, what in enumerate(('points', 'hit mask', 'depths')):
+                assert torch.equal(got[k], base[k]), (case, training, chunk, what)
+            c = got[3].cpu().long()
+            assert ops.algorithmic_evals(c, 100).sum() == ops.algorithmic_evals(base[3].cpu().long(), 100).sum()
+            runs[chunk] = ops.executed_evals(c, 100, 7)
+        monkeypatch.delenv('NEFII_SAMPLER_CHUNK')
+        coarse = {k: v[1].sum().item() for k, v in runs.items()}
+        print('[leading samples %s train=%d] single-pass samples by chunk: %s' % (case, training, coarse))
+        assert coarse[6] < coarse[0]
+
+
 def test_sdf_eval_coarse_stays_within_its_bound():
     """nefii_sdf_eval_coarse against nefii_sdf_eval and the fp64 oracle on fresh points: the calibrated bound (4 x the
     largest difference seen on 32 k points) holds with room, and the single pass is what BASELINE.md's precision table
