@@ -522,18 +522,23 @@ def test_tracer_leading_samples_first_changes_no_decision(case, monkeypatch):
     for training in (False, True):
         base = run_gpu_trace(mc, sd, o, d, om, training, steps, 'f16x3w', pm=pm)
         runs = {}
-        for chunk in (0, 2, 6, 16, 31):
+        for chunk, gate in ((0, None), (2, None), (6, None), (6, '1e30'), (6, '0.3'), (16, None), (31, '1e30')):
             monkeypatch.setenv('NEFII_SAMPLER_CHUNK', str(chunk))
+            if gate is None:
+                monkeypatch.delenv('NEFII_SAMPLER_CHUNK_GATE', raising=False)
+            else:
+                monkeypatch.setenv('NEFII_SAMPLER_CHUNK_GATE', gate)
             got = run_gpu_trace(mc, sd, o, d, om, training, steps, 'f16x3w', coarse_tau=tau, pm=pm)
             for k, what in enumerate(('points', 'hit mask', 'depths')):
                 assert torch.equal(got[k], base[k]), (case, training, chunk, what)
             c = got[3].cpu().long()
             assert ops.algorithmic_evals(c, 100).sum() == ops.algorithmic_evals(base[3].cpu().long(), 100).sum()
-            runs[chunk] = ops.executed_evals(c, 100, 7)
+            runs[(chunk, gate)] = ops.executed_evals(c, 100, 7)
         monkeypatch.delenv('NEFII_SAMPLER_CHUNK')
+        monkeypatch.delenv('NEFII_SAMPLER_CHUNK_GATE', raising=False)
         coarse = {k: v[1].sum().item() for k, v in runs.items()}
-        print('[leading samples %s train=%d] single-pass samples by chunk: %s' % (case, training, coarse))
-        assert coarse[6] < coarse[0]
+        print('[leading samples %s train=%d] single-pass samples by (chunk, gate): %s' % (case, training, coarse))
+        assert coarse[(6, None)] < coarse[(0, None)] and coarse[(6, '1e30')] <= coarse[(6, None)] <= coarse[(6, '0.3')]
 
 
 def test_sdf_eval_coarse_stays_within_its_bound():
