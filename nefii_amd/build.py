@@ -17,9 +17,12 @@ OUT = os.path.join(CSRC, 'libnefii_hip.so')
 HOST_SRC = os.path.join(CSRC, 'exr_huf.c')          # host-only helper of utils/exr.py (PIZ Huffman loop)
 HOST_OUT = os.path.join(CSRC, 'libnefii_host.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
-         # no packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): on gfx950 they compute wrong
-         # results while their wave shares a SIMD with MFMA-streaming waves of another kernel (csrc/mlp_tile.h,
-         # NEFII_CLAIM_SIMD; tools/concurrency_probe.py).  The host pass does not know the feature and says so: -Wno-...
+         # no packed-fp32 VALU instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): on gfx950 the form with op_sel on
+         # src1 read ZERO for that operand in lanes 48-63 while its wave shared a SIMD with waves of the tracer's
+         # single-pass evaluator (csrc/mlp_tile.h, NEFII_CLAIM_SIMD; tools/concurrency_probe.py).  The victim side is
+         # pinned to the instruction form; WHAT in the neighbour's instruction stream triggers it is not known (the
+         # evaluator with every MFMA compiled out still disturbed 40 of 40 runs: profiles/r03/nan_hunt/18) - so the whole
+         # class is compiled out.  The host pass does not know the feature and says so: -Wno-...
          '-Xclang', '-target-feature', '-Xclang', '-packed-fp32-ops']
 
 
@@ -51,32 +54,8 @@ def _run_quietly(cmd):
         raise subprocess.CalledProcessError(r.returncode, cmd)
 
 
-CANARY_OUT = os.path.join(CSRC, 'libnefii_canary.so')
-
-
-def build_canary(force=False, verbose=True):
-    """TEST INFRASTRUCTURE, never loaded by nefii_amd: the shading kernels compiled WITH packed-fp32 instructions - the
-    form in which nefii_mis_sample computed wrong directions beside the tracer's evaluators (mlp_tile.h, NEFII_CLAIM_SIMD).
-    tests/test_gpu_concurrency.py runs it beside every evaluator of the product library and demands bit-identical results:
-    it fails on gfx950 if an evaluator stops claiming its SIMDs."""
-    src = os.path.join(CSRC, 'nefii_shading.hip')
-    forms = os.path.join(HERE, '..', 'tests', 'canary', 'pk_forms.hip')       # packed-fp32 instruction forms, one kernel each
-    srcs = [src] + ([forms] if os.path.exists(forms) else [])
-    if not force and os.path.exists(CANARY_OUT) and os.path.getmtime(CANARY_OUT) >= max(
-            [os.path.getmtime(f) for f in srcs] + [os.path.getmtime(os.path.abspath(__file__))]):
-        return CANARY_OUT
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc] + [f for f in FLAGS if f not in ('-Xclang', '-target-feature', '-packed-fp32-ops')] + \
-        ['-shared'] + srcs + ['-o', CANARY_OUT]
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    _run_quietly(cmd)
-    return CANARY_OUT
-
-
 def build(force=False, verbose=True):
     build_host(force, verbose)
-    build_canary(force, verbose)
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')

@@ -77,16 +77,20 @@ class PackedMLP:
             m.enc_freqs[i] = self.enc_freqs[i]
         for l, s in enumerate(specs):
             k = s.k_x + s.k_e
-            self.w_fwd.append(torch.zeros(k * s.n_pad, device=device, dtype=torch.float32))
-            self.w_bwd.append(torch.zeros(k * s.n_pad, device=device, dtype=torch.float32) if need_bwd else None)
+            # nets on the fp16-MFMA kernels never get their f32 fragments packed (pack(): skip_f32) - they are not allocated
+            # and the descriptor carries NULL, so that an f32 entry point called on such a net returns NEFII_E_ARG instead of
+            # computing with zero weights
+            self.w_fwd.append(None if self.half else torch.zeros(k * s.n_pad, device=device, dtype=torch.float32))
+            self.w_bwd.append(torch.zeros(k * s.n_pad, device=device, dtype=torch.float32)
+                              if need_bwd and not self.half else None)
             self.bias.append(torch.zeros(s.n_pad, device=device, dtype=torch.float32))
             self.w_f16.append(torch.zeros(2 * k * s.n_pad, device=device, dtype=torch.float16) if f16x3 else None)
             self.w_f16b.append(torch.zeros(2 * k * s.n_pad, device=device, dtype=torch.float16)
                                if f16x3 and need_bwd else None)
             L = m.layer[l]
             L.k_x, L.k_e, L.n_out, L.n_pad = s.k_x, s.k_e, s.n_out, s.n_pad
-            L.w_fwd = self.w_fwd[l].data_ptr()
-            L.w_bwd = self.w_bwd[l].data_ptr() if need_bwd else None
+            L.w_fwd = self.w_fwd[l].data_ptr() if self.w_fwd[l] is not None else None
+            L.w_bwd = self.w_bwd[l].data_ptr() if self.w_bwd[l] is not None else None
             L.bias = self.bias[l].data_ptr()
             L.w_f16x3 = self.w_f16[l].data_ptr() if f16x3 else None
             L.w_bwd_f16x3 = self.w_f16b[l].data_ptr() if self.w_f16b[l] is not None else None

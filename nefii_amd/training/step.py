@@ -197,7 +197,11 @@ class TrainStep:
         # implementation of the identical update when the parameters live on the GPU
         fused = next(model.parameters()).is_cuda
         self._fused = fused
-        self._found = self._one = None
+        # flag and unit scale of the fused NaN guard (_update): allocated here, outside any graph capture - with
+        # graph_after = 0 the first _update runs inside torch.cuda.graph and would take them from the graph's private pool
+        _dev = next(model.parameters()).device
+        self._found = torch.zeros((), device=_dev, dtype=torch.float32)
+        self._one = torch.ones((), device=_dev, dtype=torch.float32)
         self.graph = bool(graph) and fused and getattr(model, 'render_type', None) == 'sg'
         self.graph_bucket, self.graph_after = int(graph_bucket), int(graph_after)
         self._graphs = {}
@@ -229,7 +233,12 @@ class TrainStep:
         # loss reads the radiance colour
         rn = getattr(model, 'rendering_network', None)
         if rn is not None and hasattr(rn, 'outputs_detached'):
-            rn.outputs_detached = bool(self.loss.idr_rgb_weight == 0 and secondary_train_interval == 0)
+            # ... and only for the closed-form 'sg' render type: the Monte-Carlo render types also reach the radiance
+            # network through the indirect light at secondary hits (path_tracing_render.py: rendering_network(hp, hn, hv,
+            # feats) with autograd on, as the reference's get_visibility_and_indirect_light) - detached there, an MC conf
+            # with idr_rgb_weight = 0 would silently stop training it
+            rn.outputs_detached = bool(self.loss.idr_rgb_weight == 0 and secondary_train_interval == 0
+                                       and getattr(model, 'render_type', 'sg') == 'sg')
         # steps whose loss was not finite on some rank: their gradients were zeroed on every rank before Adam ran
         # (device counter: the runner reads it at its logging points only)
         self.nonfinite_steps = torch.zeros((), device=next(model.parameters()).device, dtype=torch.float32)
@@ -248,9 +257,6 @@ class TrainStep:
         if self._fused:
             # one multi-tensor kernel (the one torch.amp.GradScaler unscales with; scale 1.0 leaves every value as it is)
             # instead of isfinite(loss) + foreach_norm + isfinite(norms): 2 launches instead of ~25 in the step's tail
-            if self._found is None:
-                self._found = torch.zeros((), device=loss.device, dtype=torch.float32)
-                self._one = torch.ones((), device=loss.device, dtype=torch.float32)
             self._found.zero_()
             torch._amp_foreach_non_finite_check_and_unscale_(grads + [loss.detach().reshape(1).clone()], self._found, self._one)
             bad = self._found.reshape(1)

@@ -5,7 +5,7 @@ gradients that appeared only under trace prefetch (DESIGN.md
 Three pins:
   * the instruction form: packed fp32 with op_sel on src1, in inline assembly, beside every evaluator (bit-identical);
   * the mechanism: a canary build of the shading kernels WITH packed-fp32 instructions (libnefii_canary.so: test
-    infrastructure, nefii_amd/build.py:build_canary) gives bit-identical results beside every tracer evaluator of the product
+    infrastructure, tests/canary/build_canary.py) gives bit-identical results beside every tracer evaluator of the product
     library - on gfx950 it does not when an evaluator leaves room for a foreign wave on its SIMDs (mlp_tile.h, NEFII_CLAIM_SIMD);
   * the symptom: config 3 at full width, 30 steps with three batches of lookahead - no step cancelled, same losses and
     parameters as the serial schedule."""
@@ -34,11 +34,19 @@ def _model(name, scene='bowl', seed=0):
     return mc, m
 
 
+def _canary():
+    """path of libnefii_canary.so (test infrastructure; built here when it did not travel prebuilt)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('build_canary', os.path.join(ROOT, 'tests', 'canary', 'build_canary.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build_canary(verbose=False)
+
+
 def test_packed_fp32_canary_beside_the_evaluators():
-    from nefii_amd import build, ops
+    from nefii_amd import ops
     from nefii_amd.ops import _ptr
-    build.build_canary(verbose=False)
-    canary = ctypes.CDLL(build.CANARY_OUT)
+    canary = ctypes.CDLL(_canary())
     P, I, I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     canary.nefii_mis_sample.restype = I
     canary.nefii_mis_sample.argtypes = [P, I, P, P, P, P, I64, P, P, P, P]
@@ -102,10 +110,9 @@ def test_op_sel_canary_beside_the_evaluators():
     src1 - both result lanes read src1's HIGH register.  Beside an evaluator that leaves 80 registers of its SIMDs free, lanes
     48-63 of such a wave get ZERO for the low result lane's src1 in 40 of 40 runs (profiles/r03/nan_hunt/13, 17); beside the
     product's evaluators, which claim their SIMDs, every run must be bit-identical to the idle-chip result."""
-    from nefii_amd import build, ops
+    from nefii_amd import ops
     from nefii_amd.ops import _ptr
-    build.build_canary(verbose=False)
-    canary = ctypes.CDLL(build.CANARY_OUT)
+    canary = ctypes.CDLL(_canary())
     P, I, I64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
     canary.nefii_canary_pk_form.restype = I
     canary.nefii_canary_pk_form.argtypes = [I, P, P, I64, I, P]
