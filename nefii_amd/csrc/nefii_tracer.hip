@@ -15,7 +15,6 @@
 #include <vector>
 
 #include "mlp_tile.h"
-#include "sdf_tile_c.h"
 
 using namespace nefii;
 
@@ -978,65 +977,6 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, cons
     }
 }
 
-// ---- "16c" (sdf_tile_c.h): the coarse evaluator with register-resident activations and an LDS ring of weight fragments.
-// 4 waves, one per SIMD, 32 queries each; the ring and the stream position persist across the workgroup's passes.
-template <int HW>
-__global__ __launch_bounds__(256, 1) void eval_kernel16c(Params P, nefii_mlp m, int round, size_t c_off) {
-    NEFII_CLAIM_SIMD_1();
-    __shared__ LdsC lds;
-    const int64_t total = (int64_t)P.counters[round * NCNT + 5] * P.p.n_steps;
-    const int64_t n_pass = (total + C_ROWS - 1) / C_ROWS;
-    if (blockIdx.x >= n_pass) return;
-    const CStream g = c_stream_geometry(m);
-    CRing r;
-    half8 a[2][4];
-    c_prime<HW / 32>(m, g, c_off, lds, r, a);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ns = P.p.n_steps;
-    for (int64_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
-        const int64_t q = pass * C_ROWS + 32 * wave + (threadIdx.x & 31);
-        float *dst = nullptr;
-        float x[3] = {0.f, 0.f, 0.f};
-        if (q < total) {                    // decode_tile_coarse, per lane
-            const int64_t di = q / ns;
-            const int i = (int)(q - di * ns);
-            const unsigned e = P.s.cdense[di];
-            const int64_t ry = e >> 1;
-            const float t = dense_depth(P, ry, i, e & 1);
-            dst = &P.s.big[(size_t)ry * ns + i];
-            x[0] = fadd(P.o[ry * 3], fmul(t, P.d[ry * 3]));
-            x[1] = fadd(P.o[ry * 3 + 1], fmul(t, P.d[ry * 3 + 1]));
-            x[2] = fadd(P.o[ry * 3 + 2], fmul(t, P.d[ry * 3 + 2]));
-        }
-        const float v = m.act == NEFII_ACT_SOFTPLUS100 ? sdf_pass16c<HW, true>(m, g, lds, r, a, x)
-                                                       : sdf_pass16c<HW, false>(m, g, lds, r, a, x);
-        if (dst && !(threadIdx.x & 32)) *dst = v;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the ring's run-ahead pieces must not outlive the workgroup's LDS
-}
-
-template <int HW>
-__global__ __launch_bounds__(256, 1) void sdf_points_kernel16c(nefii_mlp m, const float *__restrict__ xs, int64_t n,
-                                                              float *__restrict__ out, size_t c_off) {
-    NEFII_CLAIM_SIMD_1();
-    __shared__ LdsC lds;
-    const int64_t n_pass = (n + C_ROWS - 1) / C_ROWS;
-    const CStream g = c_stream_geometry(m);
-    CRing r;
-    half8 a[2][4];
-    c_prime<HW / 32>(m, g, c_off, lds, r, a);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int64_t pass = blockIdx.x; pass < n_pass; pass += gridDim.x) {
-        const int64_t q = pass * C_ROWS + 32 * wave + (threadIdx.x & 31);
-        const bool live = q < n;
-        float x[3] = {live ? xs[q * 3] : 0.f, live ? xs[q * 3 + 1] : 0.f, live ? xs[q * 3 + 2] : 0.f};
-        const float v = m.act == NEFII_ACT_SOFTPLUS100 ? sdf_pass16c<HW, true>(m, g, lds, r, a, x)
-                                                       : sdf_pass16c<HW, false>(m, g, lds, r, a, x);
-        if (live && !(threadIdx.x & 32)) out[q] = v;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 template <int FT>
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16q(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
@@ -1208,77 +1148,6 @@ int stream_steps_sp(const nefii_mlp *m) {
     int G = 0;
     for (int l = 0; l < m->n_layers - 1; ++l) G += s_units(m->layer[l]);
     return G;
-}
-
-// ---- "c" copy: the register-resident coarse evaluator's stream (sdf_tile_c.h) -----------------------------------------------
-// Nets it takes: the 512-wide pipelined shape in the 16x16x32 layout with a 6-octave encoding of one input (39 columns),
-// softplus or ReLU, at most one skip layer whose true input [previous outputs | encoding] is exactly 512 wide.
-int c_shape(const nefii_mlp *m) {
-    if (shape16p(m) != 4 || m->reserved != 1) return 0;
-    if (m->act != NEFII_ACT_SOFTPLUS100 && m->act != NEFII_ACT_RELU) return 0;
-    if (m->enc_freqs[0] != 6 || m->enc_freqs[1] >= 0 || m->enc_freqs[2] >= 0 || m->feat_width != 0) return 0;
-    const int NH = m->n_layers - 1;
-    if (NH < 2 || NH > C_MAX_HIDDEN || m->layer[0].k_x != 0 || m->layer[0].k_e != 64) return 0;
-    int skips = 0;
-    for (int l = 1; l < NH; ++l) {
-        const nefii_layer &L = m->layer[l];
-        if (L.k_e > 0) {
-            if (L.k_x != 512 || m->layer[l - 1].n_out + 39 != 512) return 0;
-            ++skips;
-        }
-        if (!L.w_f16x3 || !L.bias) return 0;
-    }
-    if (skips > 1 || !m->layer[0].w_f16x3 || !m->layer[NH].w_f16x3 || m->layer[NH].k_e != 0) return 0;
-    return 512;
-}
-static bool c_enabled() {       // NEFII_COARSE_X=0: keep the "16s" evaluator (A/B measurements)
-    static const bool v = [] {
-        const char *e = getenv("NEFII_COARSE_X");
-        return !(e && atoi(e) == 0);
-    }();
-    return v;
-}
-
-// one block of 64 threads per fragment, then one per 256 bytes of the bias table
-__global__ void pack_sdf_stream_c_kernel(nefii_mlp m, char *__restrict__ dst) {
-    const CStream g = c_stream_geometry(m);
-    const int NT = g.hw / 32, KS = g.hw / 16, lane = threadIdx.x;
-    int f = blockIdx.x;
-    if (f >= g.frags) {             // bias table: [layer][tile][h][16] floats = 64 per (layer, tile)
-        const int i = (f - g.frags) * 64 + lane;            // float index
-        if (i * 4 >= g.bias_bytes) return;
-        const int l = i / (NT * 32), T = (i / 32) % NT, h = (i >> 4) & 1, r = i & 15;
-        const int row = 8 * (r >> 2) + 4 * h + (r & 3);
-        reinterpret_cast<float *>(dst + (size_t)g.frags * 1024)[i] = m.layer[l].bias[32 * T + cperm(row)] * A16_SCALE;
-        return;
-    }
-    half8 v;
-    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
-    int l, T, s;
-    if (f < NT * 4) {
-        l = 0, T = f / 4, s = f % 4;
-    } else {
-        f -= NT * 4;
-        l = 1 + f / (NT * KS);
-        f -= (l - 1) * NT * KS;
-        T = f / KS, s = f % KS;
-    }
-    if (l <= g.nh && (l < g.nh || T == 0)) {
-        const nefii_layer &L = m.layer[l];
-        const int NT32 = L.n_pad >> 5, mrow = lane & 31, h = lane >> 5;
-        const int x_len = l == g.skip ? m.layer[l - 1].n_out : 0;
-        const half8 *w = reinterpret_cast<const half8 *>(L.w_f16x3);
-        for (int j = 0; j < 8; ++j) {
-            const int kk = 16 * s + 8 * h + j;
-            const int col = (l == g.skip && kk >= x_len) ? g.hw + (kk - x_len) : kk;     // the padded [hidden | encoding] image
-            if (col < L.k_x + L.k_e && T < NT32) {
-                const int s16 = col >> 4, hs = (col >> 3) & 1;
-                const half8 src = w[(((size_t)s16 * NT32 + T) * 2) * 64 + cperm(mrow) + 32 * hs];
-                v[j] = (_Float16)((float)src[col & 7] * (1.f / W16_SCALE));
-            }
-        }
-    }
-    reinterpret_cast<half8 *>(dst)[(size_t)blockIdx.x * 64 + lane] = v;
 }
 
 // ---- fourth copy: the value + gradient kernel's stream (sdf_value_grad16q_kernel) ------------------------------------------
@@ -1777,17 +1646,12 @@ extern "C" int nefii_trace_profile_launches(float *h_ms, int cap) {
     return n;
 }
 
-// byte offset of the "c" copy (it follows every other copy)
-static size_t c_stream_offset(const nefii_mlp *h_sdf) {
+extern "C" size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf) {
+    if (!h_sdf || h_sdf->n_layers < 2 || h_sdf->n_layers > NEFII_MAX_LAYERS || !shape16p(h_sdf)) return 0;
     size_t units_vg = 0;
     if (vg_shape(h_sdf)) units_vg = (size_t)stream_steps(h_sdf) + vg_units_bwd(h_sdf);
     return (size_t)8 * (stream_steps(h_sdf) + stream_steps8(h_sdf) + units_vg) * 256 * sizeof(half8) +
            (size_t)8 * stream_steps_sp(h_sdf) * shape16p(h_sdf) * 64 * sizeof(half8);
-}
-
-extern "C" size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf) {
-    if (!h_sdf || h_sdf->n_layers < 2 || h_sdf->n_layers > NEFII_MAX_LAYERS || !shape16p(h_sdf)) return 0;
-    return c_stream_offset(h_sdf) + (c_shape(h_sdf) ? c_stream_bytes(*h_sdf) : 0);
 }
 
 extern "C" int nefii_sdf_coarse_supported(const nefii_mlp *h_sdf) {
@@ -1823,12 +1687,6 @@ extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, voi
         hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, ft, 0);
         HIP_CHECK_LAUNCH();
         hipLaunchKernelGGL(pack_sdf_stream_bwd_kernel, dim3(Gb, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, G, ft);
-        HIP_CHECK_LAUNCH();
-    }
-    if (c_shape(h_sdf)) {
-        const CStream g = c_stream_geometry(*h_sdf);
-        hipLaunchKernelGGL(pack_sdf_stream_c_kernel, dim3(g.frags + (g.bias_bytes + 255) / 256), dim3(64), 0, (hipStream_t)stream,
-                           *h_sdf, (char *)w_stream + c_stream_offset(h_sdf));
         HIP_CHECK_LAUNCH();
     }
     return 0;
@@ -1912,13 +1770,6 @@ extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int
         h_sdf->layer[0].k_x != 0)
         return NEFII_E_UNSUPPORTED;
     const int ft = shape16p(h_sdf);
-    if (c_enabled() && c_shape(h_sdf)) {
-        const int64_t n_pass = (n + C_ROWS - 1) / C_ROWS;
-        hipLaunchKernelGGL(sdf_points_kernel16c<512>, dim3((int)(n_pass < 256 ? n_pass : 256)), dim3(256), 0, (hipStream_t)stream,
-                           *h_sdf, x, n, sdf_out, c_stream_offset(h_sdf));
-        HIP_CHECK_LAUNCH();
-        return 0;
-    }
     const int rows = coarse_rows(ft);
     const int64_t n_tiles = (n + rows - 1) / rows;
     const dim3 grid((int)(n_tiles < 512 ? n_tiles : 512));
@@ -2120,12 +1971,7 @@ int launch_round(const TraceJob &J, int r, bool profile) {
         else
             hipLaunchKernelGGL(eval_kernel, dim3(J.eval_blocks), dim3(WG), 0, st, J.P, *J.sdf, r);
         HIP_CHECK_LAUNCH();
-        if (J.coarse && c_enabled() && c_shape(J.sdf)) {
-            const int64_t t = (J.P.n * (int64_t)J.P.p.n_steps + C_ROWS - 1) / C_ROWS;
-            hipLaunchKernelGGL(eval_kernel16c<512>, dim3((int)(t < 256 ? t : 256)), dim3(256), 0, st, J.P, *J.sdf, r,
-                               c_stream_offset(J.sdf));
-            HIP_CHECK_LAUNCH();
-        } else if (J.coarse) {
+        if (J.coarse) {
             const int ft = J.pipelined == 2 ? 2 : 4, rows = coarse_rows(ft);
             const int64_t t = (J.P.n * (int64_t)J.P.p.n_steps + rows - 1) / rows;
             const dim3 grid((int)(t < J.eval_blocks_w ? t : J.eval_blocks_w));
