@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 8
+#define NEFII_ABI_VERSION 9
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -197,7 +197,7 @@ typedef struct nefii_tracer_params {
                                 round; 1.5x the chip time per query); 0: 8192.  Traces that overlap other work pass a
                                 smaller value. */
 } nefii_tracer_params;
-#define NEFII_TRACE_COUNTERS 8   /* int32 counters per round, see nefii_trace_rays */
+#define NEFII_TRACE_COUNTERS 9   /* int32 counters per round, see nefii_trace_rays */
 
 /* The pipelined evaluator behind nefii_trace_rays (precision 2) and nefii_sdf_eval reads the hidden layers' fragments as
  * ONE stream per wave, 4 KiB per 16-deep unit of the layer sequence: [8 waves][units][4 fragments][64 lanes][8 halves];
@@ -249,7 +249,9 @@ int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
  * bisection (2^levels - 1 speculative queries each), [r][3] bisection evaluations actually consumed, [r][4] coarse-pass
  * samples re-evaluated in split precision, [r][5] rays with n_steps dense queries in the single-pass (coarse) evaluator,
  * [r][6] rays entering a dense search (the reference evaluates n_steps samples for each), [r][7] = (2^levels - 1)*[2],
- * the speculative bisection evaluations executed.
+ * the speculative bisection evaluations executed, [r][8] (the bits of a float >= 0) the largest |coarse - split| among the
+ * coarse-pass samples this round re-evaluated in split precision: the online audit of coarse_tau - every refined sample
+ * is evaluated both ways anyway; a value above coarse_tau means the caller's bound does not hold for this net.
  * Algorithmic evaluations (what the reference's recurrences need) = [0] + n_steps*[6] + [3]; executed in split
  * precision = [0] + n_steps*[1] + [7] + [4]; executed in the coarse evaluator = n_steps*[5]. */
 int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
@@ -372,6 +374,14 @@ int nefii_assemble_rows(const nefii_row_block *h_blocks, int n_blocks, const int
                         void *stream);
 int nefii_gather_rows(const nefii_row_block *h_blocks, int n_blocks, const int64_t *where, int64_t n_src, int64_t rows,
                       void *stream);
+
+/* MEASUREMENT, not part of the reference's path: what the matrix cores of THIS device sustain on dense fp16 MFMAs with
+ * random operands and nothing else in the instruction stream (v_mfma_f32_16x16x32_f16, four accumulator chains per wave,
+ * one wave per SIMD, every CU): runs `groups` groups of 8 MFMAs per wave on 256 workgroups, synchronises, and returns the
+ * elapsed milliseconds and the FLOPs executed.  MI355X is power-limited under such a loop (2.0 PFLOP/s on zero operands,
+ * ~1.5 on random ones: profiles/r04/slot_probe.txt), so bench.py quotes roofline.sustained_peak beside the 2.5 PFLOP/s
+ * spec peak the roofline fraction is priced against. */
+int nefii_mfma_sustained_probe(int groups, float *h_ms, double *h_flops, void *stream);
 
 #ifdef __cplusplus
 }

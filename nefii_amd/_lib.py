@@ -14,8 +14,8 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 8
-TRACE_COUNTERS = 8          # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
+ABI_VERSION = 9
+TRACE_COUNTERS = 9          # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
 HEAD_NONE, HEAD_TANH01, HEAD_POW2, HEAD_SIGMOID, HEAD_RELU, HEAD_ABS, HEAD_RELU_INIT = range(7)
@@ -117,6 +117,7 @@ SIGNATURES = {
     'nefii_mis_sample': (I, [P, I, P, P, P, P, I64, P, P, P, P]),
     'nefii_mc_shade_forward': (I, [P] * 11 + [I64, P, P, P, P]),
     'nefii_mc_shade_backward': (I, [P] * 11 + [I64] + [P] * 9),
+    'nefii_mfma_sustained_probe': (I, [I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), P]),
 }
 
 _lib = None

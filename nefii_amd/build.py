@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-SOURCES = ['nefii_mlp.hip', 'nefii_tracer.hip', 'nefii_shading.hip']
+SOURCES = ['nefii_mlp.hip', 'nefii_tracer.hip', 'nefii_shading.hip', 'nefii_probe.hip']
 HEADERS = ['mlp_tile.h', os.path.join('..', '..', 'include', 'nefii_amd.h')]
 OUT = os.path.join(CSRC, 'libnefii_hip.so')
 HOST_SRC = os.path.join(CSRC, 'exr_huf.c')          # host-only helper of utils/exr.py (PIZ Huffman loop)

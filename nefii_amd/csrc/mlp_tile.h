@@ -1141,9 +1141,12 @@ __device__ __forceinline__ void prime16q(const nefii_mlp &m, P16<8>::Stage (&b)[
 }
 
 // One tile of 16 * QT queries through the whole SDF network (FT = 4: QT = 4 / 2 for 64 / 32 queries; FT = 2: QT = 6 / 2).
+// coarse_old / audit (the tracer's refined coarse samples only): coarse_old[query] = the value the single-pass evaluator gave
+// this query (NaN: none) - the largest |coarse - split| of the tile goes to *audit (atomic max on the float's bits)
 template <int QT, int FT, int NB = 4>
 __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, float *raw, float *const *dest,
-                                            P16<8>::Stage (&b)[NB], PCursor &cur) {
+                                            P16<8>::Stage (&b)[NB], PCursor &cur, const float *coarse_old = nullptr,
+                                            int *audit = nullptr) {
     static_assert(NB == 4 || FT == 4, "the deep-prefetch variant is the 512-wide shape's");
     constexpr int NW = 8, RT = QT / 2, XP = QGeo<FT>::XP, EP = QGeo<FT>::HW, RMAX = QGeo<FT>::ROWS;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1228,12 +1231,23 @@ __device__ __forceinline__ void sdf_tile16q(const nefii_mlp &m, LdsQ<FT> &lds, f
             for (int rt = 0; rt < RT; ++rt) raw[wave * RMAX + 32 * rt + r] = acc2[rt][0];
         }
         __syncthreads();
+        float dm = 0.f;
         if (threadIdx.x < 32 * RT) {
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) sum += raw[w * RMAX + threadIdx.x];
             float *d = dest[threadIdx.x];
-            if (d) *d = sum * inv_scale + L.bias[0];
+            const float v = sum * inv_scale + L.bias[0];
+            if (d) *d = v;
+            if (coarse_old) {
+                const float o = coarse_old[threadIdx.x];
+                if (d && o == o) dm = __builtin_fabsf(o - v);
+            }
+        }
+        if (coarse_old && threadIdx.x < 128) {      // whole waves (32 RT <= 96): every lane takes part in the reduction
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) dm = __builtin_fmaxf(dm, __shfl_xor(dm, s));
+            if ((threadIdx.x & 63) == 0 && dm > 0.f) atomicMax(audit, __builtin_bit_cast(int, dm));
         }
         __syncthreads();
     }

@@ -602,14 +602,18 @@ __device__ __forceinline__ float dense_depth(const Params &P, int64_t r, int i, 
 }
 
 // decode the ROWS queries of a tile into points (raw[ROWS][9]) and result addresses (dest[ROWS])
+// `old` (optional, [ROWS]): for a coarse-pass sample that is being re-evaluated, its coarse value (NaN for every other query) -
+// the evaluator compares it with the split-precision value it is about to store (the online audit of coarse_tau)
 template <int ROWS>
-__device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const RoundWork &W, float *raw, float **dest) {
+__device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const RoundWork &W, float *raw, float **dest,
+                                            float *old = nullptr) {
     const int tid = threadIdx.x;
     if (tid >= ROWS) return;
     const int ns = P.p.n_steps;
     int64_t q = tile * ROWS + tid;
     float *dst = nullptr;
     float px = 0.f, py = 0.f, pz = 0.f;
+    float coarse_v = __builtin_nanf("");
     if (q < W.total) {
         int64_t r;
         float t;
@@ -623,8 +627,10 @@ __device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const
             const unsigned e = P.s.refine[q - W.n_sdt];
             r = e >> 7;
             const int i = e & 127;
-            t = dense_depth(P, r, i, (P.s.flags[r] & F_PHASE) == PH_MINSDF);
+            const int ph = P.s.flags[r] & F_PHASE;
+            t = dense_depth(P, r, i, ph == PH_MINSDF);
             dst = &P.s.big[(size_t)r * ns + i];
+            if (old && ph != PH_SAMPLER_X) coarse_v = *dst;     // (the leading samples of a bracket search have no coarse value)
         } else if (q >= W.n_sd) {
             const int64_t qq = q - W.n_sd;
             const int64_t ti = qq / P.tri_nodes;
@@ -646,6 +652,7 @@ __device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const
         pz = fadd(P.o[r * 3 + 2], fmul(t, P.d[r * 3 + 2]));
     }
     dest[tid] = dst;
+    if (old) old[tid] = coarse_v;
     float *rw = raw + tid * 9;
     rw[0] = px, rw[1] = py, rw[2] = pz;
     rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
@@ -863,6 +870,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
     __shared__ LdsQ<FT> lds;
     __shared__ float raw[RMAX * 9];
     __shared__ float *dest[RMAX];
+    __shared__ float old[RMAX];
     const RoundWork W = round_work(P, round);
     const int64_t total = W.total;
     // Which instance takes which queries.  Rounds up to SMALL_ROUND: all in 32-query tiles.  Larger rounds: big tiles
@@ -894,9 +902,10 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
     PCursor cur;
     prime16q<FT, NB>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile<ROWS>(P, first + tile, W, raw, dest);
+        const bool audit = P.tau > 0.f;
+        decode_tile<ROWS>(P, first + tile, W, raw, dest, audit ? old : nullptr);
         __syncthreads();
-        sdf_tile16q<QT, FT, NB>(m, lds, raw, dest, b, cur);
+        sdf_tile16q<QT, FT, NB>(m, lds, raw, dest, b, cur, audit ? old : nullptr, P.counters + round * NCNT + 8);
     }
 }
 

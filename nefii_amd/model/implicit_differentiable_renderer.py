@@ -72,7 +72,9 @@ class ImplicitNetwork(nn.Module):
         self._pm = None
         self._pm_version = None
         self._pm_fit = None
-        self._tau = None          # (packed version, error bound of the tracer's coarse pass for these weights)
+        self._tau = None          # (packed version, radius, error bound of the tracer's coarse pass for these weights)
+        self.coarse_audit_max = 0.0       # largest |coarse - split| the tracer has reported for a refined sample
+        self.coarse_audit_events = []     # ('recalibrated' | 'disabled', observed, bound in use): what note_coarse_audit did
 
     def coarse_tau(self, radius=1.0):
         """Error bound of the tracer's single-pass evaluator for the current weights (ops.calibrate_coarse_tau), measured
@@ -81,6 +83,29 @@ class ImplicitNetwork(nn.Module):
         if self._tau is None or self._tau[0] != self._pm_version or self._tau[1] != radius:
             self._tau = (self._pm_version, radius, ops.calibrate_coarse_tau(pm, radius))
         return self._tau[2]
+
+    def note_coarse_audit(self, observed, tau_used, radius=1.0):
+        """The tracer's report for one trace: the largest |single pass - split| among the coarse samples it re-evaluated
+        (every refined sample is evaluated both ways - nefii_trace_rays, counter 8).  coarse_tau is a MEASURED bound (3 x the
+        largest difference over 65 536 random points: ops.calibrate_coarse_tau), not a proven one: a trained network with
+        sharper features than the calibration sample saw could exceed it.  observed > bound / 2 (the margin has shrunk below 2;
+        tools/tau_probe.py saw 2.2-2.5 over 16.8 M points): the bound is raised to 3 x observed.  observed > bound: a refined
+        sample was further from its exact
+        value than the decisions of that trace assumed - a sample that was NOT refined may have decided differently - so the
+        coarse pass is switched off for these weights (bound 0: every sample in split precision) with a warning."""
+        self.coarse_audit_max = max(self.coarse_audit_max, float(observed))
+        if self._tau is None or self._tau[0] != self._pm_version or self._tau[2] <= 0.0 or tau_used <= 0.0:
+            return
+        tau = self._tau[2]
+        if observed > tau_used:
+            import warnings
+            warnings.warn('coarse pass of the tracer disabled for this network: a refined sample differed from its '
+                          'single-pass value by %.3e, above the claimed bound %.3e' % (observed, tau_used))
+            self._tau = (self._pm_version, self._tau[1], 0.0)
+            self.coarse_audit_events.append(('disabled', float(observed), float(tau_used)))
+        elif observed * 2.0 > tau:
+            self._tau = (self._pm_version, self._tau[1], ops.COARSE_TAU_SAFETY * float(observed))
+            self.coarse_audit_events.append(('recalibrated', float(observed), float(tau_used)))
 
     def effective_weights(self):
         ws, bs = [], []

@@ -43,6 +43,10 @@ class RayTracing(nn.Module):
         # its eval-mode schedule): same gradients and parameter trajectory, different mask_loss value.  Default False
         # keeps the reference's outputs.
         self.skip_min_sdf_search = False
+        # with skip_min_sdf_search: still make the search's uniform draw (and drop it), so that a schedule that runs the
+        # search on some iterations only (TrainStep.min_sdf_every) leaves the host RNG stream where the every-iteration
+        # schedule leaves it
+        self.draw_when_skipped = False
         # False while a caller traces rays whose MISS outputs nothing reads (the secondary rays of pt_render_indirect_mlp:
         # their only consumer masks them with the hit mask, idr_train.py:819): the trace then runs the reference's
         # eval-mode recurrences (ray_tracing.py:62-96 without the `if self.training` blocks) - no min-SDF search for the
@@ -117,6 +121,10 @@ class RayTracing(nn.Module):
         if self.training and not self.skip_min_sdf_search and not self.miss_search and \
                 isinstance(self.minsdf_steps_override, (list, tuple)):
             self._calls += 1        # this call's entry of the per-call override list stays unused
+        if self.training and self.skip_min_sdf_search and self.draw_when_skipped and self.miss_search and \
+                self.minsdf_steps_override is None:
+            for _ in range(B if (self.steps_per_batch and B > 1) else 1):
+                torch.empty(self.n_steps).uniform_(0.0, 1.0)
         group = 0
         if training:
             rows = B if (self.steps_per_batch and B > 1) else 1
@@ -142,7 +150,7 @@ class RayTracing(nn.Module):
             group = S if rows > 1 else 0
         n_rays = dirs.shape[0]
         levels = self.bisect_levels or self.auto_levels(n_rays, self.concurrent)
-        tau = 0.0
+        tau, audit = 0.0, None
         # (batches of up to 1024 rays are latency-bound - a handful of tiles per round: the coarse pass's extra round per
         # dense search costs them more than its cheaper samples save; config 1: 2.39 vs 2.2 ms per step)
         # ... and geometry that still trains (model/trainable_geometry.py) changes its weights every step: the bound would
@@ -151,6 +159,11 @@ class RayTracing(nn.Module):
         if self.coarse and self.precision == 'f16x3w' and n_rays > 1024 and (frozen or self.coarse_tau_override is not None):
             tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
                 net.coarse_tau(self.object_bounding_sphere)
+            if self.coarse_tau_override is None and tau > 0:
+                # every refined sample is evaluated both ways: the tracer reports the largest difference it saw and the
+                # network compares it with the bound it claimed (ImplicitNetwork.note_coarse_audit)
+                radius, used = self.object_bounding_sphere, tau
+                audit = lambda v: net.note_coarse_audit(v, used, radius)
         params = ops.make_tracer_params(self._cfg(), training, self.precision, levels, coarse_tau=tau,
                                         coarse_cap=self.coarse_cap, minsdf_group=group,
                                         small_round=self.small_round_for(n_rays, self.concurrent))
@@ -162,7 +175,8 @@ class RayTracing(nn.Module):
                              object_mask.reshape(-1), self._lin, steps, want_counters=self.collect_counters,
                              rounds_state=state,
                              groups=1 if group else (self.stream_groups or 1),
-                             deferred=self.deferred_checks if state is not None else None)
+                             deferred=self.deferred_checks if state is not None else None,
+                             audit=audit if state is not None else None)
         if self.collect_counters:
             self.last_counters = res[3]
             cur = res[3]

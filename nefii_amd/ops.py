@@ -342,7 +342,10 @@ def coarse_supported(pm):
     return bool(pm.f16x3 and pm.w_stream is not None and _lib.lib().nefii_sdf_coarse_supported(ctypes.byref(pm.struct)))
 
 
-def calibrate_coarse_tau(pm, radius=1.0, n=65536, safety=3.0, seed=0):
+COARSE_TAU_SAFETY = 3.0
+
+
+def calibrate_coarse_tau(pm, radius=1.0, n=65536, safety=COARSE_TAU_SAFETY, seed=0):
     """Error bound of the tracer's coarse pass for THIS network: `safety` x the largest |single-pass - split| SDF value
     over n points drawn uniformly in the bounding sphere (where the tracer samples), at least 1e-4.  0.0 when the net
     has no single-pass stream.  One host sync; callers cache it per packed weight version (geometry is frozen)."""
@@ -359,7 +362,7 @@ def calibrate_coarse_tau(pm, radius=1.0, n=65536, safety=3.0, seed=0):
 
 
 def algorithmic_evals(counters, n_steps):
-    """SDF evaluations the reference's recurrences need for the rounds in `counters` [..., rounds, 8] (what the
+    """SDF evaluations the reference's recurrences need for the rounds in `counters` [..., rounds, 9] (what the
     roofline credits): singles + n_steps per dense search entered + bisection steps consumed."""
     c = counters.long()
     return c[..., 0] + c[..., 6] * n_steps + c[..., 3]
@@ -416,8 +419,14 @@ def _trace_streams(dev, n):
     return pool[:n]
 
 
+def _audit_of(host_counters):
+    """Largest |coarse - split| the tracer saw among the coarse samples it re-evaluated (counter column 8: float bits)."""
+    col = host_counters[..., 8].contiguous().view(torch.float32)
+    return float(col.max()) if col.numel() else 0.0
+
+
 def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_steps=None, want_counters=False,
-               rounds_state=None, groups=1, deferred=None):
+               rounds_state=None, groups=1, deferred=None, audit=None):
     """RayTracing.forward for per-ray origins.  Returns points [n,3], hit (bool [n]), dists [n] (+ counters).
 
     groups > 1: the rays are cut into that many contiguous chunks that run their rounds on separate HIP streams
@@ -425,6 +434,9 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
     small batch (fewer 64-query tiles than CUs, one tile time per round regardless) of different chunks then overlap
     on the chip.  On MI355X the dense rounds lose as much as that gains (RayTracing.stream_groups), so it is off by
     default.
+
+    audit (a callable, with rounds_state): called with the largest |coarse - split| of this trace's refined samples whenever
+    the counters reach the host (the online check of nefii_tracer_params.coarse_tau: ImplicitNetwork.note_coarse_audit).
 
     deferred (a list, with rounds_state): the call enqueues the guessed round prefix and returns WITHOUT reading the
     counters back; it appends a callable that, invoked once the work has completed, tells whether that prefix was the
@@ -515,6 +527,8 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
                         host = counters.cpu()
                     busy = torch.nonzero(host[:, :, _WORK].sum(dim=(0, 2))).flatten()
                     rounds_state.guess = (int(busy[-1]) if busy.numel() else 0) + 3
+                    if audit is not None:
+                        audit(_audit_of(host))
                     return (pts, hit.bool(), dist) if again else None
                 deferred.append(check)
                 if want_counters:
@@ -530,6 +544,8 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
             busy = torch.nonzero(host[:, :, _WORK].sum(dim=(0, 2))).flatten()
             last = int(busy[-1]) if busy.numel() else 0
             rounds_state.guess = last + 3                    # last emitting round + its consumer + one spare
+            if audit is not None:
+                audit(_audit_of(host))
     if want_counters:
         return pts, hit.bool(), dist, counters.sum(dim=0)
     return pts, hit.bool(), dist

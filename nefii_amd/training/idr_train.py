@@ -157,7 +157,10 @@ class IDRTrainRunner:
             sg_sched_factor=t.get_float('sg_sched_factor', default=0.0),
             alpha_milestones=t.get_list('alpha_milestones', default=[]), alpha_factor=t.get_float('alpha_factor', default=0.0),
             roughness_warmup=kwargs.get('roughness_warmup', -1), specular_warmup=kwargs.get('specular_warmup', -1),
-            start_iter=self.start_epoch * self.n_batches)
+            start_iter=self.start_epoch * self.n_batches,
+            # frozen geometry: the tracer's min-SDF search only feeds the VALUE of mask_loss - run it on the iterations whose
+            # loss is read (the log line every log_freq iterations, idr_train.py:784); NEFII_MIN_SDF_EVERY=1: every iteration
+            min_sdf_every=int(os.environ.get('NEFII_MIN_SDF_EVERY', str(self.log_freq))) if self.freeze_geometry else 1)
         self.loss = self.step.loss
         if saved:
             self.step.idr_optimizer.load_state_dict(saved['idr_opt']['optimizer_state_dict'])

@@ -167,7 +167,8 @@ class TrainStep:
     def __init__(self, model, loss_conf, idr_lr=5e-4, sg_lr=5e-4, world_size=1, secondary_train_interval=0,
                  secondary_batch_size=1024, num_rays=1, graph=False, graph_bucket=256, graph_after=3,
                  idr_sched_milestones=(), idr_sched_factor=0.0, sg_sched_milestones=(), sg_sched_factor=0.0,
-                 alpha_milestones=(), alpha_factor=0.0, roughness_warmup=-1, specular_warmup=-1, start_iter=0):
+                 alpha_milestones=(), alpha_factor=0.0, roughness_warmup=-1, specular_warmup=-1, start_iter=0,
+                 min_sdf_every=None):
         """graph=True: after `graph_after` eager iterations the part of the step behind the tracer - whose launch count
         (~170 small kernels) rather than its GPU time bounds it - replays as a captured hipGraph.  The hit count varies
         from batch to batch, so the compacted index list is padded to a multiple of `graph_bucket` (padding rows
@@ -182,6 +183,19 @@ class TrainStep:
         self.model = model
         self.loss = IDRLoss(**loss_conf)
         self.world_size = world_size
+        # The tracer's training-mode min-SDF search (ray_tracing.py:309-337: 100 samples per ray that misses - 57 % of config
+        # 3's single-pass evaluations, 76 % of config 2's) fills `points` / `sdf_output` of the MISS rays, and under frozen
+        # geometry those reach nothing but the VALUE of mask_loss: no gradient - and the
+        # reference reads the loss value only in its NaN check and in the line it prints every 50 iterations
+        # (idr_train.py:754,784).  min_sdf_every = E > 1 runs the search on the iterations with cur_iter % E == 0 only (the
+        # runner passes its logging period): the logged losses are the reference's, parameters and optimizer state are
+        # bit-identical to the every-iteration schedule (test_min_sdf_on_reporting_iterations_only), the losses returned on
+        # the other iterations carry a mask_loss computed without the search (finite whenever the true one is).  The
+        # search's uniform draw is made on every iteration either way.  Default (None): NEFII_MIN_SDF_EVERY, else 1 - every
+        # iteration, the reference's schedule; trainable geometry always runs it.
+        if min_sdf_every is None:
+            min_sdf_every = int(os.environ.get('NEFII_MIN_SDF_EVERY', '1'))
+        self.min_sdf_every = max(1, int(min_sdf_every))
         # secondary-point consistency step (idr_train.py:44,788,804-852): every `interval` iterations, on the first
         # secondary_batch_size // world masked secondary hits, each replicated num_rays times
         self.secondary_train_interval = secondary_train_interval
@@ -317,6 +331,14 @@ class TrainStep:
             if torch.is_tensor(g.get('lr')):
                 g['lr'] = float(g['lr'])
         return sd
+
+    def _set_min_sdf(self, *iters):
+        """The tracer's schedule for the trace(s) of the given iteration(s) (several: batches traced as one call)."""
+        if self.min_sdf_every <= 1 or not getattr(self.model, 'state_freeze_geo', False):
+            return
+        rt = self.model.ray_tracer
+        rt.skip_min_sdf_search = not any(i % self.min_sdf_every == 0 for i in iters)
+        rt.draw_when_skipped = True
 
     def _pre_iteration(self):
         """idr_train.py:692-713, in the reference's order."""
@@ -458,6 +480,7 @@ class TrainStep:
 
     def _graph_step(self, model_input, ground_truth, ctx=None):
         if ctx is None:
+            self._set_min_sdf(self.cur_iter)
             ctx = self.model.trace_head(model_input)
         idx = _hit_index(ctx)      # no host sync for a trace enqueued ahead; torch.nonzero (the step's one sync) otherwise
         n_hit, n_all = idx.numel(), ctx['points'].shape[0]
@@ -507,21 +530,28 @@ class TrainStep:
                 self._prefetch, queued, mine = [], [], False        # the caller changed its mind about the coming batches
                 expected = upcoming
             if not mine and m.training and getattr(m, 'state_freeze_geo', False):
+                self._set_min_sdf(self.cur_iter)
                 ctx = m.trace_head(model_input)         # own trace first: the tracer's random draws keep their order
             # enqueued BEFORE this batch's own (earlier enqueued) trace is waited for: the trace streams then always have
             # the next trace(s) queued behind / beside the running one and never idle while the host checks and launches
             todo = expected[len(queued):]
+            it_next = self.cur_iter + (0 if mine else 1) + len(queued)       # the iteration todo[0] belongs to
             G = self.trace_group_for(model_input)
             if G <= 1:
                 for inp in todo:
+                    self._set_min_sdf(it_next)
                     self.prefetch_trace(inp)
+                    it_next += 1
             else:
                 while len(todo) >= G:
+                    self._set_min_sdf(*range(it_next, it_next + G))
                     self.prefetch_group(todo[:G])
                     todo = todo[G:]
+                    it_next += G
                 # never let the queue run dry: when no traced batch would be left for the next call, trace what there is
                 left = len(self._prefetch) - (1 if self._prefetch and self._prefetch[0][0] is model_input else 0)
                 if left == 0 and todo:
+                    self._set_min_sdf(*range(it_next, it_next + len(todo)))
                     self.prefetch_group(todo)
         if ctx is None:
             ctx = self._take_prefetched(model_input)
@@ -536,6 +566,7 @@ class TrainStep:
         if ctx is not None:
             out = self.model.shade_tail(ctx, _hit_index(ctx))
         else:
+            self._set_min_sdf(self.cur_iter)
             out = self.model(model_input)
         lo = self.loss(out, ground_truth)
         self.idr_optimizer.zero_grad()

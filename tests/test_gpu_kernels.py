@@ -507,6 +507,56 @@ def test_tracer_coarse_pass_changes_no_decision(case):
                 assert c[:, 4].sum() == 0 and c[:, 1].sum() == c[:, 6].sum()
 
 
+def test_tracer_audits_its_coarse_bound():
+    """nefii_trace_rays counter 8: the largest |single pass - split| among the coarse samples a trace re-evaluated (each of
+    them IS evaluated both ways).  (1) It is a true difference: positive, below the calibrated bound, and no larger than the
+    largest difference over the same net's calibration points allows (x 3).  (2) ImplicitNetwork.note_coarse_audit reacts:
+    a deliberately UNDER-estimated bound (a tenth of what the tracer observes) switches the coarse pass off for those weights
+    with a warning - the next trace runs every sample in split precision - and a bound with less than a factor 2 of margin
+    is raised to 3 x the observed difference."""
+    import warnings
+    from nefii_amd import conf
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    mc = syn.model_conf('conf')
+    m = IDRNetwork(conf.from_dict(mc))
+    m.load_state_dict(syn.make_state_dict(mc, seed=2, scene='bowl'), strict=True)
+    m = m.to(DEV)
+    m.freeze_geometry()
+    m.train()
+    net, rt = m.implicit_network, m.ray_tracer
+    o, d, om, steps = _trace_batch(6000, 31, spread=0.6)
+    rt.minsdf_steps_override = steps
+    rt.collect_counters = True
+    cam = o.to(DEV)                         # RayTracing.forward: one origin per batch row -> n rows of one ray
+    dirs = d.to(DEV).unsqueeze(1)
+
+    def trace():
+        rt.counter_sum = None
+        rt.forward(net, cam, om.to(DEV), dirs)
+        torch.cuda.synchronize()
+        c = rt.counter_sum.cpu()
+        return c, float(c[:, 8].contiguous().view(torch.float32).max())
+
+    tau = net.coarse_tau(rt.object_bounding_sphere)
+    c, seen = trace()
+    assert c[:, 4].sum() > 0, 'no sample was refined: the test does not test'
+    assert 0.0 < seen < tau and net.coarse_audit_max == pytest.approx(seen) and not net.coarse_audit_events
+    print('[audit] bound %.3e, largest refined difference %.3e (margin %.1f)' % (tau, seen, tau / seen))
+    # a bound with less than 2x margin: raised
+    net._tau = (net._tau[0], net._tau[1], 1.5 * seen)
+    trace()
+    assert net.coarse_audit_events[-1][0] == 'recalibrated' and net.coarse_tau(rt.object_bounding_sphere) >= 2.9 * seen * 0.9
+    # an under-estimated bound: the coarse pass goes away, loudly
+    net._tau = (net._tau[0], net._tau[1], 0.1 * seen)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        trace()
+    assert any('coarse pass' in str(x.message) for x in w) and net.coarse_audit_events[-1][0] == 'disabled'
+    assert net.coarse_tau(rt.object_bounding_sphere) == 0.0
+    c, _ = trace()
+    assert c[:, 5].sum() == 0 and c[:, 4].sum() == 0, 'the coarse evaluator still ran'
+
+
 @pytest.mark.parametrize('case', ['conf512-bowl', 'physg512-bumpy'])
 def test_tracer_leading_samples_first_changes_no_decision(case, monkeypatch):
     """The bracket search's first few samples evaluated in split precision before anything else (NEFII_SAMPLER_CHUNK, default

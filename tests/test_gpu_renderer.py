@@ -637,6 +637,54 @@ def test_prefetched_trace_gives_the_same_steps(graph, lookahead):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('graph,lookahead', [(False, 0), (True, 3), (True, 5)])
+def test_min_sdf_on_reporting_iterations_only(graph, lookahead):
+    """TrainStep(min_sdf_every=E): under frozen geometry the tracer's min-SDF search (ray_tracing.py:309-337) only feeds the
+    VALUE of mask_loss, which the reference reads at its logging points (idr_train.py:754,784).  Running it on the iterations
+    with cur_iter % E == 0 only must leave parameters and both Adam states BIT-identical to the every-iteration schedule,
+    the losses of the reporting iterations bit-identical too (the search's draw is made every iteration: same RNG stream),
+    and every other loss term of every iteration unchanged - plain steps, traces enqueued ahead one at a time and in groups."""
+    from nefii_amd.training.step import TrainStep
+    mc = syn.model_conf('physg', hidden=64)
+    sd = syn.make_state_dict(mc, seed=4, bumpy=0.02)
+    lc = syn.loss_conf('physg')
+    lc['idr_rgb_weight'] = 1.0
+    NB, E = 13, 5
+    batches = []
+    for it in range(NB):
+        inp, gt = syn.make_inputs(256, (64, 64), 100.0 + 5 * it, (0.2, 0.1, 2.0 + 0.04 * it), -1, seed=30 + it)
+        batches.append((to_dev(inp), {'rgb': gt.to(DEV)}))
+    runs = []
+    for every in (1, E):
+        torch.manual_seed(77)                   # the search's uniforms come from the host generator
+        m = build_model(mc, sd, True)
+        st = TrainStep(m, lc, graph=graph, graph_bucket=64, graph_after=2, min_sdf_every=every)
+        losses = []
+        for i, (inp, gt) in enumerate(batches):
+            nxt = [b[0] for b in batches[i + 1:i + 1 + lookahead]] or None if lookahead else None
+            out, lo = st(inp, gt, nxt)
+            losses.append({k: v.item() for k, v in lo.items()})
+        opt = [{k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in s_.items()}
+               for o in (st.idr_optimizer, st.sg_optimizer) for s_ in o.state.values()]
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, opt, torch.rand(1).item()))
+    (l0, p0, o0, r0), (l1, p1, o1, r1) = runs
+    assert r0 == r1, 'the two schedules leave the host RNG stream in different places'
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k
+    for a, b in zip(o0, o1):
+        for k in a:
+            assert (torch.equal(a[k], b[k]) if torch.is_tensor(a[k]) else a[k] == b[k]), k
+    differ = 0
+    for i, (a, b) in enumerate(zip(l0, l1)):
+        for k in a:
+            if i % E == 0 or k not in ('loss', 'mask_loss'):
+                assert a[k] == b[k], (i, k, a[k], b[k])
+            else:
+                differ += a[k] != b[k]
+    assert differ > 0, 'the schedule never skipped a search: the test does not test'
+
+
+@pytest.mark.gpu
 def test_steps_on_traces_enqueued_ahead_do_not_synchronise_the_callers_stream(monkeypatch):
     """A graph step whose trace was enqueued ahead must not call torch.nonzero, Tensor.cpu or Tensor.item on the way (they
     would wait for the previous step's tail on the caller's stream and keep the host from running ahead: round 3's config 1
