@@ -5,14 +5,18 @@
 
 Step = one full Step-2 iteration on a synthetic batch already resident in HBM: forward (camera rays, HIP
 sphere tracer, SDF value/normal, radiance + material MLPs, SG shading) + IDRLoss + backward + both Adam
-updates (idr_train.py:750-776).  N=1 workload = BASELINE.json configs[1] ("cfg2"): "robot"-like scene, physg.conf
-model, num_pixels 4096, 128 SG lobes, indirect OFF.  N>1: every rank gets its own 4096-pixel slice of a
-4096*N-pixel global batch (the dataset's contiguous patch split) and gradients are averaged by one RCCL
-all-reduce per step: weak scaling, `value` = all ranks' primary rays / max-over-ranks time.
+updates (idr_train.py:750-776).  N=1 workload = BASELINE.json configs[2] ("cfg3"), the largest single-GPU configuration
+(the metric is not quoted on a config): what robot/run_s2.sh runs - conf.conf model, num_pixels 4096 x 64 rays per pixel,
+128 SG lobes, MC direct + near-field indirect, a secondary-consistency step every 10th iteration - on the non-convex
+stand-in scene.  N>1: every rank gets its own 4096-pixel slice of a 4096*N-pixel global batch (the dataset's contiguous
+patch split) and gradients are averaged by one RCCL all-reduce per step: weak scaling, `value` = all ranks' primary rays /
+max-over-ranks time.  `python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run, as child
+processes, before anything touches a GPU).
 
-Prints ONE JSON line (rank 0).  Beside the headline it carries, under "cfg3", the same measurement of BASELINE.json
-configs[2] (conf.conf model, 64 rays per pixel, MC direct + near-field indirect on the non-convex stand-in scene - what
-robot/run_s2.sh runs; it fills the chip where config 2 is launch-shaped) at min(K, 10) steps (one secondary-consistency step - every 10th iteration - per timed repetition); --workload X measures X alone.
+Prints ONE JSON line (rank 0).  Beside the headline it carries shorter measurements of the other BASELINE configs under
+"cfg1", "cfg2" (with its own CPU baseline and parity), "cfg2_camera_at_1.6", "cfg4" (N > 1: --scaling strong, its global
+8192 pixels split over the ranks as the dataset does) and "cfg5" (a band of rows of the 800 x 800 frame at 256 rays per
+pixel, chunks dealt round-robin over the ranks); --workload X measures X alone.
 
 `roofline` (recomputable from the numbers in the line): the tracer's SDF-evaluation kernels (eval_kernel16q: split
 precision, 3 fp16 MFMAs per product; eval_kernel16s: the single-pass coarse evaluator) against the dense fp16 MFMA peak
@@ -23,13 +27,19 @@ precision, 3 fp16 MFMAs per product; eval_kernel16s: the single-pass coarse eval
   frac_step = SURVEY.md section 8(d)'s A x rays/s / peak: A excludes the min-SDF search (dead work under frozen
          geometry), the speculative bisection nodes and the reference's repeated SDF passes, and includes the MLP and
          shading work behind the tracer; its terms are listed under roofline.step_model.
+  frac_8d = the same kernel time against SURVEY 8(d)'s evaluations only (E_tr + 3 h E_tr2: WITHOUT the min-SDF search);
+  sustained_peak: what a bare MFMA loop on random operands reaches on THIS device in THIS run (nefii_mfma_sustained_probe):
+         MI355X is power-limited under dense fp16 MFMA work (profiles/r04/slot_probe.txt) - frac is priced against the 2.5
+         PFLOP/s spec, frac_of_sustained / issued_frac_of_sustained say how far the kernels are from what the part delivers.
 `cpu_baseline`: the CPU oracle (kind "port": a PyTorch-CPU restatement of the reference, pinned against the
-reference's own outputs) running the same step on a bounded sample of the same workload on the host cores.
+reference's own outputs) running the same step on a bounded sample of the same workload on the host cores: 2 warm-ups,
+best of 5, the reference's own 1-thread setting after a warm-up, host CPU model and core count.
 """
 import argparse
 import json
 import math
 import os
+import subprocess
 import sys
 import time
 
@@ -48,7 +58,20 @@ def mlp_flops(specs):
     return sum(2 * s.k_in * s.n_out for s in specs)
 
 
-def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
+def host_info():
+    """CPU model and PHYSICAL core count of the host (lscpu), for the CPU baseline's line."""
+    info = {}
+    try:
+        for ln in subprocess.run(['lscpu'], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = ln.partition(':')
+            info[k.strip()] = v.strip()
+        cores = int(info.get('Core(s) per socket', 0)) * int(info.get('Socket(s)', 1))
+        return info.get('Model name', 'unknown'), cores or (os.cpu_count() or 1), int(info.get('CPU(s)', os.cpu_count() or 1))
+    except Exception:  # noqa: BLE001
+        return 'unknown', os.cpu_count() or 1, os.cpu_count() or 1
+
+
+def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None):
     """Oracle training step on the host cores, bounded sample of the workload (rank 0 only).  Also returns the
     parity of the HIP path against the oracle on that sample (identical rays and weights): relative L2 and PSNR
     (evaluate.py:36-44: 20 log10(1/sqrt(MSE))) of rendered RGB and albedo over the hit pixels."""
@@ -57,11 +80,11 @@ def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
     w = dict(syn.WORKLOADS[workload])
     mc = syn.model_conf(w['model'])
     lc = syn.loss_conf(w['model'])
-    if w['num_rays'] > 0:       # several rays per pixel (and MC shading behind each): keep the sample at ~10-30 s of CPU work
-        sample_pixels = max(16, sample_pixels * 4 // w['num_rays'])
+    R_ = w['num_rays'] if w['num_rays'] > 0 else 1
+    sample_pixels = max(8, sample_rays // R_)       # ~10-30 s of CPU work in all: 2 + 5 steps and 1 + 1 on one thread
     inp, gt = syn.make_inputs(sample_pixels, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
-    n_rays = inp['uv'].shape[1] * (w['num_rays'] if w['num_rays'] > 0 else 1)
-    ncpu = os.cpu_count() or 1
+    n_rays = inp['uv'].shape[1] * R_
+    cpu_model, phys_cores, logical = host_info()
 
     def run(threads, n_steps, n_warm):
         torch.set_num_threads(threads)
@@ -91,13 +114,14 @@ def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
 
     # these small GEMMs stop scaling early: on the 2x64-core EPYC 9575F GPU host 16 threads was the measured
     # optimum (1 thread 253, 8: 848, 16: 1029, 32: 853, 64: 396, 128: 151 rays/s; tools/cpu_threads_probe.py)
-    threads = min(16, ncpu)
+    threads = min(16, phys_cores)
     value, ref = run(threads, steps, warmup)
-    value1, _ = run(1, 1, 0)
+    value1, _ = run(1, 1, 1)
     res = {'value': value, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
-           'value_1_thread': value1,
-           'sample': '%d of the workload\'s pixels (%d primary rays), best of %d steps after %d warm-up, %d torch threads (measured '
-                     'optimum on the host; value_1_thread = the reference\'s own setting, idr_train.py:26)'
+           'value_1_thread': value1, 'host_cpu': cpu_model, 'host_cores': phys_cores, 'host_logical_cpus': logical,
+           'sample': '%d of the workload\'s pixels (%d primary rays), best of %d steps after %d warm-ups, %d torch threads (the '
+                     'measured optimum on this host class: more threads are slower; value_1_thread = the reference\'s own '
+                     'setting, idr_train.py:26, one step after one warm-up)'
                      % (sample_pixels, n_rays, steps, warmup, threads)}
     parity = None
     if device is not None:
@@ -127,7 +151,7 @@ def cpu_baseline(workload, sample_pixels, steps, warmup, device=None):
     return res, parity
 
 
-def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side=True):
+def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side=True, scaling=None, sustained=None):
     """Time `steps` training steps of WORKLOADS[name] (every rank), then measure the roofline terms in un-timed extra
     steps.  Returns the result dict on rank 0, None elsewhere."""
     import ctypes
@@ -148,7 +172,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     model.train()
     # weak scaling (default): global batch = num_pixels * world; --scaling strong: the config's own global batch (config 4:
     # 8192 pixels) - either way the contiguous per-rank slice of the global patch list (scene_dataset.py:268-279)
-    strong = getattr(args, 'scaling', 'weak') == 'strong'
+    strong = (scaling or getattr(args, 'scaling', 'weak')) == 'strong'
     inp, gt = syn.make_inputs(w['num_pixels'] * (1 if strong else world), w['image_hw'], w['focal'], w['cam_pos'],
                               w['num_rays'], seed=1, rank=rank, world_size=world)
     inp = {k: v.to(dev) for k, v in inp.items()}
@@ -296,6 +320,9 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     # the evaluators' algorithmic flops over the TIMED step (several traces run beside each other there, so this can
     # exceed frac_kernel, which prices one trace's evaluator launches run back to back on one stream)
     frac_chip = queries * f_eval / (ms_per_step * 1e-3) / (peak * 1e12)
+    # SURVEY 8(d)-strict on the same kernel time: only the evaluations 8(d) counts (no min-SDF search)
+    frac_8d = evals_live * f_eval / (eval_ms.value * 1e-3) / (peak * 1e12) if eval_ms.value > 0 else 0.0
+    issued = (executed * (3 if split else 1) + executed_coarse) * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
     # HBM traffic of the same kernels: NOT measured by this run - read from the rocprofv3 PMC passes of this command
     # committed under profiles/ (tools/profile_round.sh; separate FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied
     # by tools/pmc_traffic.py), and only quoted for the workload / kernels it was measured on
@@ -313,11 +340,19 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     roofline = {'bound': 'mfma',
                 'kernel': kname + ' (fused SDF MLP over the tracer work list)',
                 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                'frac_kernel': achieved / peak, 'frac_step': frac_step, 'frac_chip': frac_chip,
+                'frac_kernel': achieved / peak, 'frac_step': frac_step, 'frac_chip': frac_chip, 'frac_8d': frac_8d,
+                'issued_tflops': issued,
+                'sustained_peak': sustained,
+                'frac_of_sustained': (achieved / sustained['value']) if sustained else None,
+                'issued_frac_of_sustained': (issued / sustained['value']) if sustained else None,
                 'frac_definitions': 'frac_kernel: evaluator flops / evaluator launch time of ONE trace run serially (HIP '
                                     'events, an extra un-timed step); frac_chip: the same flops / ms_per_step of the timed '
                                     'steps (traces overlapped); frac_step: SURVEY 8(d) A x rays/s / peak (whole step, dead '
-                                    'min-SDF search excluded)',
+                                    'min-SDF search excluded); frac_8d: evaluations WITHOUT the min-SDF search / the same '
+                                    'evaluator launch time as frac_kernel; issued_tflops: MFMA flops the evaluators issue '
+                                    '(3 per split-precision product, refined samples and speculative bisection nodes '
+                                    'included) / that time; sustained_peak: a bare fp16 MFMA loop on random operands, '
+                                    'measured in this run on this device (the part is power-limited: 2.5 PFLOP/s spec)',
                 'traffic': traffic, 'traffic_source': traffic_source,
                 'arithmetic': ('split precision: 3x v_mfma_f32_16x16x32_f16 per k-step on fp16 hi/lo operand pairs, fp32 '
                                'accumulate; coarse pass (bracket / min-SDF searches): 1x, decisive samples re-evaluated in '
@@ -343,6 +378,9 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
         'ms_per_step': ms_per_step,
         'ms_per_step_repeats': [e / steps * 1e3 for e in reps],
         'ms_per_step_without_dead_min_sdf_search': ms_skip,
+        # the runner's default schedule under frozen geometry (TrainStep.min_sdf_every = log_freq = 50: the search runs on
+        # the iterations whose loss is read, idr_train.py:784): 49 steps without the search and one with it, both measured here
+        'ms_per_step_min_sdf_on_reporting_iterations': None if ms_skip is None else (49.0 * ms_skip + ms_per_step) / 50.0,
         'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f16x3' if split else 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %s, %s model, num_pixels=%d per GPU%s, 128 SG lobes, %s, frozen geometry, '
@@ -380,8 +418,8 @@ def syn_is_render(name):
 def run_render(name, args, frames, rank, world, dev, backend):
     """BASELINE config 5: eval-mode full-frame render, the frame's chunks dealt round-robin over the ranks and gathered on
     rank 0 (training/render.py:render_frame <-> scripts/render.py:267-360).  One "step" = one 800 x 800 frame at 256 rays per
-    pixel; strong scaling by definition (the frame is the unit).  --frame-rows R renders the first R rows only (a
-    bounded run: a whole frame takes ~1.5 minutes on one GPU)."""
+    pixel; strong scaling by definition (the frame is the unit).  --frame-rows R renders a band of R rows through the middle of
+    the frame only (a bounded run: a whole frame takes ~1.5 minutes on one GPU)."""
     import torch.distributed as dist
     from nefii_amd import conf, synthetic as syn
     from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
@@ -394,7 +432,8 @@ def run_render(name, args, frames, rank, world, dev, backend):
     model.freeze_geometry()
     H, W = w['image_hw']
     rows = min(H, args.frame_rows) if args.frame_rows > 0 else H
-    inp = syn.frame_inputs(w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], rows=(0, rows))
+    row0 = (H - rows) // 2              # a band through the middle of the frame (through the object)
+    inp = syn.frame_inputs(w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], rows=(row0, rows))
     inp = {k: v.to(dev) for k, v in inp.items()}
     n_pix = rows * W
     warm = {'uv': inp['uv'][:, :1024 * world].contiguous(), 'object_mask': inp['object_mask'][:, :1024 * world].contiguous(),
@@ -433,32 +472,55 @@ def run_render(name, args, frames, rank, world, dev, backend):
             'invalid': False}
 
 
+def measure_sustained(lib):
+    """nefii_mfma_sustained_probe: TFLOP/s of a bare v_mfma_f32_16x16x32_f16 loop on random operands, every CU, ~20 ms."""
+    import ctypes
+    ms, fl = ctypes.c_float(), ctypes.c_double()
+    rc = lib.nefii_mfma_sustained_probe(200000, ctypes.byref(ms), ctypes.byref(fl), None)
+    if rc != 0 or ms.value <= 0:
+        return None
+    return {'value': fl.value / (ms.value * 1e-3) / 1e12, 'unit': 'TFLOP/s', 'ms': ms.value,
+            'what': 'v_mfma_f32_16x16x32_f16 only, random operands, 4 accumulator chains per wave, one wave per SIMD, 256 workgroups'}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run on
+    127.0.0.1), before this process has touched a GPU, forward their output and exit with their code."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default=None, help='measure this workload alone (default: cfg2, with cfg3 nested)')
+    ap.add_argument('--workload', default=None, help='measure this workload alone (default: cfg3, with the others nested)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-nested', action='store_true', help='skip the nested cfg3 measurement')
+    ap.add_argument('--no-nested', action='store_true', help='skip the nested measurements of the other configs')
     ap.add_argument('--no-side-measurement', action='store_true',
                     help='skip the untimed side loop without the min-SDF search (profiling runs: nearly every step of the\n'
                          'process is then the headline step, so rocprofv3 per-kernel averages compare directly)')
-    ap.add_argument('--cpu-sample-pixels', type=int, default=512)
+    ap.add_argument('--cpu-sample-rays', type=int, default=1024,
+                    help='primary rays of the CPU baseline\'s sample (MC workloads: ~2 s per 16-thread step at 1024)')
     ap.add_argument('--repeats', type=int, default=3, help='repetitions of the timed K-step region (median reported)')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
                     help='N > 1: weak = every rank its own num_pixels (default); strong = the workload\'s global batch split '
                          'over the ranks as the dataset does (config 4: 8192 pixels); cfg5 (one frame) is always strong')
-    ap.add_argument('--frame-rows', type=int, default=0, help='cfg5: render only the first R rows of the frame (0: all 800)')
+    ap.add_argument('--frame-rows', type=int, default=0, help='cfg5: render only a band of R rows of the frame (0: all 800)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d'
-                             % (args.gpus, args.gpus))
+    if args.gpus > 1 and world == 1 and 'RANK' not in os.environ:
+        spawn_ranks(args.gpus)          # does not return
     import torch.distributed as dist
     # one process per GPU; NEFII_BENCH_BACKEND=gloo lets the multi-process path be smoke-tested on a 1-GPU box
     backend = os.environ.get('NEFII_BENCH_BACKEND', 'nccl')
@@ -473,7 +535,7 @@ def main():
 
     from nefii_amd import _lib
     lib = _lib.lib()
-    headline = args.workload or 'cfg2'
+    headline = args.workload or 'cfg3'
     if syn_is_render(headline):
         result = run_render(headline, args, max(1, args.steps if args.steps != 20 else 1), rank, world, dev, backend)
         if world > 1:
@@ -482,21 +544,37 @@ def main():
         if rank == 0:
             print(json.dumps(result), flush=True)
         return
+    sustained = measure_sustained(lib)          # every rank (its own device); rank 0's goes into the line
     result = run_workload(headline, args, args.steps, args.warmup, rank, world, dev, backend, lib,
-                          side=not args.no_side_measurement)
-    nested = near = None
+                          side=not args.no_side_measurement, sustained=sustained)
+    nested = {}
     if args.workload is None and not args.no_nested:
-        near = run_workload('cfg2_near', args, max(1, min(args.steps, 20)), min(args.warmup, 3), rank, world, dev, backend, lib,
-                            side=False)
-        nested = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 2), rank, world, dev, backend, lib,
-                              side=False)
+        short = dict(steps=max(1, min(args.steps, 20)), warmup=min(args.warmup, 3))
+        nested['cfg2'] = run_workload('cfg2', args, short['steps'], short['warmup'], rank, world, dev, backend, lib,
+                                      side=True, sustained=sustained)
+        nested['cfg2_near'] = run_workload('cfg2_near', args, short['steps'], short['warmup'], rank, world, dev, backend, lib,
+                                           side=False, sustained=sustained)
+        nested['cfg1'] = run_workload('cfg1', args, short['steps'], short['warmup'], rank, world, dev, backend, lib,
+                                      side=False, sustained=sustained)
+        # BASELINE's 8-GPU training config as it is defined: the global 8192-pixel batch split over the ranks
+        nested['cfg4'] = run_workload('cfg4', args, max(1, min(args.steps, 10)), min(args.warmup, 2), rank, world, dev, backend,
+                                      lib, side=False, scaling='strong' if world > 1 else 'weak', sustained=sustained)
+        # ... and its render config, bounded: a band of 32 rows through the object (25 600 pixels x 256 rays)
+        band = argparse.Namespace(**vars(args))
+        band.frame_rows = args.frame_rows or 32
+        nested['cfg5'] = run_render('cfg5', band, 1, rank, world, dev, backend)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()        # nothing below communicates (rank 0 alone runs the CPU baseline)
     if rank == 0:
-        if nested is not None:
-            result['cfg3'] = {k: nested[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step',
-                                                     'ms_per_step_repeats', 'dtype', 'config', 'roofline')}
+        keep = ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_repeats', 'scaling', 'dtype', 'config', 'roofline',
+                'ms_per_step_without_dead_min_sdf_search', 'ms_per_step_min_sdf_on_reporting_iterations')
+        for k in ('cfg2', 'cfg1', 'cfg4'):
+            if nested.get(k) is not None:
+                result[k] = {f: nested[k][f] for f in keep if f in nested[k]}
+        if nested.get('cfg5') is not None:
+            result['cfg5'] = nested['cfg5']
+        near = nested.get('cfg2_near')
         if near is not None:
             # SURVEY.md section 8(d) planned a ~40 % hit fraction for config 2; the geometric-init surface seen from 2.4 gives
             # 18 % (most rays end in the min-SDF search).  The same step with the camera at 1.6 (42 %), for comparison only
@@ -504,14 +582,16 @@ def main():
                                                                  'ms_per_step_repeats')}
             result['cfg2_camera_at_1.6'].update({'workload': near['config']['workload'], 'camera': [0.0, 0.0, 1.6],
                                                  'hit_fraction': near['roofline']['hit_fraction'],
-                                                 'headline_hit_fraction': result['roofline']['hit_fraction'],
                                                  'nonfinite_steps': near['config']['nonfinite_steps']})
         if not args.no_cpu_baseline:
-            result['cpu_baseline'], result['parity_vs_cpu_oracle'] = cpu_baseline(
-                headline, args.cpu_sample_pixels, steps=3, warmup=1, device=dev)
+            result['cpu_baseline'], result['parity_vs_cpu_oracle'] = cpu_baseline(headline, args.cpu_sample_rays, device=dev)
+            if 'cfg2' in result:
+                result['cfg2']['cpu_baseline'], result['cfg2']['parity_vs_cpu_oracle'] = cpu_baseline(
+                    'cfg2', 512, steps=3, warmup=1, device=dev)
         # a step the NaN guard cancelled costs the same time as a good one but did not train: a throughput of such steps
         # is not a measurement of the metric (round 2's nested config 3 had one in seven)
-        cancelled = result['config']['nonfinite_steps'] + sum(x['config']['nonfinite_steps'] for x in (nested, near) if x)
+        cancelled = result['config']['nonfinite_steps'] + sum(
+            x['config']['nonfinite_steps'] for k, x in nested.items() if x and k != 'cfg5')
         result['invalid'] = cancelled > 0
         if cancelled:
             result['invalid_reason'] = '%d training step(s) produced a non-finite loss or gradient and were cancelled' % cancelled

@@ -89,6 +89,44 @@ def allreduce_mean_gradients(params, world_size, group=None, flags=None):
     return flat.numel() * flat.element_size(), out_flags
 
 
+class FlatGrads:
+    """Every trainable parameter's .grad as a VIEW into one persistent flat buffer (+ a tail of flag slots): the multi-rank
+    step zeroes the buffer with one fill, backward accumulates into the views in place, and the gradient exchange is ONE
+    all-reduce of the buffer itself - no torch.cat to build it and no per-parameter copy back (round 3: ~3 launches per
+    parameter, ~80 per step).  Fixed layout, as allreduce_mean_gradients: a parameter that received no gradient on this rank
+    contributes its zeros, every rank sends the same bytes and always enters the collective."""
+
+    def __init__(self, params, n_flags=1):
+        self.params = list(params)
+        dev = self.params[0].device
+        self.n_par = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.n_par + n_flags, device=dev, dtype=torch.float32)
+        self.flags = self.flat[self.n_par:]
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def zero(self):
+        """the step's zero_grad(): one fill, and every parameter's .grad (re-)pointed at its view"""
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+    def adopt(self):
+        """gradients that autograd (or a captured graph) left in tensors of their own: copied into the views once"""
+        for p, v in zip(self.params, self.views):
+            if p.grad is not None and p.grad is not v and p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            p.grad = v
+
+    def allreduce_mean(self, world_size, group=None):
+        _all_reduce_sum(self.flat, group)
+        self.flat[:self.n_par].mul_(1.0 / world_size)
+        return self.flat.numel() * 4
+
+
 def _detached(d):
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in d.items()}
 
@@ -104,14 +142,22 @@ class _StepGraph:
         self.idx, self.dst = idx_pad.clone(), dst_pad.clone()
         self.gt = {k: v.clone() for k, v in ground_truth.items() if torch.is_tensor(v)}
         self.graph = torch.cuda.CUDAGraph()
-        step.idr_optimizer.zero_grad(set_to_none=True)
-        step.sg_optimizer.zero_grad(set_to_none=True)
+        # one process: gradients are allocated inside the capture.  Several ranks: they are views of the step's flat
+        # buffer - the capture zeroes it (one fill) and backward accumulates in place; the all-reduce and both Adam updates
+        # follow the replay eagerly (3 launches + 2), or run INSIDE the graph with NEFII_GRAPH_COLLECTIVES=1 on an RCCL
+        # group (capture of RCCL kernels: never run on hardware by this repo - off by default)
+        in_graph = step.world_size <= 1 or step.graph_collectives
+        if step._flat is None:
+            step._zero_grads(set_to_none=True)
         with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):   # RCCL's watchdog thread stays legal
             self.out = step.model.shade_tail(self.static_ctx, self.idx, self.dst)
             self.lo = step.loss(self.out, self.gt)
+            if step._flat is not None:
+                step._zero_grads()
             self.lo['loss'].backward()
-            if step.world_size <= 1:
+            if in_graph:
                 step._update(self.lo['loss'])
+        self.updates_in_graph = in_graph
         self.grads = [(p, p.grad) for p in step.trainable]      # the tensors every replay writes its gradients to
         # keep the static result tensors, not the autograd graph behind them: AccumulateGrad nodes that outlive their
         # iteration are re-used by the next backward on THEIR stream, which breaks the next capture
@@ -218,6 +264,8 @@ class TrainStep:
         self._one = torch.ones((), device=_dev, dtype=torch.float32)
         self.graph = bool(graph) and fused and getattr(model, 'render_type', None) == 'sg'
         self.graph_bucket, self.graph_after = int(graph_bucket), int(graph_after)
+        self.graph_collectives = (world_size > 1 and os.environ.get('NEFII_GRAPH_COLLECTIVES', '0') == '1' and
+                                  dist.is_initialized() and dist.get_backend() == 'nccl')
         self._graphs = {}
         self._eager_steps = 0     # captures need an initialised optimiser state: the first steps run eagerly
         self._prefetch, self._trace_stream, self._trace_pool = [], None, []   # traces enqueued ahead: (input, ctx, event, checks)
@@ -242,6 +290,8 @@ class TrainStep:
         self.sg_scheduler = torch.optim.lr_scheduler.MultiStepLR(self.sg_optimizer, list(sg_sched_milestones),
                                                                  gamma=sg_sched_factor)
         self.trainable = [p for p in model.parameters() if p.requires_grad]
+        # several ranks: gradients live in one flat buffer that is all-reduced as it stands (FlatGrads)
+        self._flat = FlatGrads(self.trainable) if world_size > 1 and self.trainable else None
         # physg.conf weights the radiance colour with 0 and IDRLoss detaches it: the radiance network then runs without
         # autograd, weight norm and repacking (its weights never change).  Not with the secondary-consistency step, whose own
         # loss reads the radiance colour
@@ -260,6 +310,17 @@ class TrainStep:
             # the reference's DDP wrap broadcasts rank 0's parameters and buffers at construction (idr_train.py:308-309);
             # without it every rank would train the replica its own RNG initialised
             broadcast_parameters(model)
+
+    def _zero_grads(self, set_to_none=None):
+        if self._flat is not None:
+            self._flat.zero()
+            return
+        if set_to_none is None:
+            self.idr_optimizer.zero_grad()
+            self.sg_optimizer.zero_grad()
+        else:
+            self.idr_optimizer.zero_grad(set_to_none=set_to_none)
+            self.sg_optimizer.zero_grad(set_to_none=set_to_none)
 
     def _update(self, loss):
         """Gradient exchange + both Adam updates, with the reference's NaN check (idr_train.py:754-757: before
@@ -280,7 +341,13 @@ class TrainStep:
                 norms = torch.stack(torch._foreach_norm(grads))
                 bad = bad + (~torch.isfinite(norms).all()).reshape(1).to(torch.float32)
         if self.world_size > 1:
-            _, bad = allreduce_mean_gradients(self.trainable, self.world_size, flags=bad)
+            if self._flat is not None:
+                self._flat.adopt()
+                self._flat.flags.copy_(bad.reshape(-1).to(torch.float32))
+                self._flat.allreduce_mean(self.world_size)
+                bad = self._flat.flags.clone()
+            else:
+                _, bad = allreduce_mean_gradients(self.trainable, self.world_size, flags=bad)
         if self._fused:             # the flag stays a float 0 / 1 on the device: no compare / cast launches
             bad = bad.reshape(()).clamp(max=1.0) if self.world_size > 1 else bad.reshape(())
             self.nonfinite_steps += bad
@@ -510,7 +577,7 @@ class TrainStep:
         g.graph.replay()
         for p, grad in g.grads:       # an eager step in between may have re-pointed .grad
             p.grad = grad
-        if self.world_size > 1:
+        if not g.updates_in_graph:
             self._update(g.lo['loss'])
         return g.out, g.lo
 
@@ -569,8 +636,7 @@ class TrainStep:
             self._set_min_sdf(self.cur_iter)
             out = self.model(model_input)
         lo = self.loss(out, ground_truth)
-        self.idr_optimizer.zero_grad()
-        self.sg_optimizer.zero_grad()
+        self._zero_grads()
         if lo['loss'].requires_grad:        # a slice without a single hit (and no background term) has nothing to
             lo['loss'].backward()           # differentiate; the reference wraps backward in try/except (:764-770)
         self._update(lo['loss'])
@@ -598,8 +664,7 @@ class TrainStep:
             torch.nonzero(mask.reshape(-1)).flatten()[:self.secondary_batch_size]
         if idx.numel() == 0 and self.world_size <= 1:
             return None
-        self.idr_optimizer.zero_grad()
-        self.sg_optimizer.zero_grad()
+        self._zero_grads()
         loss = None
         if idx.numel() > 0:
             p = pts.detach().reshape(-1, 3).index_select(0, idx)

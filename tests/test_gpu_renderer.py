@@ -532,27 +532,37 @@ model { %s }
 
 
 def test_bench_two_processes_share_one_gpu():
-    """bench.py's multi-process path end to end (sharded inputs, gradient all-reduce, graph step with eager Adam, the
-    profiled step on every rank, clean exit) with two ranks on this box's one GPU over gloo - RCCL needs two devices."""
+    """bench.py's multi-process path end to end, started the way the driver starts the one-GPU bench - `python bench.py --gpus
+    2`, NO launcher: the script spawns its own two ranks (torch.distributed.run as a child process, before it touches a GPU).
+    Headline = config 3 (MC shading, secondary-consistency step, its own all-reduces) in weak scaling; nested: config 2 and
+    1 (graph step with eager Adam), config 4 as BASELINE defines it on several GPUs (--scaling strong: the global 8192-pixel
+    batch split over the ranks) and a band of config 5's frame.  Two ranks on this box's one GPU over gloo - RCCL needs two
+    devices."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NEFII_BENCH_BACKEND='gloo')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', '29517', os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup',
-           '4', '--no-cpu-baseline']
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=env, cwd=root)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '4', '--repeats', '1',
+           '--no-cpu-baseline', '--frame-rows', '4']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
     d = json.loads(line)
-    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['value'] > 0
-    assert d['config']['primary_rays_per_step_per_gpu'] == 4096
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['value'] > 0 and d['scaling'] == 'weak'
+    assert d['config']['workload'].startswith('cfg3') and d['config']['primary_rays_per_step_per_gpu'] == 4096 * 64
     assert d['config']['rank_param_spread'] < 1e-9       # both ranks hold the same parameters after 8+ synchronised steps
-    # the nested config-3 measurement ran on both ranks too (MC shading, secondary-consistency step, its own all-reduces)
-    assert d['cfg3']['value'] > 0 and d['cfg3']['config']['rank_param_spread'] < 1e-9, (d['cfg3']['config'], d['config'])
-    assert d['cfg3']['roofline']['secondary_hit_fraction'] > 0.2 and 0 < d['roofline']['frac_step'] < d['roofline']['frac_kernel']
+    assert d['roofline']['secondary_hit_fraction'] > 0.2 and 0 < d['roofline']['frac_8d'] < d['roofline']['frac_kernel']
+    assert d['roofline']['sustained_peak']['value'] > 500.0
+    for k in ('cfg2', 'cfg1'):
+        assert d[k]['value'] > 0 and d[k]['config']['rank_param_spread'] < 1e-9 and d[k]['scaling'] == 'weak', d[k]['config']
+    assert d['cfg4']['scaling'] == 'strong' and d['cfg4']['config']['primary_rays_per_step_per_gpu'] == 4096 * 64
+    assert d['cfg4']['config']['rank_param_spread'] < 1e-9
+    assert d['cfg5']['n_gpus'] == 2 and d['cfg5']['config']['finite'] and d['cfg5']['config']['primary_rays_per_frame'] == 4 * 800 * 256
+    assert not d['invalid']
 
 
 def _run_bench(args, nproc, port, timeout=600):
