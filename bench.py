@@ -100,7 +100,8 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None):
             out = R.forward(inp)
             lo = orr.idr_loss(out, gt, lc)
             opt.zero_grad()
-            lo['loss'].backward()
+            if lo['loss'].requires_grad:        # (a sample without a single hit has nothing to differentiate)
+                lo['loss'].backward()
             opt.step()
             dt = time.perf_counter() - t0
             if first is None:
@@ -465,7 +466,9 @@ def run_render(name, args, frames, rank, world, dev, backend):
             'config': {'workload': '%s: conf.conf model at full width on the non-convex stand-in, %d x %d pixels x %d rays per '
                                    'pixel, chunks of %d pixels dealt round-robin over %d rank(s) and gathered on rank 0'
                                    % (name, rows, W, w['num_rays'], (1 << level) // w['num_rays'], world),
-                       'primary_rays_per_frame': rays, 'seconds_per_800x800_frame': elapsed / frames * (H / rows),
+                       'primary_rays_per_frame': rays,
+                       # (a band through the object is dearer per pixel than the frame's average: no extrapolation from it)
+                       'seconds_per_800x800_frame': elapsed / frames if rows == H else None,
                        'hit_pixel_fraction': out['network_object_mask'].float().mean().item(),
                        'finite': bool(all(torch.isfinite(v).all() for v in out.values() if v.dtype.is_floating_point)),
                        'parallelism': 'pixel chunks x %d' % world},
@@ -473,14 +476,23 @@ def run_render(name, args, frames, rank, world, dev, backend):
 
 
 def measure_sustained(lib):
-    """nefii_mfma_sustained_probe: TFLOP/s of a bare v_mfma_f32_16x16x32_f16 loop on random operands, every CU, ~20 ms."""
+    """nefii_mfma_sustained_probe: TFLOP/s of a bare v_mfma_f32_16x16x32_f16 loop on random operands on every CU, for three
+    launch lengths - the part is power-limited and what it holds depends on how long the burst lasts: ~0.3 ms (a small
+    tracer round), ~3 ms (a big round of config 3) and ~25 ms of uninterrupted MFMAs (`value`: the sustained figure)."""
     import ctypes
-    ms, fl = ctypes.c_float(), ctypes.c_double()
-    rc = lib.nefii_mfma_sustained_probe(200000, ctypes.byref(ms), ctypes.byref(fl), None)
-    if rc != 0 or ms.value <= 0:
-        return None
-    return {'value': fl.value / (ms.value * 1e-3) / 1e12, 'unit': 'TFLOP/s', 'ms': ms.value,
-            'what': 'v_mfma_f32_16x16x32_f16 only, random operands, 4 accumulator chains per wave, one wave per SIMD, 256 workgroups'}
+    out = {}
+    for tag, groups in (('burst_0.3ms', 3700), ('burst_3ms', 37000), ('value', 250000)):
+        ms, fl = ctypes.c_float(), ctypes.c_double()
+        rc = lib.nefii_mfma_sustained_probe(groups, ctypes.byref(ms), ctypes.byref(fl), None)
+        if rc != 0 or ms.value <= 0:
+            return None
+        out[tag] = fl.value / (ms.value * 1e-3) / 1e12
+        if tag == 'value':
+            out['ms'] = ms.value
+    out['unit'] = 'TFLOP/s'
+    out['what'] = ('v_mfma_f32_16x16x32_f16 only, random operands, 4 accumulator chains per wave, one wave per SIMD, 256 '
+                   'workgroups; value = a 25 ms launch (behind a 6 ms warm-up launch), burst_* = shorter launches')
+    return out
 
 
 def spawn_ranks(n):
@@ -507,8 +519,8 @@ def main():
     ap.add_argument('--no-side-measurement', action='store_true',
                     help='skip the untimed side loop without the min-SDF search (profiling runs: nearly every step of the\n'
                          'process is then the headline step, so rocprofv3 per-kernel averages compare directly)')
-    ap.add_argument('--cpu-sample-rays', type=int, default=1024,
-                    help='primary rays of the CPU baseline\'s sample (MC workloads: ~2 s per 16-thread step at 1024)')
+    ap.add_argument('--cpu-sample-rays', type=int, default=2048,
+                    help='primary rays of the CPU baseline\'s sample (MC workloads: ~4 s per 16-thread step at 2048)')
     ap.add_argument('--repeats', type=int, default=3, help='repetitions of the timed K-step region (median reported)')
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
                     help='N > 1: weak = every rank its own num_pixels (default); strong = the workload\'s global batch split '
@@ -554,8 +566,9 @@ def main():
                                       side=True, sustained=sustained)
         nested['cfg2_near'] = run_workload('cfg2_near', args, short['steps'], short['warmup'], rank, world, dev, backend, lib,
                                            side=False, sustained=sustained)
-        nested['cfg1'] = run_workload('cfg1', args, short['steps'], short['warmup'], rank, world, dev, backend, lib,
-                                      side=False, sustained=sustained)
+        # (config 1's traces are enqueued in groups of three, four groups ahead: a dozen steps until the schedule has settled)
+        nested['cfg1'] = run_workload('cfg1', args, max(short['steps'], 30), max(short['warmup'], 12), rank, world, dev, backend,
+                                      lib, side=False, sustained=sustained)
         # BASELINE's 8-GPU training config as it is defined: the global 8192-pixel batch split over the ranks
         nested['cfg4'] = run_workload('cfg4', args, max(1, min(args.steps, 10)), min(args.warmup, 2), rank, world, dev, backend,
                                       lib, side=False, scaling='strong' if world > 1 else 'weak', sustained=sustained)

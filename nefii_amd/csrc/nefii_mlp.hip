@@ -314,14 +314,17 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(nefii_mlp m, const 
     }
 }
 
-static int check_mlp(const nefii_mlp *m) {
+// need_f32: the caller reads the f32 fragments (w_fwd); the fp16-MFMA entry points do not - nets that only run on those
+// carry NULL there (nefii_amd.ops.PackedMLP(half=...)), so that an f32 entry point called on them fails instead of
+// multiplying by weights that were never packed
+static int check_mlp(const nefii_mlp *m, bool need_f32 = true) {
     if (!m || m->n_layers < 1 || m->n_layers > NEFII_MAX_LAYERS) return NEFII_E_ARG;
     for (int l = 0; l < m->n_layers; ++l) {
         const nefii_layer &L = m->layer[l];
         if ((L.k_x & 31) || (L.k_e & 31) || (L.n_pad & 31) || L.k_x + L.k_e <= 0) return NEFII_E_SHAPE;
         if (L.k_x > NEFII_MAX_WIDTH || L.k_e > NEFII_MAX_ENC || L.n_pad > NEFII_MAX_WIDTH || L.n_out > L.n_pad)
             return NEFII_E_SHAPE;
-        if (!L.w_fwd || !L.bias) return NEFII_E_ARG;
+        if ((need_f32 && !L.w_fwd) || !L.bias) return NEFII_E_ARG;
         if (l > 0 && L.k_x != m->layer[l - 1].n_pad) return NEFII_E_SHAPE;
     }
     int ew = 0;
@@ -1001,7 +1004,7 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, con
 }
 
 static int check_mlp16(const nefii_mlp *m, bool bwd) {
-    int rc = check_mlp(m);
+    int rc = check_mlp(m, false);
     if (rc) return rc;
     for (int l = 0; l < m->n_layers; ++l) {
         if (!m->layer[l].w_f16x3) return NEFII_E_ARG;

@@ -234,8 +234,9 @@ class TrainStep:
         # geometry those reach nothing but the VALUE of mask_loss: no gradient - and the
         # reference reads the loss value only in its NaN check and in the line it prints every 50 iterations
         # (idr_train.py:754,784).  min_sdf_every = E > 1 runs the search on the iterations with cur_iter % E == 0 only (the
-        # runner passes its logging period): the logged losses are the reference's, parameters and optimizer state are
-        # bit-identical to the every-iteration schedule (test_min_sdf_on_reporting_iterations_only), the losses returned on
+        # runner passes its logging period): the logged losses are the reference's, the gradients - hence parameters and
+        # optimizer state - are those of the every-iteration schedule (test_min_sdf_on_reporting_iterations_only: as close as
+        # two runs of one schedule are to each other - the light's gradient is summed with float atomics), the losses returned on
         # the other iterations carry a mask_loss computed without the search (finite whenever the true one is).  The
         # search's uniform draw is made on every iteration either way.  Default (None): NEFII_MIN_SDF_EVERY, else 1 - every
         # iteration, the reference's schedule; trainable geometry always runs it.

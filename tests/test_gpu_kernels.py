@@ -507,6 +507,59 @@ def test_tracer_coarse_pass_changes_no_decision(case):
                 assert c[:, 4].sum() == 0 and c[:, 1].sum() == c[:, 6].sum()
 
 
+def test_pack_mlp_equals_the_per_layer_packers():
+    """nefii_pack_mlp (every layer and every fragment form in ONE launch: what PackedMLP.pack runs) against the per-layer
+    entry points the header still exports - nefii_pack_linear (f32 fragments, transpose, padded bias), nefii_pack_linear_f16x3
+    and _f16x3_bwd - bit for bit, for the SDF net (f32 + fp16 forms) and a radiance net on the fp16 kernels; and the fp16 nets
+    carry NO f32 fragments: an f32 entry point called on one returns NEFII_E_ARG instead of multiplying by unpacked zeros."""
+    import ctypes
+    from nefii_amd import _lib
+    lib = _lib.lib()
+    mc = syn.model_conf('conf')
+    sd = syn.make_state_dict(mc, seed=5, scene='bowl')
+    st = torch.cuda.current_stream().cuda_stream
+    # SDF net: f32 and fp16 forms
+    specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
+    pm = ops.PackedMLP(specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, enc, 0, DEV, f16x3=True)
+    ws, bs = zip(*[nets.linear_params(sd, 'implicit_network.lin%d' % l) for l in range(len(specs))])
+    ws, bs = [w.to(DEV).float().contiguous() for w in ws], [b.to(DEV).float().contiguous() for b in bs]
+    pm.pack(ws, bs)
+    for l, sp in enumerate(specs):
+        k = sp.k_x + sp.k_e
+        wf, wb = torch.zeros(k * sp.n_pad, device=DEV), torch.zeros(k * sp.n_pad, device=DEV)
+        bp = torch.zeros(sp.n_pad, device=DEV)
+        assert lib.nefii_pack_linear(ws[l].data_ptr(), bs[l].data_ptr(), sp.n_out, sp.k_in, sp.x_src0, sp.x_len, sp.e_src0,
+                                     sp.e_len, sp.scale, wf.data_ptr(), wb.data_ptr(), bp.data_ptr(), st) == 0
+        h = torch.zeros(2 * k * sp.n_pad, device=DEV, dtype=torch.float16)
+        hb = torch.zeros(2 * k * sp.n_pad, device=DEV, dtype=torch.float16)
+        assert lib.nefii_pack_linear_f16x3(ws[l].data_ptr(), sp.n_out, sp.k_in, sp.x_src0, sp.x_len, sp.e_src0, sp.e_len,
+                                           sp.scale, h.data_ptr(), st) == 0
+        assert lib.nefii_pack_linear_f16x3_bwd(ws[l].data_ptr(), sp.n_out, sp.k_in, sp.x_src0, sp.x_len, sp.e_src0, sp.e_len,
+                                               sp.scale, hb.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(pm.w_fwd[l], wf) and torch.equal(pm.w_bwd[l], wb) and torch.equal(pm.bias[l], bp), l
+        assert torch.equal(pm.w_f16[l].view(torch.int16), h.view(torch.int16)), l
+        assert torch.equal(pm.w_f16b[l].view(torch.int16), hb.view(torch.int16)), l
+    # a net on the fp16-MFMA kernels: fp16 forms equal, no f32 fragments at all
+    from nefii_amd import conf as nconf
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    m = IDRNetwork(nconf.from_dict(mc))
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV)
+    rn = m.rendering_network
+    pmr = rn.packed(torch.device(DEV))
+    if pmr is not None and pmr.half:
+        assert all(w is None for w in pmr.w_fwd) and all(w is None for w in pmr.w_bwd)
+        assert all(pmr.struct.layer[l].w_fwd is None for l in range(pmr.n_layers))
+        n = 64
+        a = torch.zeros(n, 3, device=DEV)
+        out = torch.empty(n, pmr.specs[-1].n_out, device=DEV)
+        feat = torch.zeros(n, max(pmr.feat_width, 1), device=DEV)
+        rc = lib.nefii_mlp_forward(ctypes.byref(pmr.struct), a.data_ptr(), a.data_ptr(), a.data_ptr(), feat.data_ptr(), n,
+                                   out.data_ptr(), out.shape[1], None, 0, None, 0, st)
+        assert rc == -1, rc
+
+
 def test_tracer_audits_its_coarse_bound():
     """nefii_trace_rays counter 8: the largest |single pass - split| among the coarse samples a trace re-evaluated (each of
     them IS evaluated both ways).  (1) It is a true difference: positive, below the calibrated bound, and no larger than the

@@ -651,9 +651,11 @@ def test_prefetched_trace_gives_the_same_steps(graph, lookahead):
 def test_min_sdf_on_reporting_iterations_only(graph, lookahead):
     """TrainStep(min_sdf_every=E): under frozen geometry the tracer's min-SDF search (ray_tracing.py:309-337) only feeds the
     VALUE of mask_loss, which the reference reads at its logging points (idr_train.py:754,784).  Running it on the iterations
-    with cur_iter % E == 0 only must leave parameters and both Adam states BIT-identical to the every-iteration schedule,
-    the losses of the reporting iterations bit-identical too (the search's draw is made every iteration: same RNG stream),
-    and every other loss term of every iteration unchanged - plain steps, traces enqueued ahead one at a time and in groups."""
+    with cur_iter % E == 0 only must change nothing else: mask_loss on the reporting iterations BIT-identical (it depends on
+    the frozen geometry and the trace alone; the search's draw is made every iteration: same RNG stream), every other loss
+    term of every iteration and the parameters / Adam states after 13 steps as close to the every-iteration schedule as a
+    second run of that schedule is to the first (the light's gradient leaves sg_render's backward through float atomics: two
+    identical runs differ in its last bits) - plain steps, traces enqueued ahead one at a time and in groups."""
     from nefii_amd.training.step import TrainStep
     mc = syn.model_conf('physg', hidden=64)
     sd = syn.make_state_dict(mc, seed=4, bumpy=0.02)
@@ -665,32 +667,38 @@ def test_min_sdf_on_reporting_iterations_only(graph, lookahead):
         inp, gt = syn.make_inputs(256, (64, 64), 100.0 + 5 * it, (0.2, 0.1, 2.0 + 0.04 * it), -1, seed=30 + it)
         batches.append((to_dev(inp), {'rgb': gt.to(DEV)}))
     runs = []
-    for every in (1, E):
+    for every in (1, 1, E):
         torch.manual_seed(77)                   # the search's uniforms come from the host generator
         m = build_model(mc, sd, True)
         st = TrainStep(m, lc, graph=graph, graph_bucket=64, graph_after=2, min_sdf_every=every)
         losses = []
         for i, (inp, gt) in enumerate(batches):
-            nxt = [b[0] for b in batches[i + 1:i + 1 + lookahead]] or None if lookahead else None
+            nxt = ([b[0] for b in batches[i + 1:i + 1 + lookahead]] or None) if lookahead else None
             out, lo = st(inp, gt, nxt)
             losses.append({k: v.item() for k, v in lo.items()})
-        opt = [{k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in s_.items()}
-               for o in (st.idr_optimizer, st.sg_optimizer) for s_ in o.state.values()]
-        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}, opt, torch.rand(1).item()))
-    (l0, p0, o0, r0), (l1, p1, o1, r1) = runs
-    assert r0 == r1, 'the two schedules leave the host RNG stream in different places'
+        state = {k: v.detach().clone() for k, v in m.state_dict().items() if v.dtype.is_floating_point}
+        for j, o in enumerate((st.idr_optimizer, st.sg_optimizer)):
+            for n_, s_ in enumerate(o.state.values()):
+                for k, v in s_.items():
+                    if torch.is_tensor(v) and v.dtype.is_floating_point and v.numel() > 1:
+                        state['opt%d.%d.%s' % (j, n_, k)] = v.detach().clone()
+        runs.append((losses, state, torch.rand(1).item()))
+    (l0, p0, r0), (l0b, p0b, r0b), (l1, p1, r1) = runs
+    assert r0 == r0b == r1, 'the schedules leave the host RNG stream in different places'
     for k in p0:
-        assert torch.equal(p0[k], p1[k]), k
-    for a, b in zip(o0, o1):
-        for k in a:
-            assert (torch.equal(a[k], b[k]) if torch.is_tensor(a[k]) else a[k] == b[k]), k
+        noise = rel_l2(p0b[k], p0[k])
+        assert rel_l2(p1[k], p0[k]) <= max(4.0 * noise, 1e-6), (k, rel_l2(p1[k], p0[k]), noise)
     differ = 0
     for i, (a, b) in enumerate(zip(l0, l1)):
         for k in a:
-            if i % E == 0 or k not in ('loss', 'mask_loss'):
+            if k == 'mask_loss' and i % E == 0:
                 assert a[k] == b[k], (i, k, a[k], b[k])
-            else:
+            elif k in ('loss', 'mask_loss') and i % E != 0:
                 differ += a[k] != b[k]
+            elif k != 'loss':
+                assert abs(a[k] - b[k]) <= 1e-5 * max(abs(a[k]), 1e-3), (i, k, a[k], b[k])
+            else:
+                assert abs(a[k] - b[k]) <= 1e-5 * max(abs(a[k]), 1e-3), (i, k, a[k], b[k])
     assert differ > 0, 'the schedule never skipped a search: the test does not test'
 
 
