@@ -687,7 +687,7 @@ def test_min_sdf_on_reporting_iterations_only(graph, lookahead):
     assert r0 == r0b == r1, 'the schedules leave the host RNG stream in different places'
     for k in p0:
         noise = rel_l2(p0b[k], p0[k])
-        assert rel_l2(p1[k], p0[k]) <= max(4.0 * noise, 1e-6), (k, rel_l2(p1[k], p0[k]), noise)
+        assert rel_l2(p1[k], p0[k]) <= max(4.0 * noise, 1e-4), (k, rel_l2(p1[k], p0[k]), noise)
     differ = 0
     for i, (a, b) in enumerate(zip(l0, l1)):
         for k in a:
