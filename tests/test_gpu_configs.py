@@ -58,6 +58,9 @@ def gpu_forward_with_per_ray_draws(m, inp, uniforms):
 
 
 SHRUNK = {'cfg2': 256, 'cfg3': 48, 'cfg4': 48}
+# measured on these exact workloads (round 4): every count of discrete differences between the HIP path and the oracle
+# (a sampled lobe that differs = a uniform draw within rounding of a CDF boundary: 0-1 rays of config 3's 3072 by box)
+PINNED_DISCRETE = {'cfg2': {'flips': 0}, 'cfg3': {'flips': 0, 'dir': 2, 'vis': 0}, 'cfg4': {'flips': 0}}
 
 
 @pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg4'])
@@ -99,7 +102,12 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
     out = gpu_forward_with_per_ray_draws(m, to_dev(flat), uniforms)
     stats = compare_outputs(out, ref, max_flips=max(2, n_ray // 1000), what=wl + ' shrunk', rays_per_pixel=1,
                             ray_hit=m.last_ray_hit, ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02)
-    print('[%s] %d rays, oracle %.1f s, hit fraction %.3f' % (wl, n_ray, t_oracle, ref['_ray_hit'].float().mean()))
+    print('[%s] %d rays, oracle %.1f s, hit fraction %.3f, discrete differences %s' % (
+        wl, n_ray, t_oracle, ref['_ray_hit'].float().mean(), stats))
+    # where the measured count of discrete differences IS zero it is asserted to be zero (the allowances above are for
+    # workloads with knife-edge rays): hit-mask flips, rays with another sampled lobe, secondary rays hitting on one side only
+    for k, allowed in PINNED_DISCRETE[wl].items():
+        assert stats[k] <= allowed, (wl, k, stats[k], allowed)
     if mc_shading:
         sm, rsm = m.last_ray_hit.cpu(), ref['_ray_hit']
         assert ref['secondary_mask'].float().mean().item() > 0.2          # the indirect branch does real work here
@@ -117,7 +125,10 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
             assert p.grad is not None, name
             worst = max(worst, rel_l2(p.grad, gref))
             # 3 x the worst value measured in round 3 (5.1e-4 / 9.3e-4 / 1.9e-3): a regression of the one-pass fp16
-            # backward or the weight-gradient GEMM no longer hides inside a 5e-2 bound
+            # backward or the weight-gradient GEMM no longer hides inside a 5e-2 bound.  What this check can NOT resolve:
+            # the oracle itself sits 1.8e-3 from the reference on `rendering_network.lin0.bias` of the full-width fixture
+            # (forward_conf512_train: CPU fp32 against CPU fp32, the summation order of a tiny gradient) - on such biases
+            # a difference below ~2e-3 is within the oracle's own distance from the reference
             assert rel_l2(p.grad, gref) < {'cfg2': 1.5e-3, 'cfg3': 3e-3, 'cfg4': 6e-3}[wl], (name, rel_l2(p.grad, gref))
     print('[%s] worst parameter-gradient rel-L2 %.2e' % (wl, worst))
     # ---- algorithmic SDF evaluations: tracer counters (primary + secondary traces) = the oracle's evaluation counts
@@ -265,3 +276,53 @@ def test_config5_render_strip_vs_oracle():
     assert rel_l2(merged['normal_values'], per_px('normal_values')[:, 0]) < 1e-5
     a, b = merged['sg_rgb_values'].mean().item(), out['sg_rgb_values'].mean().item()
     assert abs(a - b) < 0.05 * abs(b), (a, b)           # other draws, same estimator: 4096 rays x 3 samples
+
+
+def test_config5_scattered_pixels_of_the_frame_vs_oracle():
+    """Config 5's frame at its real geometry (800 x 800, 256 rays per pixel, the frame's own sub-pixel jitter): 16 pixels
+    scattered over the WHOLE frame - half of them inside the object's projection, half anywhere (silhouette, background) -
+    per ray against the oracle with injected sampler draws, zero hit-mask flips tolerated beyond the knife-edge allowance,
+    then through render_frame at the frame's own memory_capacity_level against the per-ray forward on everything that does
+    not pass through the sampler.  (tools/render_full_frame.py does the same on 64 pixels of a whole rendered frame; this
+    is the part of it that fits a test: ~20 s of oracle.)"""
+    from nefii_amd.training import render as RR
+    w = syn.WORKLOADS['cfg5']
+    mc, sd = syn.workload_state_dict('cfg5', seed=0)
+    H, W = w['image_hw']
+    full = syn.frame_inputs(w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'])
+    g = torch.Generator().manual_seed(5)
+    # the bowl (radius 0.8 at distance 2.4, focal 1111 px) projects to ~370 px around the centre: a disc of 250 px is on it
+    rad, ang = 250.0 * torch.rand(8, generator=g).sqrt(), 6.2831853 * torch.rand(8, generator=g)
+    on = ((H // 2 + rad * ang.sin()).long() * W + (W // 2 + rad * ang.cos()).long())
+    pick = torch.cat([on, torch.randperm(H * W, generator=g)[:8]]).unique()
+    P = pick.numel()
+    sub = {'uv': full['uv'][:, pick].contiguous(), 'object_mask': full['object_mask'][:, pick].contiguous(),
+           'pose': full['pose'], 'intrinsics': full['intrinsics']}
+    flat, _, R = per_ray_layout(sub)
+    n_ray = flat['uv'].shape[1]
+    assert R == 256 and n_ray == P * 256
+    uniforms = torch.rand(n_ray, 7, generator=g)
+    Ro = orr.Renderer({k: v.clone() for k, v in sd.items()}, mc, training=False)
+    Ro.dead_work = False
+    with torch.no_grad():
+        ref = Ro.forward(flat, None, uniforms, None)
+    m = build_model(mc, sd, False)
+    with torch.no_grad():
+        out = gpu_forward_with_per_ray_draws(m, to_dev(flat), uniforms)
+    stats = compare_outputs(out, ref, max_flips=2, what='cfg5 scattered pixels', rays_per_pixel=1, ray_hit=m.last_ray_hit,
+                            ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02)
+    hit = ref['_ray_hit'].float().mean().item()
+    print('[cfg5 scattered] %d pixels, %d rays, hit fraction %.3f, %s' % (P, n_ray, hit, stats))
+    assert 0.3 < hit < 0.95 and ref['secondary_mask'].float().mean().item() > 0.0
+    both = (out['network_object_mask'].cpu() == ref['network_object_mask'])
+    assert rel_l2(out['sg_rgb_values'][both.to(DEV)], ref['sg_rgb_values'][both]) < 1e-3
+    assert rel_l2(out['sg_diffuse_albedo_values'][both.to(DEV)], ref['sg_diffuse_albedo_values'][both]) < 1e-3
+    # the frame path (chunks of 2^18 / 256 = 1024 pixels, fresh sampler draws) on the same pixels
+    merged = RR.render_frame(m, to_dev(sub), P, num_rays=256, memory_capacity_level=w['memory_capacity_level'])
+    per_px = lambda k: out[k].reshape(P, R, -1)
+    assert torch.equal(merged['network_object_mask'], out['network_object_mask'].reshape(P, R).all(1))
+    for k in ('points', 'sg_diffuse_albedo_values', 'sg_roughness_values', 'idr_rgb_values'):
+        assert rel_l2(merged[k], per_px(k).mean(1)) < 1e-5, k
+    assert rel_l2(merged['normal_values'], per_px('normal_values')[:, 0]) < 1e-5
+    a, b = merged['sg_rgb_values'].mean().item(), out['sg_rgb_values'].mean().item()
+    assert abs(a - b) < 0.05 * abs(b), (a, b)
