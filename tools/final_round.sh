@@ -2,7 +2,7 @@
 # Everything profiles/rNN/ holds for a round, in one gpurun call:  tools/final_round.sh <tag>
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-T=${1:-r03}; O=gpurun_out/$T
+T=${1:-r04}; O=gpurun_out/$T
 mkdir -p $O
 for w in cfg2 cfg3 cfg4; do
     bash tools/profile_round.sh $T $w eval_kernel16 $([ $w = cfg2 ] && echo 20 || echo 10) > $O/log_$w.txt 2>&1
@@ -21,4 +21,6 @@ python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 python3 tools/render_bench.py 2> /dev/null | tail -1 > $O/render_cfg5_crop.json
 python3 tools/trace_rounds.py cfg3 2> /dev/null | grep -v "Warning\|WeightNorm\|amdgpu" > $O/rounds_cfg3.txt
 python3 tools/trace_rounds.py cfg2 2> /dev/null | grep -v "Warning\|WeightNorm\|amdgpu" > $O/rounds_cfg2.txt
+(bash tools/pmc_microbench.sh 12) > $O/pmc_microbench_eval_tile.txt 2>&1
+tools/probes/slot_probe > $O/slot_probe.txt 2>&1
 tail -c 300 $O/bench_default.json
