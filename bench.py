@@ -362,6 +362,10 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                 'flops_per_sdf_eval': f_eval, 'sdf_evals_per_step': queries,
                 'sdf_evals_executed_split_precision': executed, 'sdf_evals_executed_single_pass': executed_coarse,
                 'coarse_tau': coarse_tau,
+                # the online audit of that bound (every refined sample is evaluated both ways): the largest |single pass -
+                # split| the tracer saw in this run, and what ImplicitNetwork.note_coarse_audit did about it (nothing, if empty)
+                'coarse_audit_max': float(model.implicit_network.coarse_audit_max),
+                'coarse_audit_events': [list(e) for e in model.implicit_network.coarse_audit_events],
                 'sdf_evals_per_primary_ray': queries / rays_per_rank,
                 'nonempty_launches_per_step': launches, 'launches_per_step': n_eval.value,
                 'kernel_ms_per_step': eval_ms.value, 'tracer_span_ms': span_ms.value,

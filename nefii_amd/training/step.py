@@ -328,7 +328,13 @@ class TrainStep:
         backward / step) as a device-side guard: when the loss - or a gradient - is not finite on ANY rank, every rank
         zeroes its gradients and both optimizers skip the step: parameters, moments and step counters are those of the
         last good iteration, so the emergency checkpoint the runner writes is the pre-NaN state.  The flag travels in
-        the gradient all-reduce: one collective, no host sync."""
+        the gradient all-reduce: one collective, no host sync.
+        After a cancelled step `.grad` is UNDEFINED on the fused (GPU) path - the non-finite values stay where backward put
+        them (several ranks: the all-reduce spreads them) and only the optimizers look at the flag; anything that reads
+        gradients between steps (a gradient-norm log) must check `nonfinite_steps` first.  The check itself is torch's amp
+        multi-tensor kernel (`torch._amp_foreach_non_finite_check_and_unscale_`, what GradScaler.unscale_ runs) and the skip is
+        the fused Adam's `found_inf` input: private interfaces, pinned by
+        test_nonfinite_step_is_skipped_not_run_on_zero_gradients (eager and graph) against a torch upgrade."""
         grads = [p.grad for p in self.trainable if p.grad is not None]
         if self._fused:
             # one multi-tensor kernel (the one torch.amp.GradScaler unscales with; scale 1.0 leaves every value as it is)
