@@ -364,3 +364,41 @@ def test_config5_frame_plan_matches_the_reference(world):
     # every rank renders the same number of pixels of the frame (xGMI gather of equal-sized packed buffers)
     px = [sum(split[c]['uv'].shape[1] for c in order[a:b]) for a, b in slices]
     assert len(set(px)) == 1 and sum(px) == total
+
+
+def test_flat_grads_are_views_of_one_buffer():
+    """training/step.py:FlatGrads - the multi-rank step's gradients: every parameter's .grad is a view into ONE flat buffer
+    (so the exchange is one all-reduce of the buffer as it stands), zero() is one fill that also re-points .grad, backward
+    accumulates into the views IN PLACE, adopt() takes over gradients that landed in tensors of their own, and the flag slot
+    rides behind the parameters."""
+    from nefii_amd.training.step import FlatGrads
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3))
+    params = list(net.parameters())
+    fg = FlatGrads(params, n_flags=1)
+    n_par = sum(p.numel() for p in params)
+    assert fg.flat.numel() == n_par + 1 and fg.flags.data_ptr() == fg.flat[n_par:].data_ptr()
+    fg.zero()
+    ptrs = [p.grad.data_ptr() for p in params]
+    assert all(p.grad is v for p, v in zip(params, fg.views))
+    x = torch.randn(11, 5)
+    net(x).square().sum().backward()
+    assert [p.grad.data_ptr() for p in params] == ptrs, 'backward replaced a gradient view instead of accumulating into it'
+    ref = torch.cat([p.grad.reshape(-1) for p in params])
+    assert torch.equal(fg.flat[:n_par], ref) and ref.abs().sum() > 0
+    # a second backward accumulates; zero() clears through the views
+    net(x).square().sum().backward()
+    assert torch.allclose(fg.flat[:n_par], 2 * ref)
+    fg.zero()
+    assert fg.flat.abs().sum() == 0 and all(p.grad.abs().sum() == 0 for p in params)
+    # gradients that ended up elsewhere (optimizer.zero_grad(set_to_none=True) + backward; a captured graph's own tensors)
+    for p in params:
+        p.grad = None
+    net(x).square().sum().backward()
+    assert all(p.grad.data_ptr() != q for p, q in zip(params, ptrs))
+    fg.adopt()
+    assert [p.grad.data_ptr() for p in params] == ptrs and torch.allclose(fg.flat[:n_par], ref)
+    # mean over "ranks" without a process group: world_size 1 is a no-op elsewhere; here only the scale is checked
+    fg.flags.fill_(1.0)
+    fg.flat[:n_par].mul_(1.0 / 4)
+    assert torch.allclose(fg.flat[:n_par], ref / 4) and fg.flags.item() == 1.0
