@@ -45,6 +45,7 @@ def main(argv=None):
     p.add_argument('--dataset_class', type=str, default='',
                    help="default: the conf's train.dataset_class; nefii_amd.datasets.synthetic_dataset."
                         "SyntheticSceneDataset needs no data on disk")
+    p.add_argument('--coordinate_type', type=str, default='mitsuba')     # exp_runner.py: axes of the logged envmap image
     p.add_argument('--no_graph', default=False, action='store_true')
     p.add_argument('--plots', default=False, action='store_true',
                    help="every train.plot_freq iterations render one training view and write its buffers under plots/")
@@ -63,7 +64,7 @@ def main(argv=None):
         pretrain_geometry_path=opt.pretrain_geometry_path, pretrain_idr_rendering_path=opt.pretrain_idr_rendering_path,
         pretrain_diffuse_path=opt.pretrain_diffuse_path, light_sg_path=opt.light_sg, geometry=opt.geometry, geometry_neus=opt.geometry_neus,
         local_rank=local_rank, model_class=opt.model_class, dataset_class=opt.dataset_class or None,
-        graph=not opt.no_graph, plots=opt.plots)
+        graph=not opt.no_graph, plots=opt.plots, coordinate_type=opt.coordinate_type)
     runner.run()
 
 

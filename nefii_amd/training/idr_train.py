@@ -56,6 +56,7 @@ class IDRTrainRunner:
         self.freeze_diffuse = kwargs.get('freeze_diffuse', False)
         self.ckpt_freq = kwargs.get('ckpt_freq', self.conf.get_int('train.ckpt_freq', default=5000))
         self.log_freq = kwargs.get('log_freq', 50)
+        self.coordinate_type = kwargs.get('coordinate_type', 'mitsuba')         # idr_train.py:67 (the envmap image's axes)
         self.prefetch = kwargs.get('prefetch', True)       # TrainStep.prefetch_trace (frozen geometry only)
         if kwargs.get('train_cameras', False):
             raise NotImplementedError('camera optimisation is outside the Step-2 hot path')
@@ -169,6 +170,12 @@ class IDRTrainRunner:
             self.step.sg_scheduler.load_state_dict(saved['sg_sched']['scheduler_state_dict'])
             self.step.retensor_lr()
         self.history = []
+        # the reference's tensorboardX log (idr_train.py:114-115): an event file in <exps>/<expname>/<timestamp>/, written by
+        # this package's own writer (utils/tb_writer.py: tensorboard / tensorboardX are not installable here); rank 0 only
+        self.writer = None
+        if self.rank == 0 and kwargs.get('tensorboard', True):
+            from ..utils.tb_writer import SummaryWriter
+            self.writer = SummaryWriter(os.path.join(self.expdir, self.timestamp))
 
     # ---- idr_train.py:329-372
     def save_checkpoints(self, epoch):
@@ -206,7 +213,15 @@ class IDRTrainRunner:
             out = R.render_frame(self.model, model_input, ds.total_pixels, num_rays=max(self.plot_num_rays, 1),
                                  memory_capacity_level=self.memory_capacity_level)
             plots = os.path.join(self.expdir, self.timestamp, 'plots')
-            R.write_frame(self.model, out, gt['rgb'].to(self.device), model_input['pose'], ds.img_res, plots, it)
+            buf = R.write_frame(self.model, out, gt['rgb'].to(self.device), model_input['pose'], ds.img_res, plots, it)
+            if self.writer is not None:                  # idr_train.py:516-550: the training view as images
+                self.writer.add_image('train/panel-%d' % view, buf['panel'].clamp(0., 1.).permute(2, 0, 1), it)
+                env = R.compute_envmap(self.model.envmap_material_network.get_light(), 256, 512,
+                                       upper_hemi=getattr(self.model.envmap_material_network, 'upper_hemi', False),
+                                       coordinate_type=getattr(self, 'coordinate_type', 'mitsuba'))
+                env = env.clamp(min=0.).pow(1. / 2.2)      # tonemap_img + clip_img (idr_train.py:390-391,548-550)
+                self.writer.add_image('train/envmap', env.clamp(0., 1.).permute(2, 0, 1), it)
+                self.writer.flush()
         finally:
             ds.sampling_idx, ds.sampling_rays = keep
             self.model.train()
@@ -275,6 +290,20 @@ class IDRTrainRunner:
                            'idr_lr': float(self.step.idr_optimizer.param_groups[0]['lr']),
                            'sg_lr': float(self.step.sg_optimizer.param_groups[0]['lr'])}
                     self.history.append(rec)
+                    if self.writer is not None:          # the scalars of the reference's log() (idr_train.py:881-895)
+                        for k in ('idr_rgb_loss', 'sg_rgb_loss', 'mask_loss', 'normalsmooth_loss', 'background_rgb_loss'):
+                            if k in lo:
+                                self.writer.add_scalar(k, lo[k].item(), it)
+                        self.writer.add_scalar('loss', loss, it)
+                        self.writer.add_scalar('sg_psnr', rec['sg_psnr'], it)
+                        if 'idr_rgb_loss' in lo:
+                            self.writer.add_scalar('idr_psnr', float(mse2psnr(lo['idr_rgb_loss'].item())), it)
+                        for k in ('alpha', 'mask_weight', 'idr_rgb_weight', 'sg_rgb_weight', 'normalsmooth_weight'):
+                            if hasattr(self.loss, k):
+                                self.writer.add_scalar(k, float(getattr(self.loss, k)), it)
+                        self.writer.add_scalar('idr_lr', rec['idr_lr'], it)
+                        self.writer.add_scalar('sg_lr', rec['sg_lr'], it)
+                        self.writer.flush()
                     if self.rank == 0:
                         print('{0} [{1}] ({2}/{3}): loss = {4:.6f}, sg_rgb_loss = {5:.6f}, sg_psnr = {6:.3f}, idr_lr = {7}, '
                               'sg_lr = {8}'.format(self.expname, epoch, data_index, self.n_batches, loss,

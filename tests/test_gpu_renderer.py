@@ -449,6 +449,16 @@ def test_runner_checkpoint_layout_and_resume(tmp_path, graph):
     full = make(expname='full', max_niters=15, new_timestamp='t0')
     full.run()
     assert full.step.cur_iter == 16
+    # the tensorboard event file where the reference's SummaryWriter puts it (idr_train.py:114-115), scalars at the logging points
+    from nefii_amd.utils import tb_writer
+    run_dir = os.path.join(str(tmp_path), 'full', 't0')
+    ev_files = [f for f in os.listdir(run_dir) if f.startswith('events.out.tfevents.')]
+    assert len(ev_files) == 1
+    full.writer.close()
+    ev = tb_writer.read_events(os.path.join(run_dir, ev_files[0]))
+    logged = {(e['tag'], e['step']) for e in ev if 'value' in e}
+    assert {('loss', 0), ('sg_psnr', 4), ('mask_loss', 8), ('idr_lr', 12), ('alpha', 12)} <= logged, sorted(logged)[:12]
+    assert all(s_ % 4 == 0 for _, s_ in logged)
     part = make(expname='part', max_niters=7, new_timestamp='t0')
     part.run()                                            # epoch 0 = iterations 0..7; the epoch-1 checkpoint follows
     ck = os.path.join(str(tmp_path), 'part', 't0', 'checkpoints')
