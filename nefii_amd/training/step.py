@@ -209,6 +209,20 @@ def _hit_index(ctx):
     return torch.nonzero(ctx['network_object_mask']).flatten()
 
 
+_TRACE_POOLS = {}
+
+
+def _trace_pool(dev, n):
+    """The trace streams are the PROCESS's, not the TrainStep's: HIP multiplexes its streams onto a handful of hardware
+    queues, and every further TrainStep that made its own streams found them sharing queues with the ones the step's tail
+    and the tracer's round groups run on - config 1 measured 0.92 ms per step with the first TrainStep of a process and
+    1.19 ms with every later one (tools/experiments/nested_cfg1.py: not the garbage collector, not the allocator)."""
+    pool = _TRACE_POOLS.setdefault(dev, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 class TrainStep:
     def __init__(self, model, loss_conf, idr_lr=5e-4, sg_lr=5e-4, world_size=1, secondary_train_interval=0,
                  secondary_batch_size=1024, num_rays=1, graph=False, graph_bucket=256, graph_after=3,
@@ -464,7 +478,7 @@ class TrainStep:
     def _trace_stream_next(self, after, grouped=False):
         if self._trace_stream is None:
             n = max(1, int(os.environ.get('NEFII_TRACE_STREAMS', '4' if grouped else '3')))
-            self._trace_pool = [torch.cuda.Stream() for _ in range(n)]
+            self._trace_pool = list(_trace_pool(torch.cuda.current_device(), n))
         self._trace_pool.append(self._trace_pool.pop(0))
         self._trace_stream = self._trace_pool[0]
         self._trace_stream.wait_event(after if after is not None else torch.cuda.current_stream().record_event())
