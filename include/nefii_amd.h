@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 9
+#define NEFII_ABI_VERSION 10
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -148,6 +148,26 @@ int nefii_mlp_backward_f16(const nefii_mlp *h_mlp, const float *d_out, int out_s
                            int stash_stride, int64_t n, float *dz, int dz_stride, const float *scale, void *stream);
 int nefii_mlp_wgrad_f16(const float *dz, int dz_stride, const float *x, int x_stride, int64_t n, int n_out, int k_in,
                         float scale, const float *gscale, float *dW, float *db, void *stream);
+
+/* ABI 10 - the same three calls with the training state in HALVES, for nets nefii_mlp_h16_supported() accepts (streamed
+ * forward and backward kernels: 512-wide hidden layers, no skip layer, a head of <= 8 outputs - the reference's material,
+ * radiance and indirect-radiance networks, sg_envmap_material.py:131-176, implicit_differentiable_renderer.py:126-193).
+ * What autograd keeps between RenderingNetwork.forward and its backward in the reference (fp32 activations per layer) is
+ * here: stash16 = [n_layers - 1][n][stash_stride] halves holding 16 * h_l (the forward's own fp16 operand image),
+ * z_last = [n][8] floats (pre-activations of the head), dz16 = [n_layers][n][dz_stride] halves holding scale[0] * dz_l.
+ * nefii_mlp_wgrad_f16h consumes one layer's dz16 with x = its input: fp32 rows (x_half = 0: nefii_encode_inputs' matrix,
+ * layer 0) or the stash16 slice of the layer below (x_half = 1).  Weight gradients are bit-identical to the fp32-stash
+ * calls (the GEMM rounded its operands to these very halves); the backward's act'(h) is taken from the fp16 h.
+ * Strides count elements of the array's own type. */
+int nefii_mlp_h16_supported(const nefii_mlp *h_mlp);
+int nefii_mlp_forward_f16h(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
+                           const float *feat, int64_t n, float *out, int out_stride, float *hidden_out, int hid_stride,
+                           void *stash16, int stash_stride, float *z_last, void *stream);
+int nefii_mlp_backward_f16h(const nefii_mlp *h_mlp, const float *d_out, int out_stride, const void *stash16,
+                            int stash_stride, const float *z_last, int64_t n, void *dz16, int dz_stride,
+                            const float *scale, void *stream);
+int nefii_mlp_wgrad_f16h(const void *dz16, int dz_stride, const void *x, int x_stride, int x_half, int64_t n, int n_out,
+                         int k_in, float scale, const float *gscale, float *dW, float *db, void *stream);
 
 /* The reference's layer-0 concatenation [PE(a) | PE(b) | PE(c) | feat] as a dense [n, width] matrix. */
 int nefii_encode_inputs(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,

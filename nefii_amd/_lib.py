@@ -14,7 +14,7 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 9
+ABI_VERSION = 10
 TRACE_COUNTERS = 9          # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
@@ -85,6 +85,10 @@ SIGNATURES = {
     'nefii_mlp_grad_scale': (I, [P, I64, P, P]),
     'nefii_mlp_backward_f16': (I, [ctypes.POINTER(Mlp), P, I, P, I, I64, P, I, P, P]),
     'nefii_mlp_wgrad_f16': (I, [P, I, P, I, I64, I, I, F, P, P, P, P]),
+    'nefii_mlp_h16_supported': (I, [ctypes.POINTER(Mlp)]),
+    'nefii_mlp_forward_f16h': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P, P]),
+    'nefii_mlp_backward_f16h': (I, [ctypes.POINTER(Mlp), P, I, P, I, P, I64, P, I, P, P]),
+    'nefii_mlp_wgrad_f16h': (I, [P, I, P, I, I, I64, I, I, F, P, P, P, P]),
     'nefii_encode_inputs': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P]),
     'nefii_sdf_value_grad': (I, [ctypes.POINTER(Mlp), P, I64, P, I, P, I, P, P, P]),
     'nefii_sdf_value_grad_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp), I64]),

@@ -797,15 +797,21 @@ extern "C" int nefii_pack_mlp_stream(const nefii_mlp *h_mlp, void *w_stream, voi
     return 0;
 }
 
-template <int QT, int EW>
+// H16: the stash is what the backward pass and the weight gradients read it as - fp16.  stash_v = [n_layers - 1][n][stash_stride]
+// HALVES holding 16 h_l (A16_SCALE: the very hi halves this kernel parks in its own activation image, so the weight-gradient
+// GEMM sees bit for bit the operand it used to round from fp32 itself), z_last = [n][8] fp32 pre-activations of the head.
+template <int QT, int EW, bool H16>
 __global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, const float *__restrict__ in_a,
                                                                const float *__restrict__ in_b,
                                                                const float *__restrict__ in_c,
                                                                const float *__restrict__ feat, int64_t n,
                                                                float *__restrict__ out, int out_stride,
                                                                float *__restrict__ hidden_out, int hid_stride,
-                                                               float *__restrict__ stash, int stash_stride, int G) {
+                                                               void *__restrict__ stash_v, int stash_stride,
+                                                               float *__restrict__ z_last, int G) {
     NEFII_CLAIM_SIMD_2();
+    float *const stash = H16 ? nullptr : static_cast<float *>(stash_v);
+    _Float16 *const stash16 = H16 ? static_cast<_Float16 *>(stash_v) : nullptr;
     constexpr int ROWS = 16 * QT, XP = LdsM<QT, EW>::XP, EP = 512, NW = 8, NJ = 4 * QT, RT = (QT + 1) / 2;
     __shared__ LdsM<QT, EW> lds;
     __shared__ float raw[ROWS * 9];
@@ -924,6 +930,8 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, con
                         const half4 hi = __builtin_convertvector(hs, half4);
                         phi[j] = hi;
                         plo[j] = __builtin_convertvector(hs - __builtin_convertvector(hi, float4v), half4);
+                        if (H16 && stash16 && row < n)
+                            *reinterpret_cast<half4 *>(stash16 + ((size_t)l * n + row) * stash_stride + f0) = hi;
                     }
                 }
             };
@@ -988,6 +996,7 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, con
                     for (int w = 0; w < NW; ++w) sum += psum[(w * ROWS + p) * 8 + c];
                     const float z = sum * inv_scale + L.bias[c];
                     if (stash) stash[((size_t)NH * n + base + p) * stash_stride + c] = z;
+                    if (H16 && z_last) z_last[(size_t)(base + p) * 8 + c] = z;
                     out[(size_t)(base + p) * out_stride + c] = head_fwd(z, m.head);
                 }
             }
@@ -1035,17 +1044,17 @@ extern "C" int nefii_mlp_forward_f16(const nefii_mlp *h_mlp, const float *in_a, 
         const int ew = mstream_shape(h_mlp), G = mstream_units(h_mlp);
         if (ew == 64) {
             const int64_t t = (n + 63) / 64;
-            hipLaunchKernelGGL((mlp_forward16q_kernel<4, 64>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream,
-                               *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash,
-                               stash_stride, G);
+            hipLaunchKernelGGL((mlp_forward16q_kernel<4, 64, false>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0,
+                               (hipStream_t)stream, *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride,
+                               (void *)stash, stash_stride, (float *)nullptr, G);
             HIP_CHECK_LAUNCH();
             return 0;
         }
         if (ew == 96) {
             const int64_t t = (n + 63) / 64;
-            hipLaunchKernelGGL((mlp_forward16q_kernel<4, 96>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream,
-                               *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash,
-                               stash_stride, G);
+            hipLaunchKernelGGL((mlp_forward16q_kernel<4, 96, false>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0,
+                               (hipStream_t)stream, *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride,
+                               (void *)stash, stash_stride, (float *)nullptr, G);
             HIP_CHECK_LAUNCH();
             return 0;
         }
@@ -1056,6 +1065,38 @@ extern "C" int nefii_mlp_forward_f16(const nefii_mlp *h_mlp, const float *in_a, 
     else
         hipLaunchKernelGGL(mlp_forward16_kernel<false>, dim3(grid_for(n_tiles, 1)), dim3(WG), 0, (hipStream_t)stream, *h_mlp,
                            in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash, stash_stride);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- the fp16 training path of the streamed nets (ABI 10): stash and dz in halves -------------------------------------------
+// What the backward pass and the weight-gradient GEMMs consume is fp16 anyway: the stash's activations as the GEMM's B
+// operand and (through act') as the backward epilogue's factor, dz as the GEMM's A operand and the next layer's image.  Kept in
+// fp32 they were written once and read twice at twice the bytes (1.4-2.3 GB per call on config 3).  nefii_mlp_h16_supported:
+// the net runs on the streamed kernels forward AND backward (512-wide hidden layers, no skip layer, head of <= 8 outputs).
+extern "C" int nefii_mlp_h16_supported(const nefii_mlp *h_mlp) {
+    if (!h_mlp || check_mlp16(h_mlp, true)) return 0;
+    return h_mlp->w_stream && mlp_stream_enabled() && mstream_shape(h_mlp) && mstream_units_bwd(h_mlp) > 0;
+}
+
+extern "C" int nefii_mlp_forward_f16h(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
+                                      const float *feat, int64_t n, float *out, int out_stride, float *hidden_out,
+                                      int hid_stride, void *stash16, int stash_stride, float *z_last, void *stream) {
+    int rc = check_mlp16(h_mlp, false);
+    if (rc) return rc;
+    if (!nefii_mlp_h16_supported(h_mlp)) return NEFII_E_SHAPE;
+    if (n <= 0) return 0;
+    if (!out || !stash16 || !z_last || (stash_stride & 3)) return NEFII_E_ARG;
+    const int ew = mstream_shape(h_mlp), G = mstream_units(h_mlp);
+    const int64_t t = (n + 63) / 64;
+    if (ew == 64)
+        hipLaunchKernelGGL((mlp_forward16q_kernel<4, 64, true>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream,
+                           *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash16, stash_stride,
+                           z_last, G);
+    else
+        hipLaunchKernelGGL((mlp_forward16q_kernel<4, 96, true>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream,
+                           *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash16, stash_stride,
+                           z_last, G);
     HIP_CHECK_LAUNCH();
     return 0;
 }
@@ -1156,11 +1197,19 @@ __global__ __launch_bounds__(256, 2) void mlp_backward16_kernel(nefii_mlp m, con
 // over its outputs, the epilogue multiplies by act'(h_{l-1}) from the forward's stash, writes dz_{l-1} (fp32, row-major:
 // what nefii_mlp_wgrad_f16 reads) and parks S dz_{l-1} as the next image.  The 32-row kernel above fetched each layer's
 // fragments per tile with nothing in flight (~30 GB/s per CU).
+// H16 (nefii_mlp_backward_f16h): stash_v = the forward's fp16 stash (16 h_l), z_last its head pre-activations, dz_v =
+// [n_layers][n][dz_stride] HALVES holding S dz_l - the values this kernel parks as the next layer's image anyway.
+template <bool H16>
 __global__ __launch_bounds__(512, 2) void mlp_backward16s_kernel(nefii_mlp m, const float *__restrict__ d_out, int out_stride,
-                                                                const float *__restrict__ stash, int stash_stride, int64_t n,
-                                                                float *__restrict__ dz, int dz_stride,
+                                                                const void *__restrict__ stash_v, int stash_stride,
+                                                                const float *__restrict__ z_last, int64_t n,
+                                                                void *__restrict__ dz_v, int dz_stride,
                                                                 const float *__restrict__ scale, size_t stream_off, int G) {
     NEFII_CLAIM_SIMD_2();
+    const float *const stash = static_cast<const float *>(stash_v);
+    const _Float16 *const stash16 = static_cast<const _Float16 *>(stash_v);
+    float *const dz = static_cast<float *>(dz_v);
+    _Float16 *const dz16 = static_cast<_Float16 *>(dz_v);
     constexpr int QT = 4, FT = 4, ROWS = 64, XP = QGeo<4>::XP, NJ = FT * QT;
     __shared__ LdsS<4, ROWS> lds;
     const int tid = threadIdx.x;
@@ -1192,11 +1241,13 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16s_kernel(nefii_mlp m, co
                 float v = 0.f;
                 if (base + p < n && c < L.n_pad) {
                     if (c < L.n_out) {
-                        const float pre = stash[((size_t)Lm1 * n + base + p) * stash_stride + c];
+                        const float pre = H16 ? z_last[(size_t)(base + p) * 8 + c]
+                                              : stash[((size_t)Lm1 * n + base + p) * stash_stride + c];
                         const float y = head_fwd(pre, m.head);
                         v = d_out[(size_t)(base + p) * out_stride + c] * head_bwd_from_out(y, pre, m.head);
                     }
-                    dz[((size_t)Lm1 * n + base + p) * dz_stride + c] = v;
+                    if (H16) dz16[((size_t)Lm1 * n + base + p) * dz_stride + c] = (_Float16)(v * S);
+                    else dz[((size_t)Lm1 * n + base + p) * dz_stride + c] = v;
                 }
                 lds.Xh[p * XP + c] = (_Float16)(v * S);
             }
@@ -1220,6 +1271,8 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16s_kernel(nefii_mlp m, co
             half4 phi[NJ];
             const float *sp = stash + (size_t)(l - 1) * n * stash_stride;
             float *dp = dz + (size_t)(l - 1) * n * dz_stride;
+            const _Float16 *sp16 = stash16 + (size_t)(l - 1) * n * stash_stride;
+            _Float16 *dp16 = dz16 + (size_t)(l - 1) * n * dz_stride;
             auto epilogue = [&](auto actc) {
                 constexpr int ACT = decltype(actc)::value;
 #pragma unroll
@@ -1231,12 +1284,18 @@ __global__ __launch_bounds__(512, 2) void mlp_backward16s_kernel(nefii_mlp m, co
                         const int64_t row = base + 16 * qt + (lane & 15);
                         float4v v = {0.f, 0.f, 0.f, 0.f};
                         if (row < n) {
-                            const float4v h = *reinterpret_cast<const float4v *>(sp + (size_t)row * stash_stride + f0);
+                            float4v h;
+                            if (H16)
+                                h = __builtin_convertvector(*reinterpret_cast<const half4 *>(sp16 + (size_t)row * stash_stride + f0),
+                                                            float4v) * (1.f / A16_SCALE);
+                            else
+                                h = *reinterpret_cast<const float4v *>(sp + (size_t)row * stash_stride + f0);
 #pragma unroll
                             for (int k = 0; k < 4; ++k) v[k] = acc[j][k] * inv * act_bwd_from_out(h[k], ACT);
-                            *reinterpret_cast<float4v *>(dp + (size_t)row * dz_stride + f0) = v;
+                            if (!H16) *reinterpret_cast<float4v *>(dp + (size_t)row * dz_stride + f0) = v;
                         }
                         phi[j] = __builtin_convertvector(v * S, half4);
+                        if (H16 && row < n) *reinterpret_cast<half4 *>(dp16 + (size_t)row * dz_stride + f0) = phi[j];
                     }
                 }
             };
@@ -1269,9 +1328,9 @@ extern "C" int nefii_mlp_backward_f16(const nefii_mlp *h_mlp, const float *d_out
     if (h_mlp->w_stream && mlp_stream_enabled() && mstream_shape(h_mlp) && mstream_units_bwd(h_mlp) > 0 &&
         (stash_stride & 3) == 0 && (dz_stride & 3) == 0) {
         const int64_t t = (n + 63) / 64;
-        hipLaunchKernelGGL(mlp_backward16s_kernel, dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream, *h_mlp,
-                           d_out, out_stride, stash, stash_stride, n, dz, dz_stride, scale,
-                           (size_t)8 * mstream_units(h_mlp) * 256, mstream_units_bwd(h_mlp));
+        hipLaunchKernelGGL(mlp_backward16s_kernel<false>, dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream,
+                           *h_mlp, d_out, out_stride, (const void *)stash, stash_stride, (const float *)nullptr, n, (void *)dz,
+                           dz_stride, scale, (size_t)8 * mstream_units(h_mlp) * 256, mstream_units_bwd(h_mlp));
         HIP_CHECK_LAUNCH();
         return 0;
     }
@@ -1282,13 +1341,33 @@ extern "C" int nefii_mlp_backward_f16(const nefii_mlp *h_mlp, const float *d_out
     return 0;
 }
 
+extern "C" int nefii_mlp_backward_f16h(const nefii_mlp *h_mlp, const float *d_out, int out_stride, const void *stash16,
+                                       int stash_stride, const float *z_last, int64_t n, void *dz16, int dz_stride,
+                                       const float *scale, void *stream) {
+    int rc = check_mlp16(h_mlp, true);
+    if (rc) return rc;
+    if (!nefii_mlp_h16_supported(h_mlp)) return NEFII_E_SHAPE;
+    if (n <= 0) return 0;
+    if (!d_out || !stash16 || !z_last || !dz16 || !scale || (stash_stride & 3) || (dz_stride & 3)) return NEFII_E_ARG;
+    const int64_t t = (n + 63) / 64;
+    hipLaunchKernelGGL(mlp_backward16s_kernel<true>, dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream, *h_mlp,
+                       d_out, out_stride, stash16, stash_stride, z_last, n, dz16, dz_stride, scale,
+                       (size_t)8 * mstream_units(h_mlp) * 256, mstream_units_bwd(h_mlp));
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // dW[n][k] = scale * sum_p dz[p][n] * x[p][k] on v_mfma_f32_32x32x16_f16: 16 points per instruction.  A = (S dz)^T
 // fragment (lane (n, p-group): 8 consecutive points), B = x fragment (lane (k, p-group)); fp32 loads (coalesced over the
 // 32 lanes of a point row), converted on the fly.  Same block shape / point split / atomics as mlp_wgrad_kernel.
-__global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const float *__restrict__ dz, int dz_stride,
-                                                          const float *__restrict__ x, int x_stride, int64_t P, int n_out,
+// DZ16 / X16: operands stored as halves (S dz / 16 h), see mlp_wgrad16t_kernel.
+template <bool DZ16, bool X16>
+__global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const void *__restrict__ dz_v, int dz_stride,
+                                                          const void *__restrict__ x_v, int x_stride, int64_t P, int n_out,
                                                           int k_in, float scale, const float *__restrict__ gscale,
                                                           float *__restrict__ dW, float *__restrict__ db, int atomic) {
+    const float *const dz = static_cast<const float *>(dz_v), *const x = static_cast<const float *>(x_v);
+    const _Float16 *const dz16 = static_cast<const _Float16 *>(dz_v), *const x16 = static_cast<const _Float16 *>(x_v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 64 + (wave & 1) * 32;
@@ -1321,9 +1400,9 @@ __global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const float *__restric
                 for (int j = 0; j < 8; ++j) {
                     const int64_t p = pb + 16 * u + 8 * h + j;
                     const int64_t pc = p < p_last ? p : p_last;
-                    a[u][j] = dz[pc * dz_stride + nc];
+                    a[u][j] = DZ16 ? (float)dz16[pc * dz_stride + nc] : dz[pc * dz_stride + nc];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) b[u][t][j] = x[pc * x_stride + kc[t]];
+                    for (int t = 0; t < 4; ++t) b[u][t][j] = X16 ? (float)x16[pc * x_stride + kc[t]] : x[pc * x_stride + kc[t]];
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -1333,7 +1412,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const float *__restric
                     const bool ok = (pb + 16 * u + 8 * h + j) < p_end && n_ok;
                     const float av = ok ? a[u][j] : 0.f;
                     bsum += av;
-                    af[j] = (_Float16)(av * S);
+                    af[j] = DZ16 ? (_Float16)av : (_Float16)(av * S);       // (halves come back exactly)
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -1344,7 +1423,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const float *__restric
                 }
             }
         }
-        const float os = scale / S;
+        const float os = scale / S * (X16 ? 1.f / A16_SCALE : 1.f);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1359,6 +1438,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const float *__restric
     }
     if (db && blockIdx.y == 0 && (wave >> 1) == 0) {
         bsum += __shfl_xor(bsum, 32);
+        if (DZ16) bsum /= S;
         if (h == 0 && n_ok) {
             if (atomic) atomicAdd(&db[n0 + i], bsum);
             else db[n0 + i] = bsum;
@@ -1391,13 +1471,18 @@ __device__ __forceinline__ half8 wg2_fragment(const _Float16 *tile, int col0, in
     return half8{l4[0], l4[1], l4[2], l4[3], h4[0], h4[1], h4[2], h4[3]};
 }
 
-template <bool XVEC>
-__global__ __launch_bounds__(256, 2) void mlp_wgrad16t_kernel(const float *__restrict__ dz, int dz_stride,
-                                                              const float *__restrict__ x, int x_stride, int64_t P, int n_out,
+// DZ16 / X16 (nefii_mlp_wgrad_f16h): the operand arrives as the fp16 image itself - dz_v = S dz in halves (the backward
+// pass's own rounding), x_v = 16 h in halves (the forward's) - and is copied to LDS with 16-byte loads, eight columns per
+// thread, instead of being loaded as fp32 and rounded here: the same operands bit for bit at half the bytes.
+template <bool XVEC, bool DZ16, bool X16>
+__global__ __launch_bounds__(256, 2) void mlp_wgrad16t_kernel(const void *__restrict__ dz_v, int dz_stride,
+                                                              const void *__restrict__ x_v, int x_stride, int64_t P, int n_out,
                                                               int k_in, float scale, const float *__restrict__ gscale,
                                                               float *__restrict__ dW, float *__restrict__ db, int splits,
                                                               int tiles_n, int tiles_k) {
     __shared__ __attribute__((aligned(16))) _Float16 A[2][WG2_ROWS * WG2_STRIDE], B[2][WG2_ROWS * WG2_STRIDE];
+    const float *const dz = static_cast<const float *>(dz_v), *const x = static_cast<const float *>(x_v);
+    const _Float16 *const dz16 = static_cast<const _Float16 *>(dz_v), *const x16 = static_cast<const _Float16 *>(x_v);
     // XCD-aware order: the tiles_n * tiles_k blocks of one point slice get consecutive positions on one XCD
     const int nt = tiles_n * tiles_k;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -1411,47 +1496,107 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad16t_kernel(const float *__res
     const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;
     if (p_begin >= p_end) return;
     const float S = gscale[0];
-    // staging: thread -> columns 4 c4 .. 4 c4+3 of rows r8, r8 + 8, r8 + 16, r8 + 24
+    // staging, fp32 source: thread -> columns 4 c4 .. 4 c4+3 of rows r8, r8 + 8, r8 + 16, r8 + 24
+    //          fp16 source: thread -> columns 8 c8 .. 8 c8+7 of rows r16, r16 + 16
     const int c4 = tid & 31, r8 = tid >> 5;
-    const int na = n0 + 4 * c4, ka = k0 + 4 * c4;
-    const bool n_in = na + 3 < n_out, k_in_ok = ka + 3 < k_in;      // whole float4 inside (else element-wise)
+    const int c8 = tid & 15, r16 = tid >> 4;
+    const int na = n0 + (DZ16 ? 8 * c8 : 4 * c4), ka = k0 + (X16 ? 8 * c8 : 4 * c4);
+    const bool n_in = na + (DZ16 ? 7 : 3) < n_out, k_in_ok = ka + (X16 ? 7 : 3) < k_in;   // whole vector inside (else element-wise)
     float4v ra[4], rb[4];
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    half8 ha[2], hb[2];
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const half8 hzero = {0, 0, 0, 0, 0, 0, 0, 0};
     auto fetch = [&](int64_t pb) {
+        if (DZ16) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t pr = pb + r8 + 8 * u;
-            const int64_t pc = pr < p_end ? pr : p_end - 1;
-            const bool live = pr < p_end;
-            float4v a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-            if (n_in) {
-                a = *reinterpret_cast<const float4v *>(dz + pc * dz_stride + na);
-            } else {
+            for (int u = 0; u < 2; ++u) {
+                const int64_t pr = pb + r16 + 16 * u;
+                const int64_t pc = pr < p_end ? pr : p_end - 1;
+                half8 a = hzero;
+                if (n_in) {
+                    a = *reinterpret_cast<const half8 *>(dz16 + pc * dz_stride + na);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = dz[pc * dz_stride + (na + e < n_out ? na + e : n_out - 1)];
+                    for (int e = 0; e < 8; ++e) a[e] = dz16[pc * dz_stride + (na + e < n_out ? na + e : n_out - 1)];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = na + e < n_out ? a[e] : 0.f;
+                    for (int e = 0; e < 8; ++e) a[e] = na + e < n_out ? a[e] : (_Float16)0;
+                }
+                ha[u] = pr < p_end ? a : hzero;
             }
-            if (XVEC && k_in_ok) {
-                b = *reinterpret_cast<const float4v *>(x + pc * x_stride + ka);
-            } else {
+        } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b[e] = x[pc * x_stride + (ka + e < k_in ? ka + e : k_in - 1)];
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pr = pb + r8 + 8 * u;
+                const int64_t pc = pr < p_end ? pr : p_end - 1;
+                float4v a = {0.f, 0.f, 0.f, 0.f};
+                if (n_in) {
+                    a = *reinterpret_cast<const float4v *>(dz + pc * dz_stride + na);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) b[e] = ka + e < k_in ? b[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) a[e] = dz[pc * dz_stride + (na + e < n_out ? na + e : n_out - 1)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = na + e < n_out ? a[e] : 0.f;
+                }
+                ra[u] = pr < p_end ? a : float4v{0.f, 0.f, 0.f, 0.f};
             }
-            ra[u] = live ? a : float4v{0.f, 0.f, 0.f, 0.f};
-            rb[u] = live ? b : float4v{0.f, 0.f, 0.f, 0.f};
+        }
+        if (X16) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t pr = pb + r16 + 16 * u;
+                const int64_t pc = pr < p_end ? pr : p_end - 1;
+                half8 b = hzero;
+                if (XVEC && k_in_ok) {
+                    b = *reinterpret_cast<const half8 *>(x16 + pc * x_stride + ka);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b[e] = x16[pc * x_stride + (ka + e < k_in ? ka + e : k_in - 1)];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) b[e] = ka + e < k_in ? b[e] : (_Float16)0;
+                }
+                hb[u] = pr < p_end ? b : hzero;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t pr = pb + r8 + 8 * u;
+                const int64_t pc = pr < p_end ? pr : p_end - 1;
+                float4v b = {0.f, 0.f, 0.f, 0.f};
+                if (XVEC && k_in_ok) {
+                    b = *reinterpret_cast<const float4v *>(x + pc * x_stride + ka);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = x[pc * x_stride + (ka + e < k_in ? ka + e : k_in - 1)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[e] = ka + e < k_in ? b[e] : 0.f;
+                }
+                rb[u] = pr < p_end ? b : float4v{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     auto stage = [&](int buf) {
+        if (DZ16) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bsum[e] += ra[u][e];
-            const int off = (r8 + 8 * u) * WG2_STRIDE + 4 * c4;
-            *reinterpret_cast<half4 *>(&A[buf][off]) = __builtin_convertvector(ra[u] * S, half4);
-            *reinterpret_cast<half4 *>(&B[buf][off]) = __builtin_convertvector(rb[u], half4);
+                for (int e = 0; e < 8; ++e) bsum[e] += (float)ha[u][e];
+                *reinterpret_cast<half8 *>(&A[buf][(r16 + 16 * u) * WG2_STRIDE + 8 * c8]) = ha[u];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bsum[e] += ra[u][e];
+                *reinterpret_cast<half4 *>(&A[buf][(r8 + 8 * u) * WG2_STRIDE + 4 * c4]) = __builtin_convertvector(ra[u] * S, half4);
+            }
+        }
+        if (X16) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) *reinterpret_cast<half8 *>(&B[buf][(r16 + 16 * u) * WG2_STRIDE + 8 * c8]) = hb[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                *reinterpret_cast<half4 *>(&B[buf][(r8 + 8 * u) * WG2_STRIDE + 4 * c4]) = __builtin_convertvector(rb[u], half4);
         }
     };
     f32x16 acc[4];
@@ -1482,7 +1627,7 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad16t_kernel(const float *__res
         __syncthreads();
         buf ^= 1;
     }
-    const float os = scale / S;
+    const float os = scale / S * (X16 ? 1.f / A16_SCALE : 1.f);
     const int i = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -1494,17 +1639,22 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad16t_kernel(const float *__res
                 if (nn < n_out && k < k_in) atomicAdd(&dW[(size_t)nn * k_in + k], acc[2 * t + v][r] * os);
             }
     if (db && tk == 0) {
-        // column sums of this thread's rows: reduce the 8 row groups through LDS, then one atomic per column and block
+        // column sums of this thread's rows: reduce the row groups through LDS, then one atomic per column and block
         __syncthreads();
-        float *red = reinterpret_cast<float *>(&A[0][0]);         // [8][128]
+        float *red = reinterpret_cast<float *>(&A[0][0]);         // [8][128] (fp32 source) / [16][128] (fp16 source)
+        if (DZ16) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) red[r8 * 128 + 4 * c4 + e] = bsum[e];
+            for (int e = 0; e < 8; ++e) red[r16 * 128 + 8 * c8 + e] = bsum[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[r8 * 128 + 4 * c4 + e] = bsum[e];
+        }
         __syncthreads();
         if (tid < 128 && n0 + tid < n_out) {
             float sum = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) sum += red[g * 128 + tid];
-            atomicAdd(&db[n0 + tid], sum);
+            for (int g = 0; g < (DZ16 ? 16 : 8); ++g) sum += red[g * 128 + tid];
+            atomicAdd(&db[n0 + tid], DZ16 ? sum / S : sum);
         }
     }
 }
@@ -1540,17 +1690,65 @@ extern "C" int nefii_mlp_wgrad_f16(const float *dz, int dz_stride, const float *
         const int tiles_n = (n_out + 127) / 128, tiles_k = (k_in + 127) / 128;
         const unsigned blocks = (unsigned)(tiles_n * tiles_k * splits);
         if ((x_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
-            hipLaunchKernelGGL(mlp_wgrad16t_kernel<true>, dim3(blocks), dim3(256), 0, st, dz, dz_stride, x, x_stride, n, n_out,
-                               k_in, scale, gscale, dW, db, splits, tiles_n, tiles_k);
+            hipLaunchKernelGGL((mlp_wgrad16t_kernel<true, false, false>), dim3(blocks), dim3(256), 0, st, (const void *)dz, dz_stride,
+                               (const void *)x, x_stride, n, n_out, k_in, scale, gscale, dW, db, splits, tiles_n, tiles_k);
         else
-            hipLaunchKernelGGL(mlp_wgrad16t_kernel<false>, dim3(blocks), dim3(256), 0, st, dz, dz_stride, x, x_stride, n, n_out,
-                               k_in, scale, gscale, dW, db, splits, tiles_n, tiles_k);
+            hipLaunchKernelGGL((mlp_wgrad16t_kernel<false, false, false>), dim3(blocks), dim3(256), 0, st, (const void *)dz, dz_stride,
+                               (const void *)x, x_stride, n, n_out, k_in, scale, gscale, dW, db, splits, tiles_n, tiles_k);
         HIP_CHECK_LAUNCH();
         return 0;
     }
     dim3 grid((n_out + 63) / 64, (k_in + 255) / 256, split);
-    hipLaunchKernelGGL(mlp_wgrad16_kernel, grid, dim3(256), 0, st, dz, dz_stride, x, x_stride, n, n_out, k_in, scale, gscale,
-                       dW, db, split > 1 ? 1 : 0);
+    hipLaunchKernelGGL((mlp_wgrad16_kernel<false, false>), grid, dim3(256), 0, st, (const void *)dz, dz_stride, (const void *)x,
+                       x_stride, n, n_out, k_in, scale, gscale, dW, db, split > 1 ? 1 : 0);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+// dz16 = [n][dz_stride] halves holding S dz (nefii_mlp_backward_f16h); x = fp32 rows (x_half = 0: the encoded network input
+// of layer 0) or halves holding 16 h (x_half = 1: the forward's fp16 stash).  Strides in ELEMENTS of the operand's type.
+extern "C" int nefii_mlp_wgrad_f16h(const void *dz16, int dz_stride, const void *x, int x_stride, int x_half, int64_t n,
+                                    int n_out, int k_in, float scale, const float *gscale, float *dW, float *db, void *stream) {
+    if (!dz16 || !x || !dW || !gscale || n_out <= 0 || k_in <= 0) return NEFII_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    int split = (int)((n + 255) / 256);       // <= 256 points per workgroup
+    if (split < 1) split = 1;
+    if (split > 64) split = 64;
+    if (split > 1 || n <= 0) {
+        const size_t nw = (size_t)n_out * k_in;
+        const size_t nz = nw + (db ? (size_t)n_out : 0);
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, dW, nw, db, (size_t)n_out);
+        HIP_CHECK_LAUNCH();
+    }
+    if (n <= 0) return 0;
+    if (wgrad_tr_enabled() && n_out >= 64 && k_in >= 64 && n >= 1024 && (dz_stride & 7) == 0 &&
+        (reinterpret_cast<uintptr_t>(dz16) & 15) == 0) {
+        int splits = (int)((n + WG2_POINTS - 1) / WG2_POINTS);
+        splits = (splits + 7) / 8 * 8;
+        const int tiles_n = (n_out + 127) / 128, tiles_k = (k_in + 127) / 128;
+        const dim3 blocks((unsigned)(tiles_n * tiles_k * splits));
+        const bool xvec = (x_stride & (x_half ? 7 : 3)) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+#define NEFII_WG2H(XV, XH)                                                                                                    \
+    hipLaunchKernelGGL((mlp_wgrad16t_kernel<XV, true, XH>), blocks, dim3(256), 0, st, dz16, dz_stride, x, x_stride, n, n_out, \
+                       k_in, scale, gscale, dW, db, splits, tiles_n, tiles_k)
+        if (x_half) {
+            if (xvec) NEFII_WG2H(true, true);
+            else NEFII_WG2H(false, true);
+        } else {
+            if (xvec) NEFII_WG2H(true, false);
+            else NEFII_WG2H(false, false);
+        }
+#undef NEFII_WG2H
+        HIP_CHECK_LAUNCH();
+        return 0;
+    }
+    dim3 grid((n_out + 63) / 64, (k_in + 255) / 256, split);
+    if (x_half)
+        hipLaunchKernelGGL((mlp_wgrad16_kernel<true, true>), grid, dim3(256), 0, st, dz16, dz_stride, x, x_stride, n, n_out, k_in,
+                           scale, gscale, dW, db, split > 1 ? 1 : 0);
+    else
+        hipLaunchKernelGGL((mlp_wgrad16_kernel<true, false>), grid, dim3(256), 0, st, dz16, dz_stride, x, x_stride, n, n_out, k_in,
+                           scale, gscale, dW, db, split > 1 ? 1 : 0);
     HIP_CHECK_LAUNCH();
     return 0;
 }

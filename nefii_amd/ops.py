@@ -162,7 +162,27 @@ def mlp_precision():
     return os.environ.get('NEFII_MLP_PRECISION', 'f16x3')
 
 
-def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False):
+def h16_supported(pm):
+    """The net trains with its stash and dz kept in halves (nefii_mlp_*_f16h: streamed kernels forward and backward).
+    NEFII_MLP_H16=0 keeps the fp32 stash (A/B measurements)."""
+    if pm.half != 'f16x3' or os.environ.get('NEFII_MLP_H16', '1') == '0':
+        return False
+    if getattr(pm, '_h16', None) is None:        # a property of the net's shape and buffers, not of its weights
+        pm._h16 = bool(_lib.lib().nefii_mlp_h16_supported(ctypes.byref(pm.struct)))
+    return pm._h16
+
+
+class HalfStash:
+    """What nefii_mlp_forward_f16h leaves for the backward pass: h [n_layers - 1, n, stride] halves (16 x the hidden
+    activations), z_last [n, 8] floats (pre-activations of the head)."""
+
+    def __init__(self, h, z_last):
+        self.h, self.z_last = h, z_last
+
+
+def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False, h16=None):
+    """(out, last hidden or None, stash or None).  The stash is a HalfStash where the net supports it (h16=False: the fp32
+    [n_layers, n, stride] tensor regardless), else fp32."""
     lib = _lib.lib()
     n = in_a.shape[0]
     dev = in_a.device
@@ -172,6 +192,14 @@ def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False)
     if want_hidden:
         hidden = torch.empty(n, pm.specs[-2].n_out, device=dev, dtype=torch.float32)
     stash = None
+    if want_stash and n > 0 and h16 is not False and h16_supported(pm):
+        stash = HalfStash(torch.empty(pm.n_layers - 1, n, pm.hidden_stride, device=dev, dtype=torch.float16),
+                          torch.empty(n, 8, device=dev, dtype=torch.float32))
+        _lib.check(lib.nefii_mlp_forward_f16h(ctypes.byref(pm.struct), _ptr(in_a), _ptr(in_b), _ptr(in_c), _ptr(feat), n,
+                                              _ptr(out), n_out, _ptr(hidden), hidden.shape[1] if hidden is not None else 0,
+                                              _ptr(stash.h), pm.hidden_stride, _ptr(stash.z_last), _stream()),
+                   'nefii_mlp_forward_f16h')
+        return out, hidden, stash
     if want_stash:
         stash = torch.empty(pm.n_layers, n, pm.hidden_stride, device=dev, dtype=torch.float32)
     if n > 0:
@@ -188,6 +216,12 @@ def mlp_backward(pm, d_out, stash, gscale=None):
     """gscale (pm.half): device scalar from mlp_grad_scale(d_out)"""
     lib = _lib.lib()
     n = d_out.shape[0]
+    if isinstance(stash, HalfStash):        # dz comes back in halves too: gscale x dz_l
+        dz = torch.empty(pm.n_layers, n, pm.hidden_stride, device=d_out.device, dtype=torch.float16)
+        _lib.check(lib.nefii_mlp_backward_f16h(ctypes.byref(pm.struct), _ptr(d_out), d_out.shape[1], _ptr(stash.h),
+                                               pm.hidden_stride, _ptr(stash.z_last), n, _ptr(dz), pm.hidden_stride,
+                                               _ptr(gscale), _stream()), 'nefii_mlp_backward_f16h')
+        return dz
     dz = torch.empty(pm.n_layers, n, pm.hidden_stride, device=d_out.device, dtype=torch.float32)
     if n > 0:
         if pm.half:
@@ -218,6 +252,12 @@ def encode_inputs(pm, in_a, in_b, in_c, feat):
     return out
 
 
+def _stash_tensors(stash, like):
+    if stash is None:
+        return (like.new_empty(0),)
+    return (stash.h, stash.z_last) if isinstance(stash, HalfStash) else (stash,)
+
+
 class FusedMLPFn(torch.autograd.Function):
     """y = MLP(PE(a), PE(b), PE(c), feat); differentiable wrt the layer weights and biases only
     (the raw inputs come from frozen geometry: IDRNetwork.freeze_geometry, Step-2; in the Step-1 geometry fit the inputs
@@ -233,8 +273,7 @@ class FusedMLPFn(torch.autograd.Function):
         ctx.pm = pm
         ctx.save_for_backward(in_a, in_b if in_b is not None else in_a.new_empty(0),
                               in_c if in_c is not None else in_a.new_empty(0),
-                              feat if feat is not None else in_a.new_empty(0),
-                              stash if stash is not None else in_a.new_empty(0))
+                              feat if feat is not None else in_a.new_empty(0), *_stash_tensors(stash, in_a))
         ctx.has = (in_b is not None, in_c is not None, feat is not None)
         # an output that nothing differentiable reads (physg.conf weights the radiance colour with 0 and the loss detaches it)
         # may still be reachable in the autograd graph through a node it shares with other outputs (AssembleRowsFn): its
@@ -247,7 +286,9 @@ class FusedMLPFn(torch.autograd.Function):
         pm = ctx.pm
         if d_out is None:
             return (None,) * (5 + 2 * pm.n_layers)
-        in_a, in_b, in_c, feat, stash = ctx.saved_tensors
+        in_a, in_b, in_c, feat, *st = ctx.saved_tensors
+        stash = HalfStash(*st) if len(st) == 2 else st[0]
+        h16 = isinstance(stash, HalfStash)
         in_b = in_b if ctx.has[0] else None
         in_c = in_c if ctx.has[1] else None
         feat = feat if ctx.has[2] else None
@@ -262,6 +303,8 @@ class FusedMLPFn(torch.autograd.Function):
         for l, s in enumerate(pm.specs):
             if l == 0:
                 xin, xs = x0, x0.shape[1]
+            elif h16:
+                xin, xs = stash.h[l - 1], pm.hidden_stride
             elif s.e_len:
                 # skip layer: its input is [previous activations | encoded network input] (the 1/sqrt(2) is s.scale)
                 # in the Linear's column order (x_src0 / e_src0 are column offsets into its weight)
@@ -272,7 +315,11 @@ class FusedMLPFn(torch.autograd.Function):
                 xin, xs = stash[l - 1], pm.hidden_stride
             g = torch.empty(s.n_out, s.k_in, device=d_out.device, dtype=torch.float32)
             b = torch.empty(s.n_out, device=d_out.device, dtype=torch.float32)
-            if pm.half:
+            if h16:
+                _lib.check(lib.nefii_mlp_wgrad_f16h(_ptr(dz[l]), pm.hidden_stride, _ptr(xin), xs, 1 if l else 0, n, s.n_out,
+                                                    s.k_in, s.scale, _ptr(gscale), _ptr(g), _ptr(b), _stream()),
+                           'nefii_mlp_wgrad_f16h')
+            elif pm.half:
                 _lib.check(lib.nefii_mlp_wgrad_f16(_ptr(dz[l]), pm.hidden_stride, _ptr(xin), xs, n, s.n_out, s.k_in, s.scale,
                                                    _ptr(gscale), _ptr(g), _ptr(b), _stream()), 'nefii_mlp_wgrad_f16')
             else:
@@ -295,7 +342,7 @@ class FusedMLPHiddenFn(torch.autograd.Function):
         out, hidden, stash = mlp_forward(pm, in_a, None, None, None, want_hidden=True, want_stash=need)
         ctx.pm = pm
         empty = in_a.new_empty(0)
-        ctx.save_for_backward(in_a, empty, empty, empty, stash if stash is not None else empty)
+        ctx.save_for_backward(in_a, empty, empty, empty, *_stash_tensors(stash, in_a))
         ctx.has = (False, False, False)
         ctx.mark_non_differentiable(hidden)
         ctx.set_materialize_grads(False)

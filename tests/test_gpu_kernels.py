@@ -186,6 +186,21 @@ def test_streamed_mlp_backward_matches_the_f32_kernels(name, n):
             w = sp[l].n_out
             assert torch.isfinite(dz16[l, :, :w]).all()
             assert rel_l2(dz16[l, :, :w], dz32[l, :, :w]) < 4e-3, (l, rel_l2(dz16[l, :, :w], dz32[l, :, :w]))
+        # ... and with stash and dz in halves (nefii_mlp_backward_f16h): S dz_l of the call above rounded to fp16 - exactly
+        # for the ReLU net (act' is a sign), within a few fp16 ulps for ELU (act' from the fp16 activation)
+        _, _, sh = ops.mlp_forward(pm16, *args, want_stash=True)
+        _, _, sf = ops.mlp_forward(pm16, *args, want_stash=True, h16=False)
+        S = ops.mlp_grad_scale(d_out)
+        dzf = ops.mlp_backward(pm16, d_out, sf, S)
+        dzh = ops.mlp_backward(pm16, d_out, sh, S)
+        assert dzh.dtype == torch.float16
+        for l in range(len(sp)):
+            w = sp[l].n_out
+            want = (dzf[l, :, :w] * S).half()
+            if act == ops.ACT_RELU:
+                assert torch.equal(dzh[l, :, :w], want), l
+            else:
+                assert rel_l2(dzh[l, :, :w].float(), want.float()) < 1e-3, (l, rel_l2(dzh[l, :, :w].float(), want.float()))
 
 
 @pytest.mark.parametrize('n,n_out,k_in,x_stride', [(5000, 512, 512, 512), (4097, 512, 605, 605), (1024, 512, 575, 576),
@@ -214,6 +229,41 @@ def test_weight_gradient_gemm_fp16(n, n_out, k_in, x_stride):
     assert rel_l2(dW, want) < 2e-6, rel_l2(dW, want)
     assert ((dW.double() - want).abs().max() / want.abs().max()).item() < 2e-5
     assert rel_l2(db, dz[:, :n_out].double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize('n,n_out,k_in,x_half', [(5000, 512, 512, 1), (70001, 512, 512, 1), (4097, 512, 605, 0), (1024, 512, 575, 0),
+                                                  (2000, 3, 512, 1), (3000, 100, 512, 1), (1500, 512, 39, 0)])
+def test_weight_gradient_gemm_from_halves(n, n_out, k_in, x_half):
+    """nefii_mlp_wgrad_f16h: the same GEMM fed with S dz (and, x_half, 16 x) already in halves equals nefii_mlp_wgrad_f16 on
+    the fp32 values those halves came from - the fp32 call rounds to the very same operands - up to the order of the
+    split-K atomics."""
+    from nefii_amd import _lib
+    from nefii_amd.ops import _ptr, _stream
+    g = torch.Generator().manual_seed(n + k_in)
+    S = torch.tensor([2.0 ** 28], device=DEV)
+    dz16 = ((torch.randn(n, 512, generator=g) * 3e-7).to(DEV) * S).half()
+    dz16[:, n_out:] = 0
+    x_stride = 512 if x_half else k_in
+    xf = torch.randn(n, x_stride, generator=g).to(DEV)
+    x16 = (xf * 16.0).half()
+    scale = 0.7
+    out = []
+    for h in (True, False):
+        dW = torch.full((n_out, k_in), 7.0, device=DEV)
+        db = torch.full((n_out,), 7.0, device=DEV)
+        if h:
+            x = x16 if x_half else xf
+            _lib.check(_lib.lib().nefii_mlp_wgrad_f16h(_ptr(dz16), 512, _ptr(x), x_stride, x_half, n, n_out, k_in, scale, _ptr(S),
+                                                       _ptr(dW), _ptr(db), _stream()), 'nefii_mlp_wgrad_f16h')
+        else:
+            dz = dz16.float() / S
+            x = x16.float() / 16.0 if x_half else xf
+            _lib.check(_lib.lib().nefii_mlp_wgrad_f16(_ptr(dz), 512, _ptr(x), x_stride, n, n_out, k_in, scale, _ptr(S), _ptr(dW),
+                                                      _ptr(db), _stream()), 'nefii_mlp_wgrad_f16')
+        out.append((dW, db))
+    (dWh, dbh), (dWf, dbf) = out
+    assert rel_l2(dWh, dWf) < 1e-6, rel_l2(dWh, dWf)
+    assert rel_l2(dbh, dbf) < 1e-6, rel_l2(dbh, dbf)
 
 
 # (the sizes above 16 384 give every workgroup a SECOND tile: the forward of round 2 re-zeroed only half of its last-layer
@@ -248,13 +298,26 @@ def test_streamed_mlp_forward_matches_the_f32_kernels(name, n):
             pm.pack([w.to(DEV) for w, _ in wb], [b.to(DEV) for _, b in wb])
             if half:
                 assert pm.mlp_stream, 'the streamed kernel did not take this net'
-            outs.append(ops.mlp_forward(pm, *args, want_hidden=True, want_stash=True))
+            outs.append(ops.mlp_forward(pm, *args, want_hidden=True, want_stash=True, h16=False))
+            if half:
+                pm_stream = pm
         (o16, h16, s16), (o32, h32, s32) = outs
         assert (o16 - o32).abs().max().item() < 2e-5
         assert (h16 - h32).abs().max().item() < 2e-5
         for l in range(len(sp)):
             w = sp[l].n_out
             assert (s16[l, :, :w] - s32[l, :, :w]).abs().max().item() < 3e-5, l
+        # the same forward with the stash in halves (nefii_mlp_forward_f16h, what training uses): outputs bit-identical, the
+        # stash = the fp32 stash's values x 16 rounded to fp16 (the kernel's own operand image), head pre-activations in fp32
+        assert ops.h16_supported(pm_stream)
+        oh, hh, sh = ops.mlp_forward(pm_stream, *args, want_hidden=True, want_stash=True)
+        assert isinstance(sh, ops.HalfStash) and sh.h.dtype == torch.float16 and sh.h.shape[0] == len(sp) - 1
+        assert torch.equal(oh, o16) and torch.equal(hh, h16)
+        for l in range(len(sp) - 1):
+            w = sp[l].n_out
+            assert torch.equal(sh.h[l, :, :w], (s16[l, :, :w] * 16.0).half()), l
+        w = sp[-1].n_out
+        assert torch.equal(sh.z_last[:, :w], s16[len(sp) - 1, :, :w])
 
 
 @pytest.mark.parametrize('half', [False, 'f16x3', 'f16'])

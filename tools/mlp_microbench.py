@@ -66,4 +66,5 @@ for kind in ('radiance', 'material'):
         torch.cuda.synchronize()
         print('%-9s %s  n %7d  forward %.3f ms per call with stash, %.3f without; backward %.3f   streamed %s   finite %s' % (
             kind, name, n, ms[True], ms[False], e0.elapsed_time(e1) / 10, pm.mlp_stream,
-            bool(torch.isfinite(out).all() and torch.isfinite(dz).all())))
+            # (of the head's dz row only its n_pad <= 32 columns are written)
+            bool(torch.isfinite(out).all() and torch.isfinite(dz[:-1]).all() and torch.isfinite(dz[-1][:, :out.shape[1]]).all())))
