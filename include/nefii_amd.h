@@ -158,11 +158,16 @@ int nefii_mlp_wgrad_f16(const float *dz, int dz_stride, const float *x, int x_st
  * nefii_mlp_wgrad_f16h consumes one layer's dz16 with x = its input: fp32 rows (x_half = 0: nefii_encode_inputs' matrix,
  * layer 0) or the stash16 slice of the layer below (x_half = 1).  Weight gradients are bit-identical to the fp32-stash
  * calls (the GEMM rounded its operands to these very halves); the backward's act'(h) is taken from the fp16 h.
+ * x0_16 (optional) = [n][nefii_mlp_x0_width()] halves: 16 * layer 0's input as the kernel lays it out - its padded feature
+ * columns, then the encodings of a, b, c, zero-padded - so that layer 0's weight gradient needs no nefii_encode_inputs
+ * matrix: nefii_mlp_wgrad_f16h(dz16 of layer 0, x0_16, x_half = 1, k_in = that width) yields dW in THAT column order
+ * (columns [0, x_len) = the Linear's feature columns, [k_x, k_x + e_len) = its encoding columns).
  * Strides count elements of the array's own type. */
 int nefii_mlp_h16_supported(const nefii_mlp *h_mlp);
+int nefii_mlp_x0_width(const nefii_mlp *h_mlp);
 int nefii_mlp_forward_f16h(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
                            const float *feat, int64_t n, float *out, int out_stride, float *hidden_out, int hid_stride,
-                           void *stash16, int stash_stride, float *z_last, void *stream);
+                           void *stash16, int stash_stride, float *z_last, void *x0_16, void *stream);
 int nefii_mlp_backward_f16h(const nefii_mlp *h_mlp, const float *d_out, int out_stride, const void *stash16,
                             int stash_stride, const float *z_last, int64_t n, void *dz16, int dz_stride,
                             const float *scale, void *stream);

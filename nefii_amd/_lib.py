@@ -86,7 +86,8 @@ SIGNATURES = {
     'nefii_mlp_backward_f16': (I, [ctypes.POINTER(Mlp), P, I, P, I, I64, P, I, P, P]),
     'nefii_mlp_wgrad_f16': (I, [P, I, P, I, I64, I, I, F, P, P, P, P]),
     'nefii_mlp_h16_supported': (I, [ctypes.POINTER(Mlp)]),
-    'nefii_mlp_forward_f16h': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P, P]),
+    'nefii_mlp_x0_width': (I, [ctypes.POINTER(Mlp)]),
+    'nefii_mlp_forward_f16h': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P, P, P]),
     'nefii_mlp_backward_f16h': (I, [ctypes.POINTER(Mlp), P, I, P, I, P, I64, P, I, P, P]),
     'nefii_mlp_wgrad_f16h': (I, [P, I, P, I, I, I64, I, I, F, P, P, P, P]),
     'nefii_encode_inputs': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P]),

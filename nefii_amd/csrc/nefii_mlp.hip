@@ -799,7 +799,9 @@ extern "C" int nefii_pack_mlp_stream(const nefii_mlp *h_mlp, void *w_stream, voi
 
 // H16: the stash is what the backward pass and the weight gradients read it as - fp16.  stash_v = [n_layers - 1][n][stash_stride]
 // HALVES holding 16 h_l (A16_SCALE: the very hi halves this kernel parks in its own activation image, so the weight-gradient
-// GEMM sees bit for bit the operand it used to round from fp32 itself), z_last = [n][8] fp32 pre-activations of the head.
+// GEMM sees bit for bit the operand it used to round from fp32 itself), z_last = [n][8] fp32 pre-activations of the head,
+// x0_16 = [n][k_x(layer 0) + EW] halves: layer 0's input image (16 x [features | encodings, zero-padded]) - the B operand of
+// layer 0's weight gradient, which otherwise needs nefii_encode_inputs' fp32 matrix rebuilt in the backward pass.
 template <int QT, int EW, bool H16>
 __global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, const float *__restrict__ in_a,
                                                                const float *__restrict__ in_b,
@@ -808,7 +810,7 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, con
                                                                float *__restrict__ out, int out_stride,
                                                                float *__restrict__ hidden_out, int hid_stride,
                                                                void *__restrict__ stash_v, int stash_stride,
-                                                               float *__restrict__ z_last, int G) {
+                                                               float *__restrict__ z_last, _Float16 *__restrict__ x0_16, int G) {
     NEFII_CLAIM_SIMD_2();
     float *const stash = H16 ? nullptr : static_cast<float *>(stash_v);
     _Float16 *const stash16 = H16 ? static_cast<_Float16 *>(stash_v) : nullptr;
@@ -877,6 +879,15 @@ __global__ __launch_bounds__(512, 2) void mlp_forward16q_kernel(nefii_mlp m, con
             split16a(val, lds.Xh[p * XP + EP + c], lds.Xl[p * XP + EP + c]);
         }
         __syncthreads();
+        if (H16 && x0_16) {     // the finished input image's hi halves, 16 bytes per thread and trip
+            const int C = (kx0 + EW) >> 3;
+            for (int i = tid; i < ROWS * C; i += 512) {
+                const int p = i / C, c = i - p * C;
+                if (base + p < n)
+                    *reinterpret_cast<half8 *>(x0_16 + (size_t)(base + p) * (kx0 + EW) + 8 * c) =
+                        *reinterpret_cast<const half8 *>(lds.Xh + p * XP + EP - kx0 + 8 * c);
+            }
+        }
         for (int l = 0; l < NH; ++l) {
             const nefii_layer &L = m.layer[l];
             const int units = m_units(L);
@@ -1046,7 +1057,7 @@ extern "C" int nefii_mlp_forward_f16(const nefii_mlp *h_mlp, const float *in_a, 
             const int64_t t = (n + 63) / 64;
             hipLaunchKernelGGL((mlp_forward16q_kernel<4, 64, false>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0,
                                (hipStream_t)stream, *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride,
-                               (void *)stash, stash_stride, (float *)nullptr, G);
+                               (void *)stash, stash_stride, (float *)nullptr, (_Float16 *)nullptr, G);
             HIP_CHECK_LAUNCH();
             return 0;
         }
@@ -1054,7 +1065,7 @@ extern "C" int nefii_mlp_forward_f16(const nefii_mlp *h_mlp, const float *in_a, 
             const int64_t t = (n + 63) / 64;
             hipLaunchKernelGGL((mlp_forward16q_kernel<4, 96, false>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0,
                                (hipStream_t)stream, *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride,
-                               (void *)stash, stash_stride, (float *)nullptr, G);
+                               (void *)stash, stash_stride, (float *)nullptr, (_Float16 *)nullptr, G);
             HIP_CHECK_LAUNCH();
             return 0;
         }
@@ -1079,9 +1090,16 @@ extern "C" int nefii_mlp_h16_supported(const nefii_mlp *h_mlp) {
     return h_mlp->w_stream && mlp_stream_enabled() && mstream_shape(h_mlp) && mstream_units_bwd(h_mlp) > 0;
 }
 
+// width of nefii_mlp_forward_f16h's x0_16 rows: layer 0's padded feature columns + its 64 or 96 encoding columns (0: no h16 path)
+extern "C" int nefii_mlp_x0_width(const nefii_mlp *h_mlp) {
+    if (!nefii_mlp_h16_supported(h_mlp)) return 0;
+    return h_mlp->layer[0].k_x + mstream_shape(h_mlp);
+}
+
 extern "C" int nefii_mlp_forward_f16h(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
                                       const float *feat, int64_t n, float *out, int out_stride, float *hidden_out,
-                                      int hid_stride, void *stash16, int stash_stride, float *z_last, void *stream) {
+                                      int hid_stride, void *stash16, int stash_stride, float *z_last, void *x0_16,
+                                      void *stream) {
     int rc = check_mlp16(h_mlp, false);
     if (rc) return rc;
     if (!nefii_mlp_h16_supported(h_mlp)) return NEFII_E_SHAPE;
@@ -1092,11 +1110,11 @@ extern "C" int nefii_mlp_forward_f16h(const nefii_mlp *h_mlp, const float *in_a,
     if (ew == 64)
         hipLaunchKernelGGL((mlp_forward16q_kernel<4, 64, true>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream,
                            *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash16, stash_stride,
-                           z_last, G);
+                           z_last, (_Float16 *)x0_16, G);
     else
         hipLaunchKernelGGL((mlp_forward16q_kernel<4, 96, true>), dim3((int)(t < 256 ? t : 256)), dim3(512), 0, (hipStream_t)stream,
                            *h_mlp, in_a, in_b, in_c, feat, n, out, out_stride, hidden_out, hid_stride, stash16, stash_stride,
-                           z_last, G);
+                           z_last, (_Float16 *)x0_16, G);
     HIP_CHECK_LAUNCH();
     return 0;
 }

@@ -174,10 +174,11 @@ def h16_supported(pm):
 
 class HalfStash:
     """What nefii_mlp_forward_f16h leaves for the backward pass: h [n_layers - 1, n, stride] halves (16 x the hidden
-    activations), z_last [n, 8] floats (pre-activations of the head)."""
+    activations), z_last [n, 8] floats (pre-activations of the head), x0 [n, nefii_mlp_x0_width] halves (16 x layer 0's
+    input in the kernel's column order: padded features, then the encodings)."""
 
-    def __init__(self, h, z_last):
-        self.h, self.z_last = h, z_last
+    def __init__(self, h, z_last, x0):
+        self.h, self.z_last, self.x0 = h, z_last, x0
 
 
 def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False, h16=None):
@@ -194,10 +195,11 @@ def mlp_forward(pm, in_a, in_b, in_c, feat, want_hidden=False, want_stash=False,
     stash = None
     if want_stash and n > 0 and h16 is not False and h16_supported(pm):
         stash = HalfStash(torch.empty(pm.n_layers - 1, n, pm.hidden_stride, device=dev, dtype=torch.float16),
-                          torch.empty(n, 8, device=dev, dtype=torch.float32))
+                          torch.empty(n, 8, device=dev, dtype=torch.float32),
+                          torch.empty(n, lib.nefii_mlp_x0_width(ctypes.byref(pm.struct)), device=dev, dtype=torch.float16))
         _lib.check(lib.nefii_mlp_forward_f16h(ctypes.byref(pm.struct), _ptr(in_a), _ptr(in_b), _ptr(in_c), _ptr(feat), n,
                                               _ptr(out), n_out, _ptr(hidden), hidden.shape[1] if hidden is not None else 0,
-                                              _ptr(stash.h), pm.hidden_stride, _ptr(stash.z_last), _stream()),
+                                              _ptr(stash.h), pm.hidden_stride, _ptr(stash.z_last), _ptr(stash.x0), _stream()),
                    'nefii_mlp_forward_f16h')
         return out, hidden, stash
     if want_stash:
@@ -255,7 +257,7 @@ def encode_inputs(pm, in_a, in_b, in_c, feat):
 def _stash_tensors(stash, like):
     if stash is None:
         return (like.new_empty(0),)
-    return (stash.h, stash.z_last) if isinstance(stash, HalfStash) else (stash,)
+    return (stash.h, stash.z_last, stash.x0) if isinstance(stash, HalfStash) else (stash,)
 
 
 class FusedMLPFn(torch.autograd.Function):
@@ -287,7 +289,7 @@ class FusedMLPFn(torch.autograd.Function):
         if d_out is None:
             return (None,) * (5 + 2 * pm.n_layers)
         in_a, in_b, in_c, feat, *st = ctx.saved_tensors
-        stash = HalfStash(*st) if len(st) == 2 else st[0]
+        stash = HalfStash(*st) if len(st) == 3 else st[0]
         h16 = isinstance(stash, HalfStash)
         in_b = in_b if ctx.has[0] else None
         in_c = in_c if ctx.has[1] else None
@@ -296,11 +298,25 @@ class FusedMLPFn(torch.autograd.Function):
         d_out = d_out.contiguous()
         gscale = mlp_grad_scale(d_out) if pm.half else None
         dz = mlp_backward(pm, d_out, stash, gscale)
-        x0 = encode_inputs(pm, in_a, in_b, in_c, feat)
         lib = _lib.lib()
         n = d_out.shape[0]
         gw, gb = [], []
+        if h16:     # layer 0's input left by the forward: no encoded matrix to rebuild, dW0 comes in the image's column order
+            s0 = pm.specs[0]
+            k_img = stash.x0.shape[1]
+            g_img = torch.empty(s0.n_out, k_img, device=d_out.device, dtype=torch.float32)
+            b = torch.empty(s0.n_out, device=d_out.device, dtype=torch.float32)
+            _lib.check(lib.nefii_mlp_wgrad_f16h(_ptr(dz[0]), pm.hidden_stride, _ptr(stash.x0), k_img, 1, n, s0.n_out, k_img,
+                                                s0.scale, _ptr(gscale), _ptr(g_img), _ptr(b), _stream()), 'nefii_mlp_wgrad_f16h')
+            kx = lib.nefii_padded_width(s0.x_len)
+            parts = sorted([(s0.x_src0, g_img[:, :s0.x_len]), (s0.e_src0, g_img[:, kx:kx + s0.e_len])], key=lambda t: t[0])
+            gw.append(torch.cat([t[1] for t in parts if t[1].shape[1]], dim=1))
+            gb.append(b)
+        else:
+            x0 = encode_inputs(pm, in_a, in_b, in_c, feat)
         for l, s in enumerate(pm.specs):
+            if l == 0 and h16:
+                continue
             if l == 0:
                 xin, xs = x0, x0.shape[1]
             elif h16:
@@ -316,9 +332,8 @@ class FusedMLPFn(torch.autograd.Function):
             g = torch.empty(s.n_out, s.k_in, device=d_out.device, dtype=torch.float32)
             b = torch.empty(s.n_out, device=d_out.device, dtype=torch.float32)
             if h16:
-                _lib.check(lib.nefii_mlp_wgrad_f16h(_ptr(dz[l]), pm.hidden_stride, _ptr(xin), xs, 1 if l else 0, n, s.n_out,
-                                                    s.k_in, s.scale, _ptr(gscale), _ptr(g), _ptr(b), _stream()),
-                           'nefii_mlp_wgrad_f16h')
+                _lib.check(lib.nefii_mlp_wgrad_f16h(_ptr(dz[l]), pm.hidden_stride, _ptr(xin), xs, 1, n, s.n_out, s.k_in, s.scale,
+                                                    _ptr(gscale), _ptr(g), _ptr(b), _stream()), 'nefii_mlp_wgrad_f16h')
             elif pm.half:
                 _lib.check(lib.nefii_mlp_wgrad_f16(_ptr(dz[l]), pm.hidden_stride, _ptr(xin), xs, n, s.n_out, s.k_in, s.scale,
                                                    _ptr(gscale), _ptr(g), _ptr(b), _stream()), 'nefii_mlp_wgrad_f16')

@@ -7,6 +7,7 @@ albedo) is asserted in tests/test_gpu_renderer.py."""
 import math
 
 import pytest
+import ctypes
 import torch
 
 from nefii_amd import ops, synthetic as syn
@@ -318,6 +319,14 @@ def test_streamed_mlp_forward_matches_the_f32_kernels(name, n):
             assert torch.equal(sh.h[l, :, :w], (s16[l, :, :w] * 16.0).half()), l
         w = sp[-1].n_out
         assert torch.equal(sh.z_last[:, :w], s16[len(sp) - 1, :, :w])
+        # ... and layer 0's input image: 16 x [features, zero-padded | encodings, zero-padded] in halves
+        from nefii_amd import _lib
+        x0 = ops.encode_inputs(pm_stream, *args)
+        s0, kx = sp[0], _lib.lib().nefii_padded_width(sp[0].x_len)
+        assert sh.x0.shape[1] == _lib.lib().nefii_mlp_x0_width(ctypes.byref(pm_stream.struct)) and sh.x0.shape[1] % 8 == 0
+        assert torch.equal(sh.x0[:, :s0.x_len], (x0[:, s0.x_src0:s0.x_src0 + s0.x_len] * 16.0).half())
+        assert torch.equal(sh.x0[:, kx:kx + s0.e_len], (x0[:, s0.e_src0:s0.e_src0 + s0.e_len] * 16.0).half())
+        assert not sh.x0[:, s0.x_len:kx].any() and not sh.x0[:, kx + s0.e_len:].any()
 
 
 @pytest.mark.parametrize('half', [False, 'f16x3', 'f16'])
