@@ -15,7 +15,8 @@ done
 python3 bench.py --workload cfg1 --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_cfg1.json 2> /dev/null
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 (python3 tools/mlp_microbench.py 4096 139264; MODEL=neus python3 tools/mlp_microbench.py 139264; echo "== NEFII_MLP_STREAM=0"
- NEFII_MLP_STREAM=0 python3 tools/mlp_microbench.py 4096 139264; MODEL=neus NEFII_MLP_STREAM=0 python3 tools/mlp_microbench.py 139264) 2>&1 | grep -v amdgpu > $O/mlp_microbench.txt
+ NEFII_MLP_STREAM=0 python3 tools/mlp_microbench.py 4096 139264; MODEL=neus NEFII_MLP_STREAM=0 python3 tools/mlp_microbench.py 139264
+ echo "== NEFII_MLP_H16=0 (fp32 stash and dz)"; NEFII_MLP_H16=0 python3 tools/mlp_microbench.py 4096 139264) 2>&1 | grep -v amdgpu > $O/mlp_microbench.txt
 (python3 tools/wgrad_microbench.py; echo "== NEFII_WGRAD_TR=0"; NEFII_WGRAD_TR=0 python3 tools/wgrad_microbench.py) 2>&1 | grep -v amdgpu > $O/wgrad_microbench.txt
 (python3 tools/eval_microbench.py 1 3 12; MODEL=neus python3 tools/eval_microbench.py 1 3 12) 2>&1 | grep -v amdgpu > $O/eval_microbench.txt
 python3 tools/render_bench.py 2> /dev/null | tail -1 > $O/render_cfg5_crop.json
@@ -23,4 +24,5 @@ python3 tools/trace_rounds.py cfg3 2> /dev/null | grep -v "Warning\|WeightNorm\|
 python3 tools/trace_rounds.py cfg2 2> /dev/null | grep -v "Warning\|WeightNorm\|amdgpu" > $O/rounds_cfg2.txt
 (bash tools/pmc_microbench.sh 12) > $O/pmc_microbench_eval_tile.txt 2>&1
 tools/probes/slot_probe > $O/slot_probe.txt 2>&1
+bash tools/power_probe.sh 2>&1 | grep -v "Warn\|amdgpu.ids" | tr ";" "\n" | grep -v "=====" > $O/power_probe.txt
 tail -c 300 $O/bench_default.json
