@@ -608,7 +608,7 @@ def main():
             result['cfg2_camera_at_1.6'].update({'workload': near['config']['workload'], 'camera': [0.0, 0.0, 1.6],
                                                  'hit_fraction': near['roofline']['hit_fraction'],
                                                  'nonfinite_steps': near['config']['nonfinite_steps']})
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the contract: on rank 0 at N = 1 only
             result['cpu_baseline'], result['parity_vs_cpu_oracle'] = cpu_baseline(headline, args.cpu_sample_rays, device=dev)
             if 'cfg2' in result:
                 result['cfg2']['cpu_baseline'], result['cfg2']['parity_vs_cpu_oracle'] = cpu_baseline(
