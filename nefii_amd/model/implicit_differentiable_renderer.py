@@ -32,7 +32,11 @@ from .sg_render import render_with_sg
 
 
 def _params_version(module):
-    return tuple((p.data_ptr(), p._version) for p in module.parameters())
+    """Changes whenever a parameter's storage or content does (ops.param_list: the parameter list is gathered once)."""
+    return tuple((p.data_ptr(), p._version) for p in _plist(module))
+
+
+_plist = ops.param_list
 
 
 class ImplicitNetwork(nn.Module):
@@ -121,7 +125,7 @@ class ImplicitNetwork(nn.Module):
     def packed(self, f16x3=False):
         """Packed MFMA-order weights; repacked only when a parameter changed (never, once geometry is frozen)."""
         ver = _params_version(self)
-        dev = next(self.parameters()).device
+        dev = _plist(self)[0].device
         if self._pm is None or self._pm.device != dev or (f16x3 and not self._pm.f16x3):
             self._pm = ops.PackedMLP(self.specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, self.enc, 0, dev, f16x3=f16x3)
             self._pm_version = None
@@ -133,13 +137,13 @@ class ImplicitNetwork(nn.Module):
         return self._pm
 
     def _check_frozen(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in _plist(self)):
             raise NotImplementedError(
                 'nefii_amd: differentiating through the SDF network (trainable geometry) is outside the Step-2 '
                 'hot path; call IDRNetwork.freeze_geometry() as every shipped Step-2 script does')
 
     def _trainable(self):
-        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return torch.is_grad_enabled() and any(p.requires_grad for p in _plist(self))
 
     def forward(self, input, compute_grad=False):
         x = ops._f32(input)
@@ -243,7 +247,7 @@ class RenderingNetwork(nn.Module):
             a, b, c = p, v, None
         feat = ops._f32(feature_vectors) if self.feature_vector_size > 0 else None
         pm = self.packed(p.device)
-        if self.outputs_detached or not torch.is_grad_enabled() or not any(q.requires_grad for q in self.parameters()):
+        if self.outputs_detached or not torch.is_grad_enabled() or not any(q.requires_grad for q in _plist(self)):
             # no gradient can reach the weights: weight norm and packing only when a parameter changed (never while the loss
             # does not train this network; once per frame chunk in a render before) - 8 launches less per call
             key = (_params_version(self), id(pm))

@@ -155,7 +155,7 @@ class RayTracing(nn.Module):
         # dense search costs them more than its cheaper samples save; config 1: 2.39 vs 2.2 ms per step)
         # ... and geometry that still trains (model/trainable_geometry.py) changes its weights every step: the bound would
         # have to be re-measured per forward (two 65 k-point evaluations and a host sync) - no coarse pass there
-        frozen = not any(p.requires_grad for p in net.parameters())
+        frozen = not any(p.requires_grad for p in ops.param_list(net))
         if self.coarse and self.precision == 'f16x3w' and n_rays > 1024 and (frozen or self.coarse_tau_override is not None):
             tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
                 net.coarse_tau(self.object_bounding_sphere)

@@ -40,7 +40,14 @@ def _f32(t):
     return t.detach().to(torch.float32).contiguous()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the raw getter is ~20x cheaper than building a
+    torch.cuda.Stream object: ~1300 calls per 300 steps of config 1)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -170,6 +177,16 @@ def h16_supported(pm):
     if getattr(pm, '_h16', None) is None:        # a property of the net's shape and buffers, not of its weights
         pm._h16 = bool(_lib.lib().nefii_mlp_h16_supported(ctypes.byref(pm.struct)))
     return pm._h16
+
+
+def param_list(module):
+    """list(module.parameters()), gathered once per module: the Parameter OBJECTS of the networks here are fixed at
+    construction (weight_norm included; load_state_dict / .to() / optimizers write in place), and Module.parameters() walks
+    the module tree on every call - the per-step version / requires_grad checks cost 0.09 ms of config 1's 0.81-ms host step."""
+    plist = module.__dict__.get('_nefii_plist')
+    if plist is None:
+        plist = module.__dict__['_nefii_plist'] = list(module.parameters())
+    return plist
 
 
 class HalfStash:

@@ -124,3 +124,27 @@ def test_tensorboard_event_file_round_trip(tmp_path):
     assert (h, wd, c) == (4, 6, 3) and ev[3]['tag'] == 'train/panel-0'
     back = np.asarray(Image.open(io.BytesIO(png)))
     assert back.shape == (4, 6, 3) and back[1, 2, 0] == 255 and back[0, 0, 2] == 128 and back[0, 0, 0] == 0
+
+
+def test_scheduler_fast_path_equals_multisteplr():
+    """TrainStep steps its two MultiStepLR schedulers through _scheduler_step: off the milestones two counter increments instead of
+    torch's step() (which rewrites and clones an unchanged learning rate - launches, in graph mode).  Learning rates, get_last_lr
+    and the state dict (what the checkpoints hold, idr_train.py:251-306) must be what step() leaves, repeated milestones included."""
+    import torch
+    from nefii_amd.training.step import _scheduler_step
+
+    def run(fast):
+        p = [torch.nn.Parameter(torch.zeros(3))]
+        o = torch.optim.Adam(p, lr=5e-4)
+        s = torch.optim.lr_scheduler.MultiStepLR(o, [3, 7, 7, 12], gamma=0.5)
+        seen = []
+        for _ in range(15):
+            o.step()
+            _scheduler_step(s) if fast else s.step()
+            seen.append((o.param_groups[0]['lr'], tuple(s.get_last_lr()), s.last_epoch, s._step_count))
+        return seen, dict(s.state_dict())
+
+    a, sa = run(True)
+    b, sb = run(False)
+    assert a == b
+    assert sa == sb
