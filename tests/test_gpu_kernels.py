@@ -233,7 +233,8 @@ def test_weight_gradient_gemm_fp16(n, n_out, k_in, x_stride):
 
 
 @pytest.mark.parametrize('n,n_out,k_in,x_half', [(5000, 512, 512, 1), (70001, 512, 512, 1), (4097, 512, 605, 0), (1024, 512, 575, 0),
-                                                  (2000, 3, 512, 1), (3000, 100, 512, 1), (1500, 512, 39, 0)])
+                                                  (2000, 3, 512, 1), (3000, 100, 512, 1), (1500, 512, 39, 0), (163, 512, 512, 1),
+                                                  (1, 512, 608, 1), (1030, 512, 608, 1)])
 def test_weight_gradient_gemm_from_halves(n, n_out, k_in, x_half):
     """nefii_mlp_wgrad_f16h: the same GEMM fed with S dz (and, x_half, 16 x) already in halves equals nefii_mlp_wgrad_f16 on
     the fp32 values those halves came from - the fp32 call rounds to the very same operands - up to the order of the
@@ -244,7 +245,7 @@ def test_weight_gradient_gemm_from_halves(n, n_out, k_in, x_half):
     S = torch.tensor([2.0 ** 28], device=DEV)
     dz16 = ((torch.randn(n, 512, generator=g) * 3e-7).to(DEV) * S).half()
     dz16[:, n_out:] = 0
-    x_stride = 512 if x_half else k_in
+    x_stride = max(512, k_in) if x_half else k_in
     xf = torch.randn(n, x_stride, generator=g).to(DEV)
     x16 = (xf * 16.0).half()
     scale = 0.7
@@ -265,6 +266,49 @@ def test_weight_gradient_gemm_from_halves(n, n_out, k_in, x_half):
     (dWh, dbh), (dWf, dbf) = out
     assert rel_l2(dWh, dWf) < 1e-6, rel_l2(dWh, dWf)
     assert rel_l2(dbh, dbf) < 1e-6, rel_l2(dbh, dbf)
+
+
+def test_half_state_entry_points_refuse_what_they_cannot_run():
+    """nefii_mlp_*_f16h: a net off the streamed kernels (64-wide hidden layers) is NEFII_E_SHAPE (-2) - ops.py then keeps the
+    fp32 stash and the old entry points, which the gradient tests of the hidden = 64 models exercise; a missing array is
+    NEFII_E_ARG (-1); n = 0 is a no-op."""
+    from nefii_amd import _lib
+    from nefii_amd.ops import _ptr, _stream
+    lib = _lib.lib()
+    mc = syn.model_conf('conf')
+    F = mc['feature_vector_size']
+    specs, enc, head = ops.radiance_specs(mc['rendering_network'], F)
+    sd = syn.make_state_dict(mc, seed=4)
+    pm = ops.PackedMLP(specs, ops.ACT_RELU, head, enc, F, DEV, half='f16x3')
+    pm.pack(*[[t.to(DEV) for t in ts] for ts in zip(*[nets.linear_params(sd, 'rendering_network.lin%d' % l) for l in range(len(specs))])])
+    assert ops.h16_supported(pm) and lib.nefii_mlp_x0_width(ctypes.byref(pm.struct)) == 512 + 96
+    small = syn.model_conf('conf', hidden=64)
+    s2, e2, h2 = ops.radiance_specs(small['rendering_network'], small['feature_vector_size'])
+    sd2 = syn.make_state_dict(small, seed=4)
+    pm2 = ops.PackedMLP(s2, ops.ACT_RELU, h2, e2, small['feature_vector_size'], DEV, half='f16x3')
+    pm2.pack(*[[t.to(DEV) for t in ts] for ts in zip(*[nets.linear_params(sd2, 'rendering_network.lin%d' % l) for l in range(len(s2))])])
+    assert not ops.h16_supported(pm2) and lib.nefii_mlp_x0_width(ctypes.byref(pm2.struct)) == 0
+    n = 10
+    x = torch.zeros(n, 3, device=DEV)
+    feat = torch.zeros(n, F, device=DEV)
+    out = torch.zeros(n, 3, device=DEV)
+    st16 = torch.zeros(len(specs) - 1, n, 512, device=DEV, dtype=torch.float16)
+    zl = torch.zeros(n, 8, device=DEV)
+    x0 = torch.zeros(n, 608, device=DEV, dtype=torch.float16)
+    call = lambda p, stash, z, cnt=n: lib.nefii_mlp_forward_f16h(ctypes.byref(p.struct), _ptr(x), _ptr(x), _ptr(x), _ptr(feat), cnt,
+                                                                _ptr(out), 3, None, 0, stash, 512, z, _ptr(x0), _stream())
+    assert call(pm2, _ptr(st16), _ptr(zl)) == -2
+    assert call(pm, None, _ptr(zl)) == -1 and call(pm, _ptr(st16), None) == -1
+    assert call(pm, None, None, 0) == 0
+    assert call(pm, _ptr(st16), _ptr(zl)) == 0
+    S = torch.ones(1, device=DEV)
+    dz = torch.zeros(len(specs), n, 512, device=DEV, dtype=torch.float16)
+    bwd = lambda p, d: lib.nefii_mlp_backward_f16h(ctypes.byref(p.struct), _ptr(out), 3, _ptr(st16), 512, _ptr(zl), n, d, 512, _ptr(S),
+                                                   _stream())
+    assert bwd(pm2, _ptr(dz)) == -2 and bwd(pm, None) == -1 and bwd(pm, _ptr(dz)) == 0
+    dW = torch.zeros(512, 512, device=DEV)
+    assert lib.nefii_mlp_wgrad_f16h(None, 512, _ptr(st16), 512, 1, n, 512, 512, 1.0, _ptr(S), _ptr(dW), None, _stream()) == -1
+    torch.cuda.synchronize()
 
 
 # (the sizes above 16 384 give every workgroup a SECOND tile: the forward of round 2 re-zeroed only half of its last-layer
