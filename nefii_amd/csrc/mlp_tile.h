@@ -948,7 +948,10 @@ template <int FT>
 struct QGeo {
     static constexpr int HW = 128 * FT;                 // hidden width = first encoding column
     static constexpr int EW = FT == 4 ? 64 : 128;       // encoding columns incl. zero padding
-    static constexpr int XP = HW + EW + 8;              // halves per row: 584 / 392 (16 B * odd)
+#ifndef NEFII_XPAD
+#define NEFII_XPAD 8
+#endif
+    static constexpr int XP = HW + EW + NEFII_XPAD;     // halves per row: 584 / 392 (16 B * odd)
     static constexpr int ROWS = FT == 4 ? 64 : 96;      // queries per tile at most
 };
 template <int FT>
