@@ -30,7 +30,8 @@ precision, 3 fp16 MFMAs per product; eval_kernel16s: the single-pass coarse eval
   frac_8d = the same kernel time against SURVEY 8(d)'s evaluations only (E_tr + 3 h E_tr2: WITHOUT the min-SDF search);
   sustained_peak: what a bare MFMA loop on random operands reaches on THIS device in THIS run (nefii_mfma_sustained_probe):
          MI355X is power-limited under dense fp16 MFMA work (profiles/r04/slot_probe.txt) - frac is priced against the 2.5
-         PFLOP/s spec, frac_of_sustained / issued_frac_of_sustained say how far the kernels are from what the part delivers.
+         PFLOP/s spec, frac_of_sustained / issued_frac_of_sustained say how far the kernels are from what the part delivers;
+  board_power (N = 1): rocm-smi's package power sampled during the timed steps, beside the cap it is limited to.
 `cpu_baseline`: the CPU oracle (kind "port": a PyTorch-CPU restatement of the reference, pinned against the
 reference's own outputs) running the same step on a bounded sample of the same workload on the host cores: 2 warm-ups,
 best of 5, the reference's own 1-thread setting after a warm-up, host CPU model and core count.
@@ -152,7 +153,8 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None):
     return res, parity
 
 
-def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side=True, scaling=None, sustained=None):
+def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side=True, scaling=None, sustained=None,
+                 power=False):
     """Time `steps` training steps of WORKLOADS[name] (every rank), then measure the roofline terms in un-timed extra
     steps.  Returns the result dict on rank 0, None elsewhere."""
     import ctypes
@@ -206,22 +208,25 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     # `repeats` times back to back (63 ms of a 20-step config-2 region is a thin basis for a headline: boxes and moments
     # differ by a few percent); the line reports the MEDIAN repetition and lists them all
     reps = []
-    for _ in range(max(1, args.repeats)):
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            out, lo = step(inp, gt, nxt)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = t.item()
-        reps.append(elapsed)
+    import contextlib
+    with contextlib.ExitStack() as stack:       # (the headline at N = 1 also reads the board's power sensor meanwhile)
+        meter = stack.enter_context(BoardPower()) if power and rank == 0 and world == 1 else None
+        for _ in range(max(1, args.repeats)):
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out, lo = step(inp, gt, nxt)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            elapsed = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = t.item()
+            reps.append(elapsed)
     elapsed = sorted(reps)[len(reps) // 2]
     ms_per_step = elapsed / steps * 1e3
     value = rays_all_ranks / (elapsed / steps)
@@ -344,6 +349,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                 'frac_kernel': achieved / peak, 'frac_step': frac_step, 'frac_chip': frac_chip, 'frac_8d': frac_8d,
                 'issued_tflops': issued,
                 'sustained_peak': sustained,
+                'board_power': meter.summary() if meter is not None else None,
                 'frac_of_sustained': (achieved / sustained['value']) if sustained else None,
                 'issued_frac_of_sustained': (issued / sustained['value']) if sustained else None,
                 'frac_definitions': 'frac_kernel: evaluator flops / evaluator launch time of ONE trace run serially (HIP '
@@ -392,7 +398,8 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                                'fwd+IDRLoss+bwd+2xAdam'
                                % (name + (' (strong scaling: global batch split over the ranks)' if strong else ''),
                                   'robot-like synthetic scene (geometric-init SDF sphere)' if not w.get('scene') else
-                                  'non-convex synthetic scene (fitted ball-in-bowl SDF embedded at full width)',
+                                  'non-convex synthetic scene (fitted ball-in-bowl SDF embedded at full width%s)'
+                                  % (', no zero weights' if w['scene'].endswith('_dense') else ', zero-padded'),
                                   {'physg': 'physg.conf', 'conf': 'conf.conf', 'neus': 'conf_neus.conf'}[w['model']],
                                   w['num_pixels'], (' x %d rays/pixel' % w['num_rays']) if w['num_rays'] > 0 else '',
                                   'indirect OFF (closed-form SG)' if not indirect else 'MC direct + near-field indirect ON'),
@@ -477,6 +484,51 @@ def run_render(name, args, frames, rank, world, dev, backend):
                        'finite': bool(all(torch.isfinite(v).all() for v in out.values() if v.dtype.is_floating_point)),
                        'parallelism': 'pixel chunks x %d' % world},
             'invalid': False}
+
+
+class BoardPower:
+    """Board power (rocm-smi's "Current Socket Graphics Package Power") sampled twice a second by a background thread while the
+    timed steps of the headline run, with the cap beside it: the evaluators' bound is the part's power budget, and
+    this puts the sensor's reading into the line the run itself prints.  Best effort: no rocm-smi, no sample, no field."""
+
+    def __init__(self, period=0.5):
+        import threading
+        self.period, self.samples, self.cap = period, [], None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _query(*flags):
+        out = subprocess.run(['rocm-smi', *flags, '--json'], capture_output=True, text=True, timeout=5).stdout
+        card = next(iter(json.loads(out).values()))
+        return float(next(v for k, v in card.items() if 'Power' in k))
+
+    def _run(self):
+        while not self._stop.wait(self.period):
+            try:
+                self.samples.append(self._query('--showpower'))
+            except Exception:
+                return
+
+    def __enter__(self):
+        try:
+            self.cap = self._query('--showmaxpower')
+            self._thread.start()
+        except Exception:
+            self.cap = None
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread.is_alive():
+            self._thread.join(timeout=6)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        return {'avg_w': sum(self.samples) / len(self.samples), 'max_w': max(self.samples), 'cap_w': self.cap,
+                'samples': len(self.samples), 'source': 'rocm-smi --showpower / --showmaxpower, every %.1f s during the timed '
+                'steps (first visible device)' % self.period}
 
 
 def measure_sustained(lib):
@@ -570,7 +622,7 @@ def main():
         return
     sustained = measure_sustained(lib)          # every rank (its own device); rank 0's goes into the line
     result = run_workload(headline, args, args.steps, args.warmup, rank, world, dev, backend, lib,
-                          side=not args.no_side_measurement, sustained=sustained)
+                          side=not args.no_side_measurement, sustained=sustained, power=True)
     nested = {}
     if args.workload is None and not args.no_nested:
         short = dict(steps=max(1, min(args.steps, 20)), warmup=min(args.warmup, 3))
@@ -584,6 +636,17 @@ def main():
         # BASELINE's 8-GPU training config as it is defined: the global 8192-pixel batch split over the ranks
         nested['cfg4'] = run_workload('cfg4', args, max(1, min(args.steps, 10)), min(args.warmup, 2), rank, world, dev, backend,
                                       lib, side=False, scaling='strong' if world > 1 else 'weak', sustained=sustained)
+        if world == 1 and headline == 'cfg3':
+            # the same step on the ZERO-PADDED embedding of the same geometry (rounds 2-4's stand-in: 98 % zero weights in the
+            # SDF net): what a power-limited part makes of cheap operands - comparable with earlier rounds' lines, not a headline
+            from nefii_amd import synthetic as syn
+            scene = syn.WORKLOADS['cfg3']['scene']
+            syn.WORKLOADS['cfg3']['scene'] = 'bowl'
+            try:
+                nested['cfg3_zero_padded'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
+                                                          dev, backend, lib, side=False, sustained=sustained, power=True)
+            finally:
+                syn.WORKLOADS['cfg3']['scene'] = scene
         # ... and its render config, bounded: a band of 32 rows through the object (25 600 pixels x 256 rays)
         band = argparse.Namespace(**vars(args))
         band.frame_rows = args.frame_rows or 32
@@ -599,6 +662,14 @@ def main():
                 result[k] = {f: nested[k][f] for f in keep if f in nested[k]}
         if nested.get('cfg5') is not None:
             result['cfg5'] = nested['cfg5']
+        zp = nested.get('cfg3_zero_padded')
+        if zp is not None:
+            result['cfg3_zero_padded_stand_in'] = {
+                'ms_per_step': zp['ms_per_step'], 'ms_per_step_repeats': zp['ms_per_step_repeats'], 'value': zp['value'],
+                'frac': zp['roofline']['frac'], 'board_power': zp['roofline']['board_power'], 'workload': zp['config']['workload'],
+                'nonfinite_steps': zp['config']['nonfinite_steps'],
+                'note': 'same geometry, same kernels; the SDF net holds 98 % zero weights, the matrix cores draw less power and the '
+                        'part clocks higher - the stand-in of rounds 2-4, kept for comparison with their lines'}
         near = nested.get('cfg2_near')
         if near is not None:
             # SURVEY.md section 8(d) planned a ~40 % hit fraction for config 2; the geometric-init surface seen from 2.4 gives

@@ -290,7 +290,7 @@ def golden_forward_full_width():
     512-/256-wide path to the reference directly (the hidden-64 fixtures above pin the logic)."""
     for tag, wl, npx, nr in [('conf512', 'cfg3', 32, 4), ('neus256', 'cfg4', 32, 4)]:
         w = syn.WORKLOADS[wl]
-        mc, sd = syn.workload_state_dict(wl, seed=0)
+        mc, sd = syn.workload_state_dict(wl, seed=0, scene='bowl')
         lc = syn.loss_conf(w['model'])
         m = build_ref(mc, sd)
         inp, gt = syn.make_inputs(npx, w['image_hw'], w['focal'], w['cam_pos'], nr, seed=9)

@@ -123,7 +123,7 @@ def forward_case(tag):
     """(fixture name, model conf, state dict, loss conf) of a forward_* fixture (tests/golden/make_golden.py)."""
     if tag in ('conf512', 'neus256'):       # the confs' full widths on the non-convex stand-in scene of configs 3-5
         wl = {'conf512': 'cfg3', 'neus256': 'cfg4'}[tag]
-        mc, sd = syn.workload_state_dict(wl, seed=0)
+        mc, sd = syn.workload_state_dict(wl, seed=0, scene='bowl')
         return mc, sd, syn.loss_conf(syn.WORKLOADS[wl]['model'])
     mc = syn.model_conf(tag, hidden=64)
     return mc, syn.make_state_dict(mc, seed=0, bumpy=0.02), syn.loss_conf(tag)

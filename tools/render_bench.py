@@ -16,7 +16,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'conf'
 num_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 pixels = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 mc = syn.model_conf(name)
-sd = syn.make_state_dict(mc, seed=0, scene='bowl')   # the non-convex stand-in of configs 3-5
+sd = syn.make_state_dict(mc, seed=0, scene=os.environ.get('SCENE', 'bowl_dense'))   # the non-convex stand-in of configs 3-5
 m = IDRNetwork(conf.from_dict(mc))
 m.load_state_dict(sd)
 m = m.cuda().eval()
