@@ -31,7 +31,7 @@ precision, 3 fp16 MFMAs per product; eval_kernel16s: the single-pass coarse eval
   sustained_peak: what a bare MFMA loop on random operands reaches on THIS device in THIS run (nefii_mfma_sustained_probe):
          MI355X is power-limited under dense fp16 MFMA work (profiles/r04/slot_probe.txt) - frac is priced against the 2.5
          PFLOP/s spec, frac_of_sustained / issued_frac_of_sustained say how far the kernels are from what the part delivers;
-  board_power (N = 1): rocm-smi's package power sampled during the timed steps, beside the cap it is limited to.
+  board_power (N = 1): the device's hwmon power sensor sampled during the timed steps, beside the cap it is limited to.
 `cpu_baseline`: the CPU oracle (kind "port": a PyTorch-CPU restatement of the reference, pinned against the
 reference's own outputs) running the same step on a bounded sample of the same workload on the host cores: 2 warm-ups,
 best of 5, the reference's own 1-thread setting after a warm-up, host CPU model and core count.
@@ -487,48 +487,58 @@ def run_render(name, args, frames, rank, world, dev, backend):
 
 
 class BoardPower:
-    """Board power (rocm-smi's "Current Socket Graphics Package Power") sampled twice a second by a background thread while the
-    timed steps of the headline run, with the cap beside it: the evaluators' bound is the part's power budget, and
-    this puts the sensor's reading into the line the run itself prints.  Best effort: no rocm-smi, no sample, no field."""
+    """Board power (the amdgpu hwmon sensor power1_input of THIS process's device, found through its PCI address) sampled
+    five times a second by a background thread while the timed steps of the headline run, with the cap (power1_cap) beside it:
+    the evaluators' bound is the part's power budget, and this puts the sensor's reading into the line the run
+    itself prints.  Plain sysfs reads - no child process (a process that has initialised the GPU must not exec, and rocm-smi
+    under a profiler's preload does).  Best effort: no sensor, no field."""
 
-    def __init__(self, period=0.5):
+    def __init__(self, period=0.2):
         import threading
-        self.period, self.samples, self.cap = period, [], None
+        self.period, self.samples, self.cap, self.path = period, [], None, None
         self._stop = threading.Event()
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     @staticmethod
-    def _query(*flags):
-        out = subprocess.run(['rocm-smi', *flags, '--json'], capture_output=True, text=True, timeout=5).stdout
-        card = next(iter(json.loads(out).values()))
-        return float(next(v for k, v in card.items() if 'Power' in k))
+    def _hwmon():
+        import glob
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        addr = '%04x:%02x:%02x.0' % (getattr(pr, 'pci_domain_id', 0), pr.pci_bus_id, pr.pci_device_id)
+        found = glob.glob('/sys/bus/pci/devices/%s/hwmon/hwmon*/power1_input' % addr)
+        return os.path.dirname(found[0]) if found else None
+
+    @staticmethod
+    def _read(path):
+        with open(path) as f:
+            return float(f.read()) * 1e-6      # microwatts
 
     def _run(self):
         while not self._stop.wait(self.period):
             try:
-                self.samples.append(self._query('--showpower'))
+                self.samples.append(self._read(os.path.join(self.path, 'power1_input')))
             except Exception:
                 return
 
     def __enter__(self):
         try:
-            self.cap = self._query('--showmaxpower')
-            self._thread.start()
+            self.path = self._hwmon()
+            if self.path:
+                self.cap = self._read(os.path.join(self.path, 'power1_cap'))
+                self._thread.start()
         except Exception:
-            self.cap = None
+            self.path = None
         return self
 
     def __exit__(self, *exc):
         self._stop.set()
         if self._thread.is_alive():
-            self._thread.join(timeout=6)
+            self._thread.join(timeout=2)
 
     def summary(self):
         if not self.samples:
             return None
         return {'avg_w': sum(self.samples) / len(self.samples), 'max_w': max(self.samples), 'cap_w': self.cap,
-                'samples': len(self.samples), 'source': 'rocm-smi --showpower / --showmaxpower, every %.1f s during the timed '
-                'steps (first visible device)' % self.period}
+                'samples': len(self.samples), 'source': '%s/power1_input, every %.1f s during the timed steps' % (self.path, self.period)}
 
 
 def measure_sustained(lib):
