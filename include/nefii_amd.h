@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 10
+#define NEFII_ABI_VERSION 11
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -272,13 +272,13 @@ int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
  * minimal_sdf_points (only read when training).  counters (optional, int32 [max_rounds][NEFII_TRACE_COUNTERS])
  * receives per round: [r][0] single queries, [r][1] rays with n_steps dense queries in split precision, [r][2] rays in
  * bisection (2^levels - 1 speculative queries each), [r][3] bisection evaluations actually consumed, [r][4] coarse-pass
- * samples re-evaluated in split precision, [r][5] rays with n_steps dense queries in the single-pass (coarse) evaluator,
+ * samples re-evaluated in split precision, [r][5] QUARTER rows (ceil(n_steps / 4) samples of one ray) in the single-pass (coarse) evaluator (ABI 11; whole rows before),
  * [r][6] rays entering a dense search (the reference evaluates n_steps samples for each), [r][7] = (2^levels - 1)*[2],
  * the speculative bisection evaluations executed, [r][8] (the bits of a float >= 0) the largest |coarse - split| among the
  * coarse-pass samples this round re-evaluated in split precision: the online audit of coarse_tau - every refined sample
  * is evaluated both ways anyway; a value above coarse_tau means the caller's bound does not hold for this net.
  * Algorithmic evaluations (what the reference's recurrences need) = [0] + n_steps*[6] + [3]; executed in split
- * precision = [0] + n_steps*[1] + [7] + [4]; executed in the coarse evaluator = n_steps*[5]. */
+ * precision = [0] + n_steps*[1] + [7] + [4]; executed in the coarse evaluator = ceil(n_steps / 4)*[5]. */
 int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
                      const float *origins, const float *dirs, const uint8_t *object_mask, int64_t n_rays,
                      const float *lin_steps, const float *minsdf_steps,

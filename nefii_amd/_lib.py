@@ -14,7 +14,7 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 10
+ABI_VERSION = 11
 TRACE_COUNTERS = 9          # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2

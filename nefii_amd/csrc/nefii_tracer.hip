@@ -45,7 +45,7 @@ struct RayState {            // SoA views into the workspace
     unsigned *singles;       // [2n]  (ray << 2 | kind)
     unsigned *dense;         // [n]   (ray << 1 | which)  which: 0 sampler, 1 min-sdf
     unsigned *tri;           // [n]   rays in bisection: 7 speculative queries each (3 levels of the bisection tree)
-    unsigned *cdense;        // [n]   (ray << 1 | which): rays whose n_steps samples go through the coarse evaluator
+    unsigned *cdense;        // [4n]  (window << 29 | ray << 1 | which): quarter rows (CW samples of a ray's n_steps) for the coarse evaluator
     unsigned *refine;        // [n * cap]  (ray << 7 | sample): coarse samples to re-evaluate in split precision
 };
 
@@ -56,6 +56,10 @@ constexpr int F_STEPPED = 1 << 7;     // results belong to a step / back-off (no
 constexpr int F_SPH = 1 << 8, F_SAMP = 1 << 9, F_HIT = 1 << 10;
 constexpr int F_IT_SHIFT = 12, F_IT_MASK = 0xFF;     // sphere-tracing iteration / bisection step
 constexpr int F_K_SHIFT = 20, F_K_MASK = 0xF;        // back-off count
+// PH_SAMPLER_C only: 0 = the whole row is with the coarse evaluator; w = 1..4: windowed search, the first w quarter rows are
+constexpr int F_WIN_SHIFT = 24, F_WIN_MASK = 0x7;
+// samples per quarter row (window) of a coarse row
+__host__ __device__ __forceinline__ int coarse_window(int n_steps) { return (n_steps + 3) >> 2; }
 
 __device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
@@ -75,6 +79,7 @@ struct Params {
     int cap;                 //              most samples of one ray refined individually
     int chunk;               //              leading samples of a bracket search evaluated exactly first (0: off)
     float chunk_gate;        //              ... for rays whose front SDF is below chunk_gate x the chunk's reach
+    int window;              //              bracket searches inside the object mask take their coarse samples a quarter row at a time
     RayState s;
 };
 
@@ -88,13 +93,14 @@ __device__ __forceinline__ float minsdf_step(const Params &P, int64_t r, int i) 
 // ---- work-list append: block-aggregated ------------------------------------------------------
 // each thread contributes up to 2 single queries, one dense ray (split precision or coarse), one bisecting ray and
 // n_ref coarse samples to refine (bit set `cmask`).
-__device__ __forceinline__ void append_queries(const Params &P, int round, bool qs, bool qe, bool qt, bool qd, bool qc,
+// nc / cwin: quarter rows cwin .. cwin + nc - 1 of the ray's samples for the coarse evaluator (4 from 0: the whole row).
+__device__ __forceinline__ void append_queries(const Params &P, int round, bool qs, bool qe, bool qt, bool qd, int nc, int cwin,
                                                unsigned ray, unsigned dense_which, int consumed, int n_alg, int n_ref,
                                                const unsigned (&cmask)[4]) {
     __shared__ int wtot[7][4];
     __shared__ int base[5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long bs = __ballot(qs), be = __ballot(qe), bt = __ballot(qt), bd = __ballot(qd), bc = __ballot(qc);
+    const unsigned long long bs = __ballot(qs), be = __ballot(qe), bt = __ballot(qt), bd = __ballot(qd);
     const unsigned long long lt = (1ull << lane) - 1ull;
     int cons = consumed, alg = n_alg;
 #pragma unroll
@@ -106,13 +112,20 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
         if (lane >= o) incl += t;
     }
     const int wref = __shfl(incl, 63);
+    int cincl = nc;                 // ... and of the coarse window counts
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(cincl, o);
+        if (lane >= o) cincl += t;
+    }
+    const int wcoarse = __shfl(cincl, 63);
     if (lane == 0) {
         wtot[0][wave] = __popcll(bs) + __popcll(be);
         wtot[1][wave] = __popcll(bd);
         wtot[2][wave] = __popcll(bt);
         wtot[3][wave] = cons;
         wtot[4][wave] = wref;
-        wtot[5][wave] = __popcll(bc);
+        wtot[5][wave] = wcoarse;
         wtot[6][wave] = alg;
     }
     __syncthreads();
@@ -140,7 +153,8 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
     if (qe) P.s.singles[off_s + __popcll(bs) + __popcll(be & lt)] = (ray << 2) | Q_END;
     if (qd) P.s.dense[off_d + __popcll(bd & lt)] = (ray << 1) | dense_which;
     if (qt) P.s.tri[off_t + __popcll(bt & lt)] = ray;
-    if (qc) P.s.cdense[off_c + __popcll(bc & lt)] = (ray << 1) | dense_which;
+    for (int k = 0; k < nc; ++k)
+        P.s.cdense[off_c + cincl - nc + k] = ((unsigned)(cwin + k) << 29) | (ray << 1) | dense_which;
     if (n_ref > 0) {
         size_t o = (size_t)off_r + incl - n_ref;
 #pragma unroll
@@ -185,7 +199,8 @@ __device__ __forceinline__ void finish(const Params &P, int64_t r, float dist, b
 __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = r < P.n;
-    bool qs = false, qe = false, qt = false, qd = false, qc = false;
+    bool qs = false, qe = false, qt = false, qd = false;
+    int nc = 0, cwin = 0;         // quarter rows of this ray for the coarse evaluator
     unsigned dense_which = 0;
     int consumed = 0;          // bisection evaluations actually used this round (of the 7 speculated per ray)
     int n_alg = 0;             // dense searches entered this round (the reference evaluates n_steps samples for each)
@@ -298,7 +313,14 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                     } else {
                         fl |= go_coarse ? PH_SAMPLER_C : PH_SAMPLER;
                         qd = !go_coarse;
-                        qc = go_coarse;
+                        // inside the object mask the search ends at the first negative sample: the quarter rows go out one
+                        // at a time (P.window; outside the mask the argmin over the whole row is the result)
+                        if (go_coarse && P.window && P.obj[r] != 0) {
+                            nc = 1;
+                            fl |= 1 << F_WIN_SHIFT;
+                        } else if (go_coarse) {
+                            nc = 4;
+                        }
                     }
                     n_alg = 1;
                     dense_which = 0;
@@ -358,10 +380,47 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             ph = PH_SAMPLER;
         } else {
             fl = (fl & ~F_PHASE) | PH_SAMPLER_C;
-            qc = true;
+            if (P.window) {             // (PH_SAMPLER_X rays lie inside the object mask)
+                nc = 1;
+                fl |= 1 << F_WIN_SHIFT;
+            } else {
+                nc = 4;
+            }
             dense_which = 0;
             P.s.flags[r] = fl;
             ph = -1;
+        }
+    }
+
+    if (valid && ph == PH_SAMPLER_C && ((fl >> F_WIN_SHIFT) & F_WIN_MASK) != 0) {
+        // Windowed search (rays inside the object mask): the first wn quarter rows hold coarse values.  A sample that is
+        // SURELY negative (< -tau) among them ends the search exactly as the whole row would: the decision below reads the
+        // samples up to it only (no argmin: the ray has its negative sample inside the mask), so the rest of the row gets out
+        // of the way unevaluated.  Not if the first candidate is sample 0 - its bracket partner is the LAST sample
+        // (ray_tracing.py:245-246): then, and when all four quarters are in, the row is completed and decided as a whole.
+        const int ns = tp.n_steps, cw = coarse_window(ns);
+        const int wn = (fl >> F_WIN_SHIFT) & F_WIN_MASK;
+        const int have = wn * cw < ns ? wn * cw : ns;
+        float *v = P.s.big + (size_t)r * ns;
+        int i0 = -1, i1 = -1;
+        for (int i = 0; i < have; ++i) {
+            const float x = v[i];
+            if (x < P.tau && i0 < 0) i0 = i;
+            if (x < -P.tau && i1 < 0) i1 = i;
+        }
+        if (i1 >= 0 && i0 > 0) {
+            for (int i = have; i < ns; ++i) v[i] = 3.0e38f;
+            fl &= ~(F_WIN_MASK << F_WIN_SHIFT);                 // decided below, this round
+        } else if (have < ns) {
+            const bool rest = i0 == 0;                          // all remaining quarters at once
+            nc = rest ? 4 - wn : 1;
+            cwin = wn;
+            fl = (fl & ~(F_WIN_MASK << F_WIN_SHIFT)) | ((rest ? 4 : wn + 1) << F_WIN_SHIFT);
+            dense_which = 0;
+            P.s.flags[r] = fl;
+            ph = -1;
+        } else {
+            fl &= ~(F_WIN_MASK << F_WIN_SHIFT);                 // the whole row is in
         }
     }
 
@@ -516,7 +575,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                     fl = (fl & ~F_PHASE) | (coarse ? PH_MINSDF_C : PH_MINSDF);
                     P.s.flags[r] = fl;
                     qd = !coarse;
-                    qc = coarse;
+                    nc = coarse ? 4 : 0;
                     n_alg = 1;
                     dense_which = 1;
                     done = false;
@@ -570,7 +629,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         P.s.flags[r] = (fl & ~F_PHASE) | PH_DONE;
     }
 
-    append_queries(P, round, qs, qe, qt, qd, qc, (unsigned)r, dense_which, consumed, n_alg, n_ref, cmask);
+    append_queries(P, round, qs, qe, qt, qd, nc, cwin, (unsigned)r, dense_which, consumed, n_alg, n_ref, cmask);
 }
 
 // ---- SDF evaluation of one round's work list -------------------------------------------------
@@ -663,15 +722,15 @@ template <int ROWS>
 __device__ __forceinline__ void decode_tile_coarse(const Params &P, int64_t tile, int64_t total, float *raw, float **dest) {
     const int tid = threadIdx.x;
     if (tid >= ROWS) return;
-    const int ns = P.p.n_steps;
+    const int ns = P.p.n_steps, cw = coarse_window(ns);
     const int64_t q = tile * ROWS + tid;
     float *dst = nullptr;
     float px = 0.f, py = 0.f, pz = 0.f;
-    if (q < total) {
-        const int64_t di = q / ns;
-        const int i = (int)(q - di * ns);
-        const unsigned e = P.s.cdense[di];
-        const int64_t r = e >> 1;
+    const int64_t di = q / cw;
+    const unsigned e = q < total ? P.s.cdense[di] : 0u;
+    const int i = (int)(e >> 29) * cw + (int)(q - di * cw);
+    if (q < total && i < ns) {
+        const int64_t r = (e & 0x1FFFFFFFu) >> 1;
         const float t = dense_depth(P, r, i, e & 1);
         dst = &P.s.big[(size_t)r * ns + i];
         px = fadd(P.o[r * 3], fmul(t, P.d[r * 3]));
@@ -934,7 +993,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, 
     __shared__ LdsSx<FT, ROWS, DB> lds;
     __shared__ float raw[RMAX * 9];
     __shared__ float *dest[RMAX];
-    const int64_t total = (int64_t)P.counters[round * NCNT + 5] * P.p.n_steps;
+    const int64_t total = (int64_t)P.counters[round * NCNT + 5] * coarse_window(P.p.n_steps);
     const int64_t n_tiles = (total + ROWS - 1) / ROWS;
     if (blockIdx.x >= n_tiles) return;
     zero_lds_any(lds);      // the K-padded stream multiplies what follows a layer's own columns by zero weights: keep it finite
@@ -1582,7 +1641,7 @@ size_t carve(RayState &s, char *base, int64_t n, int ns, int cap) {
     s.singles = (unsigned *)take(sizeof(unsigned) * 2 * n);
     s.dense = (unsigned *)take(sizeof(unsigned) * n);
     s.tri = (unsigned *)take(sizeof(unsigned) * n);
-    s.cdense = (unsigned *)take(sizeof(unsigned) * n);
+    s.cdense = (unsigned *)take(sizeof(unsigned) * 4 * n);
     s.refine = (unsigned *)take(sizeof(unsigned) * (size_t)n * (cap > 0 ? cap : 0));
     return off;
 }
@@ -1902,6 +1961,11 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     P.cap = coarse_cap(h_params);
     P.chunk = 0;
     P.chunk_gate = 1e30f;
+    P.window = 0;
+    if (J.coarse && h_params->n_steps >= 16) {      // NEFII_SAMPLER_WINDOW=0: whole rows (A/B switch)
+        const char *e = getenv("NEFII_SAMPLER_WINDOW");
+        P.window = !(e && atoi(e) == 0);
+    }
     if (J.coarse) {       // NEFII_SAMPLER_CHUNK: leading samples of a bracket search evaluated exactly first (0: off; A/B switch)
         const char *e = getenv("NEFII_SAMPLER_CHUNK");
         const int c = e ? atoi(e) : 6;       // 4 / 6 / 8 / 16: 195.8 / 196.9 / 197.2 / 203.7 ms per step on config 3 (208.7 without), 2.82 / 2.79 / 2.79 / 2.81 on config 2
@@ -1982,7 +2046,7 @@ int launch_round(const TraceJob &J, int r, bool profile) {
         HIP_CHECK_LAUNCH();
         if (J.coarse) {
             const int ft = J.pipelined == 2 ? 2 : 4, rows = coarse_rows(ft);
-            const int64_t t = (J.P.n * (int64_t)J.P.p.n_steps + rows - 1) / rows;
+            const int64_t t = (J.P.n * (int64_t)(4 * coarse_window(J.P.p.n_steps)) + rows - 1) / rows;
             const dim3 grid((int)(t < J.eval_blocks_w ? t : J.eval_blocks_w));
             NEFII_COARSE_LAUNCH(eval_kernel16s, ft, grid, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();

@@ -451,7 +451,7 @@ def executed_evals(counters, n_steps, tri_nodes=None):
     """(split-precision evaluations, coarse single-pass evaluations) actually executed (tri_nodes: unused, the tracer
     counts its speculative bisection evaluations itself)."""
     c = counters.long()
-    return c[..., 0] + c[..., 1] * n_steps + c[..., 7] + c[..., 4], c[..., 5] * n_steps
+    return c[..., 0] + c[..., 1] * n_steps + c[..., 7] + c[..., 4], c[..., 5] * ((n_steps + 3) // 4)
 
 
 PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}

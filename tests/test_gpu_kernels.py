@@ -606,7 +606,7 @@ def test_tracer_coarse_pass_changes_no_decision(case):
             c = got[3].cpu().long()
             # the same algorithmic work; the dense searches entered are the same rays
             assert ops.algorithmic_evals(c, 100).sum() == ops.algorithmic_evals(cb, 100).sum()
-            assert c[:, 6].sum() == cb[:, 6].sum() and c[:, 5].sum() <= c[:, 6].sum()
+            assert c[:, 6].sum() == cb[:, 6].sum() and c[:, 5].sum() <= 4 * c[:, 6].sum()      # (column 5 counts quarter rows)
             split, coarse = ops.executed_evals(c, 100, 7)
             split0, _ = ops.executed_evals(cb, 100, 7)
             if tag == 'measured':

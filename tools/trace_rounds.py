@@ -39,11 +39,11 @@ for it in range(3):
     lib.nefii_trace_profile_enable(0)
 cnt = m.ray_tracer.last_counters.cpu().tolist()
 tot = 0.0
-print('round  singles  dense  tri(consumed)  refined  coarse rays | split-precision queries  coarse samples |   ms')
+print('round  singles  dense  tri(consumed)  refined  coarse quarter rows | split-precision queries  coarse samples |   ms')
 for r in range(n):
     c = cnt[r]
     split = c[0] + c[1] * 100 + c[7] + c[4]
-    coarse = c[5] * 100
+    coarse = c[5] * 25
     tot += buf[r]
     if split or coarse:
         print('%4d %8d %6d %5d(%6d) %8d %11d | %23d %15d | %6.3f' % (r, c[0], c[1], c[2], c[3], c[4], c[5], split, coarse,

@@ -41,11 +41,11 @@ ns = 100
 for shape, c in calls:
     c = c.long()
     tri_nodes = 7
-    print('tracer call on rays %s: singles %d, dense rays %d, bisection evaluations %d, refined %d, coarse rays %d (of them min-SDF: see '
+    print('tracer call on rays %s: singles %d, dense rays %d, bisection evaluations %d, refined %d, coarse quarter rows %d (of them min-SDF: see '
           'rounds), dense searches entered %d' % (tuple(shape), c[:, 0].sum(), c[:, 1].sum(), c[:, 7].sum(), c[:, 4].sum(), c[:, 5].sum(), c[:, 6].sum()))
     print('   split-precision evaluations %d, single-pass samples %d' % (c[:, 0].sum() + c[:, 1].sum() * ns + c[:, 7].sum() + c[:, 4].sum(),
-                                                                          c[:, 5].sum() * ns))
+                                                                          c[:, 5].sum() * ((ns + 3) // 4)))
     for r in range(c.shape[0]):
         if c[r].sum() > 0:
-            print('   round %2d: singles %7d dense %6d tri %6d refined %7d coarse rays %6d entered %6d' % (
+            print('   round %2d: singles %7d dense %6d tri %6d refined %7d coarse quarter rows %6d entered %6d' % (
                 r, c[r, 0], c[r, 1], c[r, 2], c[r, 4], c[r, 5], c[r, 6]))
