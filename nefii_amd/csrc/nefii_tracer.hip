@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                         qd = !go_coarse;
                         // inside the object mask the search ends at the first negative sample: the quarter rows go out one
                         // at a time (P.window; outside the mask the argmin over the whole row is the result)
-                        if (go_coarse && P.window && P.obj[r] != 0) {
+                        if (go_coarse && (P.window & 1) && P.obj[r] != 0) {
                             nc = 1;
                             fl |= 1 << F_WIN_SHIFT;
                         } else if (go_coarse) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             ph = PH_SAMPLER;
         } else {
             fl = (fl & ~F_PHASE) | PH_SAMPLER_C;
-            if (P.window) {             // (PH_SAMPLER_X rays lie inside the object mask)
+            if (P.window & 1) {         // (PH_SAMPLER_X rays lie inside the object mask)
                 nc = 1;
                 fl |= 1 << F_WIN_SHIFT;
             } else {
@@ -589,12 +589,44 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         ph = -1;
     }
 
+    if (valid && ph == PH_MINSDF_C && ((fl >> F_WIN_SHIFT) & F_WIN_MASK) != 0) {
+        // second stage of the two-stage refinement below: sample a (kept in the iteration bits) now holds its EXACT value
+        // v*.  The exact argmin m has exact_m <= v*, hence coarse_m <= v* + tau: only such samples are refined; every other
+        // one has exact > v* and keeps a coarse value > v* + tau - the exact stage's argmin over the mixed row is the
+        // reference's (first index of the exact minimum).
+        const int ns = tp.n_steps;
+        const float *v = P.s.big + (size_t)r * ns;
+        const int a = (fl >> F_IT_SHIFT) & F_IT_MASK;
+        const float lim = v[a] + P.tau;
+        int k = 0;
+        for (int i = 0; i < ns; ++i)
+            if (i != a && v[i] <= lim) {
+                cmask[i >> 5] |= 1u << (i & 31);
+                ++k;
+            }
+        fl &= ~((F_WIN_MASK << F_WIN_SHIFT) | (F_IT_MASK << F_IT_SHIFT));
+        if (k == 0) {
+            ph = PH_MINSDF;
+        } else {
+            if (k <= P.cap) n_ref = k; else qd = true;
+            dense_which = 1;
+            fl = (fl & ~F_PHASE) | PH_MINSDF;
+            P.s.flags[r] = fl;
+            ph = -1;
+        }
+    }
+
     if (valid && ph == PH_MINSDF_C) {
         // argmin over coarse values: every sample within 2 tau of the coarse minimum could be the exact one
         const int ns = tp.n_steps;
         const float *v = P.s.big + (size_t)r * ns;
         float vmin = v[0];
-        for (int i = 1; i < ns; ++i) vmin = v[i] < vmin ? v[i] : vmin;
+        int amin = 0;
+        for (int i = 1; i < ns; ++i)
+            if (v[i] < vmin) {
+                vmin = v[i];
+                amin = i;
+            }
         const float lim = vmin + 2.f * P.tau;
         int k = 0;
         for (int i = 0; i < ns; ++i)
@@ -604,6 +636,15 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             }
         if (k <= 1) {
             ph = PH_MINSDF;
+        } else if ((P.window & 2) && k >= 4 && ns <= 256) {
+            // two stages: the coarse argmin alone first - its exact value v* bounds the exact minimum from above, and the
+            // second stage's window (coarse <= v* + tau) is about half of this one's (coarse <= coarse min + 2 tau)
+            cmask[0] = cmask[1] = cmask[2] = cmask[3] = 0u;
+            cmask[amin >> 5] = 1u << (amin & 31);
+            n_ref = 1;
+            fl = (fl & ~((F_WIN_MASK << F_WIN_SHIFT) | (F_IT_MASK << F_IT_SHIFT))) | (1 << F_WIN_SHIFT) | (amin << F_IT_SHIFT);
+            P.s.flags[r] = fl;
+            ph = -1;
         } else {
             if (k <= P.cap) n_ref = k; else qd = true;
             dense_which = 1;
@@ -687,7 +728,7 @@ __device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const
             r = e >> 7;
             const int i = e & 127;
             const int ph = P.s.flags[r] & F_PHASE;
-            t = dense_depth(P, r, i, ph == PH_MINSDF);
+            t = dense_depth(P, r, i, ph == PH_MINSDF || ph == PH_MINSDF_C);    // (_C: the first of the two refinement stages)
             dst = &P.s.big[(size_t)r * ns + i];
             if (old && ph != PH_SAMPLER_X) coarse_v = *dst;     // (the leading samples of a bracket search have no coarse value)
         } else if (q >= W.n_sd) {
@@ -1963,8 +2004,8 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     P.chunk_gate = 1e30f;
     P.window = 0;
     if (J.coarse && h_params->n_steps >= 16) {      // NEFII_SAMPLER_WINDOW=0: whole rows (A/B switch)
-        const char *e = getenv("NEFII_SAMPLER_WINDOW");
-        P.window = !(e && atoi(e) == 0);
+        const char *e = getenv("NEFII_SAMPLER_WINDOW");      // bit 0: quarter rows, bit 1: two-stage min-SDF refinement
+        P.window = e ? (atoi(e) & 3) : 3;
     }
     if (J.coarse) {       // NEFII_SAMPLER_CHUNK: leading samples of a bracket search evaluated exactly first (0: off; A/B switch)
         const char *e = getenv("NEFII_SAMPLER_CHUNK");
