@@ -576,13 +576,17 @@ def _trace_batch(n, seed, spread=0.45):
     return o, d, om, torch.rand(100, generator=g)
 
 
+@pytest.mark.parametrize('window', ['3', '0'])
 @pytest.mark.parametrize('case', ['physg512-bumpy', 'physg512-smooth', 'conf512-bowl', 'neus256-bowl', 'neus256-bumpy'])
-def test_tracer_coarse_pass_changes_no_decision(case):
+def test_tracer_coarse_pass_changes_no_decision(case, window, monkeypatch):
     """nefii_tracer_params.coarse_tau: the 100 samples of the bracket search and of the min-SDF search go through the
     single-pass fp16 evaluator first and only the samples within the error bound of a decision are re-evaluated in split
     precision.  Every decision is then the split evaluator's: points, hit mask and depths are BIT-IDENTICAL to the trace
     without the coarse pass - for the measured bound, for a cap of one refined sample per ray (every ray with two
-    candidates falls back to 100 split-precision samples) and for a bound so loose that every sample is a candidate."""
+    candidates falls back to 100 split-precision samples) and for a bound so loose that every sample is a candidate.
+    `window` = NEFII_SAMPLER_WINDOW: '3' forces the bracket search's quarter rows (by default only batches of >= 32768 rays
+    take them) and the two-stage min-SDF refinement, '0' is the whole-row / one-stage form."""
+    monkeypatch.setenv('NEFII_SAMPLER_WINDOW', window)
     name, geo = case.split('-')
     mc = syn.model_conf({'physg512': 'physg', 'conf512': 'conf', 'neus256': 'neus'}[name])
     sd = syn.make_state_dict(mc, seed=2, bumpy={'bumpy': 0.004, 'smooth': 0.0, 'bowl': 0.0}[geo],
