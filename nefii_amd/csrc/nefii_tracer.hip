@@ -1928,9 +1928,10 @@ extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     // initial eval + iters*(step + back-offs) -> sampler -> bisection (L levels per round) -> min-SDF -> bookkeeping
     // with the coarse pass each of the two dense searches takes one round more (coarse samples -> refined samples)
     const int L = p->bisect_levels >= 1 && p->bisect_levels <= 5 ? p->bisect_levels : 3;
-    // ... and the bracket search one more for the rays whose leading samples (evaluated exactly first) hold no negative one
+    // ... and the bracket search one more for the rays whose leading samples (evaluated exactly first) hold no negative one,
+    // up to three more for the quarter rows of its coarse pass, the min-SDF search one more for its two-stage refinement
     return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + (p->n_rootfind_steps + L - 1) / L + 1 + 2 +
-           (p->coarse_tau > 0.f ? 3 : 0);
+           (p->coarse_tau > 0.f ? 3 + 3 + 1 : 0);
 }
 
 extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *p) {

@@ -47,7 +47,7 @@ def test_host_side_argument_checks_need_no_gpu():
     assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2
     w0 = lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p))
     p.coarse_tau = 2e-3          # coarse pass: one more round per dense search, a refine list of coarse_cap (default 64) entries per ray
-    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2 + 3
+    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2 + 7      # coarse: + chunk, refine x 2, quarter rows x 3, two-stage
     assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) >= w0 + 4096 * 64 * 4
     p.coarse_tau = 0.0
     assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) > 4096 * 100 * 4
