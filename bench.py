@@ -72,10 +72,12 @@ def host_info():
         return 'unknown', os.cpu_count() or 1, os.cpu_count() or 1
 
 
-def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None):
+def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None, parity_pixels=128):
     """Oracle training step on the host cores, bounded sample of the workload (rank 0 only).  Also returns the
-    parity of the HIP path against the oracle on that sample (identical rays and weights): relative L2 and PSNR
-    (evaluate.py:36-44: 20 log10(1/sqrt(MSE))) of rendered RGB and albedo over the hit pixels."""
+    parity of the HIP path against the oracle (identical rays and weights): relative L2 and PSNR (evaluate.py:36-44:
+    20 log10(1/sqrt(MSE))) of rendered RGB and albedo over the hit pixels - on its OWN sample of `parity_pixels` pixels
+    (the first pixels of the workload's batch), forward only on both sides: the timing sample is kept small for the
+    clock's sake (32 pixels of config 3 hold a dozen hit pixels - too few to quote a parity figure on)."""
     from nefii_amd import synthetic as syn
     from oracle import renderer as orr
     w = dict(syn.WORKLOADS[workload])
@@ -95,7 +97,7 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None):
             v.requires_grad_(True)
         opt = torch.optim.Adam(params, lr=5e-4)
         R = orr.Renderer(sd, mc, training=True)
-        best, first = None, None
+        best = None
         for i in range(n_warm + n_steps):
             t0 = time.perf_counter()
             out = R.forward(inp)
@@ -105,20 +107,15 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None):
                 lo['loss'].backward()
             opt.step()
             dt = time.perf_counter() - t0
-            if first is None:
-                first = {k: out[k].detach().clone() for k in ('sg_rgb_values', 'sg_diffuse_albedo_values',
-                                                              'network_object_mask')}
-                first['uniforms'], first['steps'] = out.get('_uniforms'), out.get('_minsdf_steps')
-                first['steps2'] = out.get('_minsdf_steps2')
             if i >= n_warm:
                 best = dt if best is None else min(best, dt)
-        return n_rays / best, first
+        return n_rays / best
 
     # these small GEMMs stop scaling early: on the 2x64-core EPYC 9575F GPU host 16 threads was the measured
     # optimum (1 thread 253, 8: 848, 16: 1029, 32: 853, 64: 396, 128: 151 rays/s; tools/cpu_threads_probe.py)
     threads = min(16, phys_cores)
-    value, ref = run(threads, steps, warmup)
-    value1, _ = run(1, 1, 1)
+    value = run(threads, steps, warmup)
+    value1 = run(1, 1, 1)
     res = {'value': value, 'unit': 'rays/s', 'cores': threads, 'kind': 'port',
            'value_1_thread': value1, 'host_cpu': cpu_model, 'host_cores': phys_cores, 'host_logical_cpus': logical,
            'sample': '%d of the workload\'s pixels (%d primary rays), best of %d steps after %d warm-ups, %d torch threads (the '
@@ -129,6 +126,13 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None):
     if device is not None:
         from nefii_amd import conf
         from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+        torch.set_num_threads(threads)
+        pp = max(sample_pixels, parity_pixels) // 4 * 4
+        inp, _ = syn.make_inputs(pp, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
+        with torch.no_grad():
+            out = orr.Renderer(syn.make_state_dict(mc, seed=0, scene=w.get('scene')), mc, training=True).forward(inp)
+        ref = {k: out[k].detach().clone() for k in ('sg_rgb_values', 'sg_diffuse_albedo_values', 'network_object_mask')}
+        ref['uniforms'], ref['steps'], ref['steps2'] = out.get('_uniforms'), out.get('_minsdf_steps'), out.get('_minsdf_steps2')
         m = IDRNetwork(conf.from_dict(mc))
         m.load_state_dict(syn.make_state_dict(mc, seed=0, scene=w.get('scene')), strict=True)
         m = m.to(device)
@@ -150,6 +154,9 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None):
             parity[name + '_rel_l2'] = ((a - b).norm() / (b.norm() + 1e-12)).item()
             parity[name + '_psnr_db'] = float('inf') if mse == 0 else 20.0 * math.log10(1.0 / mse ** 0.5)
         parity['tolerance_rel_l2'] = 1e-3
+        parity['sample'] = 'the first %d pixels of the workload (%d primary rays), forward only, the oracle\'s draws replayed' % (
+            pp, pp * R_)
+        parity['trace_tier'] = bool(m.ray_tracer.tier_for(pp * R_))
     return res, parity
 
 
@@ -164,6 +171,11 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     from nefii_amd.training.step import TrainStep
 
     w = dict(syn.WORKLOADS[name])
+    # NEFII_BENCH_PIXELS (tests only: the 8-rank launch on a one-GPU box): every training workload at this many pixels instead
+    # of its own - the line says so (config.num_pixels_override) and is no measurement of the BASELINE config
+    px_override = int(os.environ.get('NEFII_BENCH_PIXELS', '0'))
+    if px_override > 0:
+        w['num_pixels'] = px_override
     mc = syn.model_conf(w['model'])
     sd = syn.make_state_dict(mc, seed=0, scene=w.get('scene'))
     lc = syn.loss_conf(w['model'])
@@ -291,7 +303,8 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     queries = int(ops.algorithmic_evals(cnt, n_steps).sum().item())
     ex_split, ex_coarse = ops.executed_evals(cnt, n_steps)
     executed, executed_coarse = int(ex_split.sum().item()), int(ex_coarse.sum().item())
-    launches = int((cnt[:, [0, 1, 2, 4, 5]].sum(dim=1) > 0).sum().item())
+    launches = int((cnt[:, [0, 1, 2, 4, 5, 9]].sum(dim=1) > 0).sum().item())
+    tier_queries, tier_repeats = int(cnt[:, 9].sum().item()), int(cnt[:, 10].sum().item())
     f_eval = mlp_flops(model.implicit_network.specs)
     achieved = queries * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
     ray_hit = model.last_ray_hit
@@ -329,6 +342,9 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     # SURVEY 8(d)-strict on the same kernel time: only the evaluations 8(d) counts (no min-SDF search)
     frac_8d = evals_live * f_eval / (eval_ms.value * 1e-3) / (peak * 1e12) if eval_ms.value > 0 else 0.0
     issued = (executed * (3 if split else 1) + executed_coarse) * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
+    # what the kernels EXECUTED, one F_sdf per evaluation whatever its arithmetic (frac credits the reference's count: samples
+    # the windowed searches never evaluated are an algorithmic saving, not kernel efficiency)
+    frac_executed = (executed + executed_coarse) * f_eval / (eval_ms.value * 1e-3) / (peak * 1e12) if eval_ms.value > 0 else 0.0
     # HBM traffic of the same kernels: NOT measured by this run - read from the rocprofv3 PMC passes of this command
     # committed under profiles/ (tools/profile_round.sh; separate FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied
     # by tools/pmc_traffic.py), and only quoted for the workload / kernels it was measured on
@@ -347,6 +363,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                 'kernel': kname + ' (fused SDF MLP over the tracer work list)',
                 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
                 'frac_kernel': achieved / peak, 'frac_step': frac_step, 'frac_chip': frac_chip, 'frac_8d': frac_8d,
+                'frac_executed': frac_executed,
                 'issued_tflops': issued,
                 'sustained_peak': sustained,
                 'board_power': meter.summary() if meter is not None else None,
@@ -356,7 +373,8 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                                     'events, an extra un-timed step); frac_chip: the same flops / ms_per_step of the timed '
                                     'steps (traces overlapped); frac_step: SURVEY 8(d) A x rays/s / peak (whole step, dead '
                                     'min-SDF search excluded); frac_8d: evaluations WITHOUT the min-SDF search / the same '
-                                    'evaluator launch time as frac_kernel; issued_tflops: MFMA flops the evaluators issue '
+                                    'evaluator launch time as frac_kernel; frac_executed: the evaluations the kernels actually '
+                                    'executed (split precision + single pass, one F_sdf each) / that time; issued_tflops: MFMA flops the evaluators issue '
                                     '(3 per split-precision product, refined samples and speculative bisection nodes '
                                     'included) / that time; sustained_peak: a bare fp16 MFMA loop on random operands, '
                                     'measured in this run on this device (the part is power-limited: 2.5 PFLOP/s spec)',
@@ -368,6 +386,10 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                 'flops_per_sdf_eval': f_eval, 'sdf_evals_per_step': queries,
                 'sdf_evals_executed_split_precision': executed, 'sdf_evals_executed_single_pass': executed_coarse,
                 'coarse_tau': coarse_tau,
+                # tiered sphere tracing (nefii_tracer_params.trace_tier): sphere-tracing queries of this step that ran on the
+                # single-pass evaluator, and how many of them had to be repeated in split precision
+                'trace_tier': bool(model.ray_tracer.tier_for(rays_per_rank)),
+                'tier_queries_single_pass': tier_queries, 'tier_queries_repeated': tier_repeats,
                 # the online audit of that bound (every refined sample is evaluated both ways): the largest |single pass -
                 # split| the tracer saw in this run, and what ImplicitNetwork.note_coarse_audit did about it (nothing, if empty)
                 'coarse_audit_max': float(model.implicit_network.coarse_audit_max),
@@ -389,8 +411,9 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
         'ms_per_step': ms_per_step,
         'ms_per_step_repeats': [e / steps * 1e3 for e in reps],
         'ms_per_step_without_dead_min_sdf_search': ms_skip,
-        # the runner's default schedule under frozen geometry (TrainStep.min_sdf_every = log_freq = 50: the search runs on
-        # the iterations whose loss is read, idr_train.py:784): 49 steps without the search and one with it, both measured here
+        # the runner's OPT-IN schedule under frozen geometry (min_sdf_every = 50: the search runs on the iterations whose loss
+        # line is printed, idr_train.py:784; the losses of the other iterations are then not the reference's): 49 steps
+        # without the search and one with it, both measured here
         'ms_per_step_min_sdf_on_reporting_iterations': None if ms_skip is None else (49.0 * ms_skip + ms_per_step) / 50.0,
         'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
         'dtype': 'f16x3' if split else 'f32', 'data': 'synthetic',
@@ -405,6 +428,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                                   'indirect OFF (closed-form SG)' if not indirect else 'MC direct + near-field indirect ON'),
                    'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
                    'step_graph': bool(use_graph),
+                   'num_pixels_override': px_override or None,
                    'rank_param_spread': param_spread,
                    # steps cancelled by TrainStep's NaN guard: in warm-up + timed repetitions / in the whole run.  Any
                    # cancelled step makes the line INVALID (main() flags it and exits non-zero)
@@ -562,10 +586,15 @@ def measure_sustained(lib):
         if any(x is None for x in vals):
             return None
         out[tag] = sorted(vals)[len(vals) // 2]
+    ms8, fl8 = ctypes.c_float(), ctypes.c_double()
+    if lib.nefii_mfma_sustained_probe_chains(125000, 8, ctypes.byref(ms8), ctypes.byref(fl8), None) == 0 and ms8.value > 0:
+        out['value_8_chains'] = fl8.value / (ms8.value * 1e-3) / 1e12
     out['unit'] = 'TFLOP/s'
     out['what'] = ('v_mfma_f32_16x16x32_f16 only, random operands, 4 accumulator chains per wave, one wave per SIMD, 256 '
                    'workgroups; value = a 25 ms launch (behind a 6 ms warm-up launch); burst_* = the median of shorter launches right after it, '
-                   'each behind a quarter-length warm-up launch')
+                   'each behind a quarter-length warm-up launch.  The 4-chain loop issues 8 MFMAs in 148 cycles, not the 128 of a '
+                   'free-running pipe (profiles/r04/slot_probe.txt); value_8_chains is the same 25 ms on 8 independent chains '
+                   '(128 cycles per 8): on a power-limited part the denser loop mostly clocks lower - both are in the line')
     return out
 
 

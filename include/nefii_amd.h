@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 11
+#define NEFII_ABI_VERSION 12
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -221,8 +221,21 @@ typedef struct nefii_tracer_params {
     int32_t small_round;     /* rounds of at most this many split-precision queries run on 32-query tiles (more CUs, shorter
                                 round; 1.5x the chip time per query); 0: 8192.  Traces that overlap other work pass a
                                 smaller value. */
+    int32_t trace_tier;      /* ABI 12 - tiered sphere tracing (needs coarse_tau > 0; ignored without it).  1: a sphere-tracing
+                                evaluation (ray_tracing.py:128-134,164-168,182-183) whose front is still far from the surface
+                                - the step that led to the query exceeds tier_gate * coarse_tau; the first evaluation on the
+                                bounding sphere always - runs on the single-pass evaluator, and its value v16 is TAKEN AS THE
+                                VALUE when |v16| > max(tier_kappa * coarse_tau, coarse_tau + 2 sdf_threshold): both decisions
+                                the recurrence makes with it (v <= sdf_threshold :140-148, v < 0 :170-171,186-187) are then
+                                the split evaluator's, but the front advances by v16 instead of v.  Inside that band the
+                                query is repeated in split precision first.  UNLIKE the coarse pass of the two dense searches
+                                this changes values, not only schedules: fronts differ by up to coarse_tau per step on the
+                                way and end where the exact value is <= sdf_threshold as before (depths within ~sdf_threshold
+                                / cos of the split-precision trace; measured: DESIGN.md, "tiered sphere tracing").  0: off. */
+    float tier_kappa;        /* <= 0: 2 */
+    float tier_gate;         /* <= 0: 4 */
 } nefii_tracer_params;
-#define NEFII_TRACE_COUNTERS 9   /* int32 counters per round, see nefii_trace_rays */
+#define NEFII_TRACE_COUNTERS 11  /* int32 counters per round, see nefii_trace_rays */
 
 /* The pipelined evaluator behind nefii_trace_rays (precision 2) and nefii_sdf_eval reads the hidden layers' fragments as
  * ONE stream per wave, 4 KiB per 16-deep unit of the layer sequence: [8 waves][units][4 fragments][64 lanes][8 halves];
@@ -276,9 +289,11 @@ int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
  * [r][6] rays entering a dense search (the reference evaluates n_steps samples for each), [r][7] = (2^levels - 1)*[2],
  * the speculative bisection evaluations executed, [r][8] (the bits of a float >= 0) the largest |coarse - split| among the
  * coarse-pass samples this round re-evaluated in split precision: the online audit of coarse_tau - every refined sample
- * is evaluated both ways anyway; a value above coarse_tau means the caller's bound does not hold for this net.
- * Algorithmic evaluations (what the reference's recurrences need) = [0] + n_steps*[6] + [3]; executed in split
- * precision = [0] + n_steps*[1] + [7] + [4]; executed in the coarse evaluator = ceil(n_steps / 4)*[5]. */
+ * is evaluated both ways anyway; a value above coarse_tau means the caller's bound does not hold for this net;
+ * [r][9] (ABI 12, trace_tier) sphere-tracing queries in the single-pass evaluator, [r][10] single queries of [r][0] that
+ * repeat such a query in split precision (they take part in the audit of [r][8]).
+ * Algorithmic evaluations (what the reference's recurrences need) = [0] + [9] - [10] + n_steps*[6] + [3]; executed in split
+ * precision = [0] + n_steps*[1] + [7] + [4]; executed in the coarse evaluator = ceil(n_steps / 4)*[5] + [9]. */
 int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
                      const float *origins, const float *dirs, const uint8_t *object_mask, int64_t n_rays,
                      const float *lin_steps, const float *minsdf_steps,
@@ -407,6 +422,11 @@ int nefii_gather_rows(const nefii_row_block *h_blocks, int n_blocks, const int64
  * ~1.5 on random ones: profiles/r04/slot_probe.txt), so bench.py quotes roofline.sustained_peak beside the 2.5 PFLOP/s
  * spec peak the roofline fraction is priced against. */
 int nefii_mfma_sustained_probe(int groups, float *h_ms, double *h_flops, void *stream);
+/* The same loop on `chains` = 4 or 8 independent accumulator chains (a group is then 2 x chains MFMAs).  With 4 chains the
+ * loop takes 148 cycles per 8 MFMAs against 128 for a free-running pipe (each accumulator is wanted again after 64 cycles of
+ * issue); 8 chains leave every dependency 128 cycles - bench.py quotes both, so that the sustained figure is not an artefact
+ * of the probe's own issue rate.  (ABI 12) */
+int nefii_mfma_sustained_probe_chains(int groups, int chains, float *h_ms, double *h_flops, void *stream);
 
 #ifdef __cplusplus
 }

@@ -14,8 +14,8 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 11
-TRACE_COUNTERS = 9          # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
+ABI_VERSION = 12
+TRACE_COUNTERS = 11         # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
 HEAD_NONE, HEAD_TANH01, HEAD_POW2, HEAD_SIGMOID, HEAD_RELU, HEAD_ABS, HEAD_RELU_INIT = range(7)
@@ -41,7 +41,8 @@ class TracerParams(ctypes.Structure):
                 ('sphere_tracing_iters', ctypes.c_int32), ('n_steps', ctypes.c_int32),
                 ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32), ('bisect_levels', ctypes.c_int32),
                 ('precision', ctypes.c_int32), ('coarse_tau', ctypes.c_float), ('coarse_cap', ctypes.c_int32),
-                ('minsdf_group', ctypes.c_int32), ('small_round', ctypes.c_int32)]
+                ('minsdf_group', ctypes.c_int32), ('small_round', ctypes.c_int32), ('trace_tier', ctypes.c_int32),
+                ('tier_kappa', ctypes.c_float), ('tier_gate', ctypes.c_float)]
 
 
 class PackSource(ctypes.Structure):
@@ -123,6 +124,7 @@ SIGNATURES = {
     'nefii_mc_shade_forward': (I, [P] * 11 + [I64, P, P, P, P]),
     'nefii_mc_shade_backward': (I, [P] * 11 + [I64] + [P] * 9),
     'nefii_mfma_sustained_probe': (I, [I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), P]),
+    'nefii_mfma_sustained_probe_chains': (I, [I, I, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), P]),
 }
 
 _lib = None

@@ -47,6 +47,7 @@ struct RayState {            // SoA views into the workspace
     unsigned *tri;           // [n]   rays in bisection: 7 speculative queries each (3 levels of the bisection tree)
     unsigned *cdense;        // [4n]  (window << 29 | ray << 1 | which): quarter rows (CW samples of a ray's n_steps) for the coarse evaluator
     unsigned *refine;        // [n * cap]  (ray << 7 | sample): coarse samples to re-evaluate in split precision
+    unsigned *csingles;      // [2n]  (ray << 2 | kind): sphere-tracing queries for the coarse evaluator (tiered sphere tracing)
 };
 
 // flags layout
@@ -58,6 +59,10 @@ constexpr int F_IT_SHIFT = 12, F_IT_MASK = 0xFF;     // sphere-tracing iteration
 constexpr int F_K_SHIFT = 20, F_K_MASK = 0xF;        // back-off count
 // PH_SAMPLER_C only: 0 = the whole row is with the coarse evaluator; w = 1..4: windowed search, the first w quarter rows are
 constexpr int F_WIN_SHIFT = 24, F_WIN_MASK = 0x7;
+// Tiered sphere tracing (nefii_tracer_params.trace_tier), PH_TRACE only.  F_CRS_x: the pending result of that end comes from
+// the single-pass evaluator.  F_AUD_x: that end's query is being REPEATED in split precision this round and res_x still
+// holds the coarse value (the split evaluator compares the two: the online audit of coarse_tau).
+constexpr int F_CRS_S = 1 << 27, F_CRS_E = 1 << 28, F_AUD_S = 1 << 29, F_AUD_E = 1 << 30;
 // samples per quarter row (window) of a coarse row
 __host__ __device__ __forceinline__ int coarse_window(int n_steps) { return (n_steps + 3) >> 2; }
 
@@ -80,6 +85,8 @@ struct Params {
     int chunk;               //              leading samples of a bracket search evaluated exactly first (0: off)
     float chunk_gate;        //              ... for rays whose front SDF is below chunk_gate x the chunk's reach
     int window;              //              bracket searches inside the object mask take their coarse samples a quarter row at a time
+    float tier_band;         // tiered sphere tracing: a coarse value v16 decides (v > thr, sign) when |v16| > tier_band; 0: off
+    float tier_gate;         //              a step / back-off query goes to the coarse evaluator when the step that led to it is > tier_gate
     RayState s;
 };
 
@@ -94,17 +101,20 @@ __device__ __forceinline__ float minsdf_step(const Params &P, int64_t r, int i) 
 // each thread contributes up to 2 single queries, one dense ray (split precision or coarse), one bisecting ray and
 // n_ref coarse samples to refine (bit set `cmask`).
 // nc / cwin: quarter rows cwin .. cwin + nc - 1 of the ray's samples for the coarse evaluator (4 from 0: the whole row).
+// qcs / qce: the ray's start / end query for the COARSE evaluator (tiered sphere tracing); n_rep: split-precision singles of
+// this ray that repeat a coarse one
 __device__ __forceinline__ void append_queries(const Params &P, int round, bool qs, bool qe, bool qt, bool qd, int nc, int cwin,
                                                unsigned ray, unsigned dense_which, int consumed, int n_alg, int n_ref,
-                                               const unsigned (&cmask)[4]) {
-    __shared__ int wtot[7][4];
-    __shared__ int base[5];
+                                               const unsigned (&cmask)[4], bool qcs = false, bool qce = false, int n_rep = 0) {
+    __shared__ int wtot[9][4];
+    __shared__ int base[6];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long bs = __ballot(qs), be = __ballot(qe), bt = __ballot(qt), bd = __ballot(qd);
+    const unsigned long long bcs = __ballot(qcs), bce = __ballot(qce);
     const unsigned long long lt = (1ull << lane) - 1ull;
-    int cons = consumed, alg = n_alg;
+    int cons = consumed, alg = n_alg, rep = n_rep;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cons += __shfl_xor(cons, o), alg += __shfl_xor(alg, o);
+    for (int o = 32; o > 0; o >>= 1) cons += __shfl_xor(cons, o), alg += __shfl_xor(alg, o), rep += __shfl_xor(rep, o);
     int incl = n_ref;               // inclusive prefix sum of the refine counts over the wave
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -127,11 +137,13 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
         wtot[4][wave] = wref;
         wtot[5][wave] = wcoarse;
         wtot[6][wave] = alg;
+        wtot[7][wave] = __popcll(bcs) + __popcll(bce);
+        wtot[8][wave] = rep;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int t[7];
-        for (int i = 0; i < 7; ++i) t[i] = wtot[i][0] + wtot[i][1] + wtot[i][2] + wtot[i][3];
+        int t[9];
+        for (int i = 0; i < 9; ++i) t[i] = wtot[i][0] + wtot[i][1] + wtot[i][2] + wtot[i][3];
         int *cnt = P.counters + round * NCNT;
         for (int i = 0; i < 3; ++i) base[i] = t[i] ? atomicAdd(&cnt[i], t[i]) : 0;
         if (t[3]) atomicAdd(&cnt[3], t[3]);
@@ -139,18 +151,23 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
         base[4] = t[5] ? atomicAdd(&cnt[5], t[5]) : 0;
         if (t[6]) atomicAdd(&cnt[6], t[6]);
         if (t[2]) atomicAdd(&cnt[7], t[2] * P.tri_nodes);      // speculative bisection evaluations executed
+        base[5] = t[7] ? atomicAdd(&cnt[9], t[7]) : 0;
+        if (t[8]) atomicAdd(&cnt[10], t[8]);
     }
     __syncthreads();
-    int off_s = base[0], off_d = base[1], off_t = base[2], off_r = base[3], off_c = base[4];
+    int off_s = base[0], off_d = base[1], off_t = base[2], off_r = base[3], off_c = base[4], off_cs = base[5];
     for (int w = 0; w < wave; ++w) {
         off_s += wtot[0][w];
         off_d += wtot[1][w];
         off_t += wtot[2][w];
         off_r += wtot[4][w];
         off_c += wtot[5][w];
+        off_cs += wtot[7][w];
     }
     if (qs) P.s.singles[off_s + __popcll(bs & lt)] = (ray << 2) | Q_START;
     if (qe) P.s.singles[off_s + __popcll(bs) + __popcll(be & lt)] = (ray << 2) | Q_END;
+    if (qcs) P.s.csingles[off_cs + __popcll(bcs & lt)] = (ray << 2) | Q_START;
+    if (qce) P.s.csingles[off_cs + __popcll(bcs) + __popcll(bce & lt)] = (ray << 2) | Q_END;
     if (qd) P.s.dense[off_d + __popcll(bd & lt)] = (ray << 1) | dense_which;
     if (qt) P.s.tri[off_t + __popcll(bt & lt)] = ray;
     for (int k = 0; k < nc; ++k)
@@ -206,6 +223,9 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
     int n_alg = 0;             // dense searches entered this round (the reference evaluates n_steps samples for each)
     int n_ref = 0;             // coarse samples of this ray to re-evaluate in split precision (bits of cmask)
     unsigned cmask[4] = {0u, 0u, 0u, 0u};
+    bool cs = false, ce = false;       // tiered sphere tracing: qs / qe go to the coarse evaluator
+    int n_rep = 0;                     //                         split-precision singles that repeat a coarse one
+    const bool tier = P.tier_band > 0.f;
     const bool coarse = P.tau > 0.f;
     const nefii_tracer_params &tp = P.p;
     const float thr = tp.sdf_threshold;
@@ -240,6 +260,11 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         if (sph) {
             fl |= F_SPH | F_LIVE_S | F_LIVE_E | F_PEND_S | F_PEND_E;
             qs = qe = true;
+            // tiered sphere tracing: the first evaluations lie on the bounding sphere, far from the surface - unless the
+            // ray starts inside it (secondary rays: t0 clamped to 0.01 off the surface they leave)
+            cs = tier && t0 > 0.01f;
+            ce = tier && t1 > 0.01f;
+            fl |= (cs ? F_CRS_S : 0) | (ce ? F_CRS_E : 0);
         }
         ph = PH_TRACE;
         if (sph) {
@@ -256,7 +281,22 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         int it = (fl >> F_IT_SHIFT) & F_IT_MASK, k = (fl >> F_K_SHIFT) & F_K_MASK;
         if (fl & F_PEND_S) nxt_s = P.s.res_s[r];
         if (fl & F_PEND_E) nxt_e = P.s.res_e[r];
+        // Tiered sphere tracing (nefii_tracer_params.trace_tier).  What the recurrence decides with an SDF value v is
+        // `v <= thr` (the front has arrived) and `v < 0` (back off); a value v16 of the single-pass evaluator, |v16 - v| <
+        // tau, decides both the same way when |v16| > tier_band (>= tau + thr) - it is then taken AS the value: the front
+        // advances by v16 instead of v (not bit-identical to the split-precision trace: DESIGN, "tiered sphere tracing").
+        // Inside the band the same query is repeated in split precision before anything moves.
+        fl &= ~(F_AUD_S | F_AUD_E);
+        const bool rep_s = (fl & F_PEND_S) && (fl & F_CRS_S) && !(fabsf(nxt_s) > P.tier_band);
+        const bool rep_e = (fl & F_PEND_E) && (fl & F_CRS_E) && !(fabsf(nxt_e) > P.tier_band);
         bool wait = false;
+        if (rep_s || rep_e) {
+            if (rep_s) qs = true, fl = (fl & ~F_CRS_S) | F_AUD_S, ++n_rep;
+            if (rep_e) qe = true, fl = (fl & ~F_CRS_E) | F_AUD_E, ++n_rep;
+            P.s.flags[r] = fl;         // everything else as it is: the other end's result stays in res_x and is read again
+            ph = -1;
+        } else {
+        fl &= ~(F_CRS_S | F_CRS_E);
         if (fl & F_STEPPED) {
             // back-off line search for ends that crossed the surface (ray_tracing.py:170-188)
             const bool bad_s = nxt_s < 0.f, bad_e = nxt_e < 0.f;
@@ -266,12 +306,14 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                 if (bad_s) {
                     t_s = fsub(t_s, fmul(back, cur_s));
                     qs = true;
-                    fl |= F_PEND_S;
+                    cs = tier && back * cur_s > P.tier_gate;
+                    fl |= F_PEND_S | (cs ? F_CRS_S : 0);
                 }
                 if (bad_e) {
                     t_e = fadd(t_e, fmul(back, cur_e));
                     qe = true;
-                    fl |= F_PEND_E;
+                    ce = tier && back * cur_e > P.tier_gate;
+                    fl |= F_PEND_E | (ce ? F_CRS_E : 0);
                 }
                 ++k;
                 wait = true;
@@ -291,7 +333,9 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             if (it == tp.sphere_tracing_iters || !(live_s || live_e)) {
                 // tracing finished for this ray (ray_tracing.py:43-64)
                 const bool hit = t_s < t_e;
-                fl = (fl & F_SPH) | (hit ? F_HIT : 0) | (live_s ? F_SAMP : 0);
+                // (the K field is free from here on: it keeps the iterations this ray's sphere tracing took - read by
+                // tools/tier_parity.py from the workspace, by nothing else)
+                fl = (fl & F_SPH) | (hit ? F_HIT : 0) | (live_s ? F_SAMP : 0) | ((it & F_K_MASK) << F_K_SHIFT);
                 P.s.t_s[r] = t_s;
                 P.s.t_e[r] = t_e;
                 if (live_s) {
@@ -340,11 +384,13 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                 fl &= ~(F_PEND_S | F_PEND_E);
                 if (live_s) {
                     qs = true;
-                    fl |= F_PEND_S;
+                    cs = tier && cur_s > P.tier_gate;     // the step just taken ~ the distance the front was from the surface
+                    fl |= F_PEND_S | (cs ? F_CRS_S : 0);
                 }
                 if (live_e) {
                     qe = true;
-                    fl |= F_PEND_E;
+                    ce = tier && cur_e > P.tier_gate;
+                    fl |= F_PEND_E | (ce ? F_CRS_E : 0);
                 }
                 fl |= F_STEPPED;
                 wait = true;
@@ -362,6 +408,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             P.s.flags[r] = fl;
             ph = -1;
         }
+        }       // (not repeating a coarse query)
     }
 
     if (valid && ph == PH_SAMPLER_X) {
@@ -670,7 +717,8 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         P.s.flags[r] = (fl & ~F_PHASE) | PH_DONE;
     }
 
-    append_queries(P, round, qs, qe, qt, qd, nc, cwin, (unsigned)r, dense_which, consumed, n_alg, n_ref, cmask);
+    append_queries(P, round, qs && !cs, qe && !ce, qt, qd, nc, cwin, (unsigned)r, dense_which, consumed, n_alg, n_ref, cmask,
+                   qs && cs, qe && ce, n_rep);
 }
 
 // ---- SDF evaluation of one round's work list -------------------------------------------------
@@ -723,6 +771,8 @@ __device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const
             const int kind = e & 3;
             t = kind == Q_START ? P.s.t_s[r] : (kind == Q_END ? P.s.t_e[r] : P.s.mid[r]);
             dst = kind == Q_END ? &P.s.res_e[r] : &P.s.res_s[r];
+            // a sphere-tracing query repeated in split precision: res_x still holds its coarse value
+            if (old && P.tier_band > 0.f && (P.s.flags[r] & (kind == Q_END ? F_AUD_E : F_AUD_S))) coarse_v = *dst;
         } else if (q >= W.n_sdt) {
             const unsigned e = P.s.refine[q - W.n_sdt];
             r = e >> 7;
@@ -759,8 +809,10 @@ __device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const
 }
 
 // the same for the coarse evaluator's list: rays x n_steps samples
+// queries [0, n_rows): the quarter rows' samples; [n_rows, total): the sphere-tracing queries of the tier (csingles)
 template <int ROWS>
-__device__ __forceinline__ void decode_tile_coarse(const Params &P, int64_t tile, int64_t total, float *raw, float **dest) {
+__device__ __forceinline__ void decode_tile_coarse(const Params &P, int64_t tile, int64_t n_rows, int64_t total, float *raw,
+                                                   float **dest) {
     const int tid = threadIdx.x;
     if (tid >= ROWS) return;
     const int ns = P.p.n_steps, cw = coarse_window(ns);
@@ -768,9 +820,18 @@ __device__ __forceinline__ void decode_tile_coarse(const Params &P, int64_t tile
     float *dst = nullptr;
     float px = 0.f, py = 0.f, pz = 0.f;
     const int64_t di = q / cw;
-    const unsigned e = q < total ? P.s.cdense[di] : 0u;
+    const unsigned e = q < n_rows ? P.s.cdense[di] : 0u;
     const int i = (int)(e >> 29) * cw + (int)(q - di * cw);
-    if (q < total && i < ns) {
+    if (q >= n_rows && q < total) {
+        const unsigned s = P.s.csingles[q - n_rows];
+        const int64_t r = s >> 2;
+        const bool end = (s & 3) == Q_END;
+        const float t = end ? P.s.t_e[r] : P.s.t_s[r];
+        dst = end ? &P.s.res_e[r] : &P.s.res_s[r];
+        px = fadd(P.o[r * 3], fmul(t, P.d[r * 3]));
+        py = fadd(P.o[r * 3 + 1], fmul(t, P.d[r * 3 + 1]));
+        pz = fadd(P.o[r * 3 + 2], fmul(t, P.d[r * 3 + 2]));
+    } else if (q < n_rows && i < ns) {
         const int64_t r = (e & 0x1FFFFFFFu) >> 1;
         const float t = dense_depth(P, r, i, e & 1);
         dst = &P.s.big[(size_t)r * ns + i];
@@ -1034,7 +1095,8 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, 
     __shared__ LdsSx<FT, ROWS, DB> lds;
     __shared__ float raw[RMAX * 9];
     __shared__ float *dest[RMAX];
-    const int64_t total = (int64_t)P.counters[round * NCNT + 5] * coarse_window(P.p.n_steps);
+    const int64_t n_rows = (int64_t)P.counters[round * NCNT + 5] * coarse_window(P.p.n_steps);
+    const int64_t total = n_rows + P.counters[round * NCNT + 9];
     const int64_t n_tiles = (total + ROWS - 1) / ROWS;
     if (blockIdx.x >= n_tiles) return;
     zero_lds_any(lds);      // the K-padded stream multiplies what follows a layer's own columns by zero weights: keep it finite
@@ -1042,7 +1104,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, 
     PCursor cur;
     prime16s<FT>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile_coarse<ROWS>(P, tile, total, raw, dest);
+        decode_tile_coarse<ROWS>(P, tile, n_rows, total, raw, dest);
         __syncthreads();
         if constexpr (DB)
             sdf_tile16s2<QT, FT>(m, lds, raw, dest, b, cur);
@@ -1684,6 +1746,7 @@ size_t carve(RayState &s, char *base, int64_t n, int ns, int cap) {
     s.tri = (unsigned *)take(sizeof(unsigned) * n);
     s.cdense = (unsigned *)take(sizeof(unsigned) * 4 * n);
     s.refine = (unsigned *)take(sizeof(unsigned) * (size_t)n * (cap > 0 ? cap : 0));
+    s.csingles = (unsigned *)take(sizeof(unsigned) * 2 * n);
     return off;
 }
 
@@ -1930,8 +1993,10 @@ extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     const int L = p->bisect_levels >= 1 && p->bisect_levels <= 5 ? p->bisect_levels : 3;
     // ... and the bracket search one more for the rays whose leading samples (evaluated exactly first) hold no negative one,
     // up to three more for the quarter rows of its coarse pass, the min-SDF search one more for its two-stage refinement
-    return 1 + p->sphere_tracing_iters * (1 + p->line_step_iters) + 1 + (p->n_rootfind_steps + L - 1) / L + 1 + 2 +
-           (p->coarse_tau > 0.f ? 3 + 3 + 1 : 0);
+    // tiered sphere tracing: every sphere-tracing evaluation may take a second round (the coarse value, then the exact one)
+    const int trace = 1 + p->sphere_tracing_iters * (1 + p->line_step_iters);
+    return trace + 1 + (p->n_rootfind_steps + L - 1) / L + 1 + 2 +
+           (p->coarse_tau > 0.f ? 3 + 3 + 1 + (p->trace_tier ? trace : 0) : 0);
 }
 
 extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *p) {
@@ -2004,6 +2069,17 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     P.chunk = 0;
     P.chunk_gate = 1e30f;
     P.window = 0;
+    P.tier_band = 0.f;
+    P.tier_gate = 0.f;
+    if (h_params->trace_tier < 0 || h_params->trace_tier > 1 || h_params->tier_kappa < 0.f || h_params->tier_gate < 0.f)
+        return NEFII_E_ARG;
+    if (J.coarse && h_params->trace_tier) {
+        // the band must cover what the recurrence decides: v <= thr and v < 0, given |v16 - v| < tau
+        const float kappa = h_params->tier_kappa > 0.f ? h_params->tier_kappa : 2.f;
+        const float band = kappa * P.tau, least = P.tau + 2.f * fabsf(h_params->sdf_threshold);
+        P.tier_band = band > least ? band : least;
+        P.tier_gate = (h_params->tier_gate > 0.f ? h_params->tier_gate : 4.f) * P.tau;
+    }
     if (J.coarse && h_params->n_steps >= 16) {      // NEFII_SAMPLER_WINDOW=0: whole rows (A/B switch)
         // bit 0: quarter rows, bit 1: two-stage min-SDF refinement.  Both trade rounds for evaluations: the two-stage
         // refinement pays everywhere (config 2: 3.05 -> 2.95 ms per step), the quarter rows' three extra rounds only where
@@ -2091,7 +2167,7 @@ int launch_round(const TraceJob &J, int r, bool profile) {
         HIP_CHECK_LAUNCH();
         if (J.coarse) {
             const int ft = J.pipelined == 2 ? 2 : 4, rows = coarse_rows(ft);
-            const int64_t t = (J.P.n * (int64_t)(4 * coarse_window(J.P.p.n_steps)) + rows - 1) / rows;
+            const int64_t t = (J.P.n * (int64_t)(4 * coarse_window(J.P.p.n_steps) + 2) + rows - 1) / rows;
             const dim3 grid((int)(t < J.eval_blocks_w ? t : J.eval_blocks_w));
             NEFII_COARSE_LAUNCH(eval_kernel16s, ft, grid, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();

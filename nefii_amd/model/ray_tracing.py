@@ -65,6 +65,16 @@ class RayTracing(nn.Module):
         self.coarse = os.environ.get('NEFII_TRACER_COARSE', '1') != '0'
         self.coarse_tau_override = None
         self.coarse_cap = int(os.environ.get('NEFII_TRACER_COARSE_CAP', '0'))
+        # Tiered sphere tracing (nefii_tracer_params.trace_tier; needs the coarse pass): the sphere-tracing evaluations whose
+        # front is still far from the surface run on the single-pass evaluator and their value is taken as it is once it is
+        # out of the band where it could decide differently.  Changes VALUES (fronts move by v16 instead of v): depths of
+        # converged rays differ by up to ~sdf_threshold / cos, a handful of knife-edge rays change path (DESIGN.md,
+        # "tiered sphere tracing").  None: automatic - on for batches the tier pays for (>= 32768 rays, where evaluations and
+        # not round latency make the trace) unless NEFII_TRACE_TIER=0; True / False (or NEFII_TRACE_TIER=1 / 0) force it.
+        env = os.environ.get('NEFII_TRACE_TIER')
+        self.trace_tier = None if env is None or env == '' else env != '0'
+        self.tier_kappa = float(os.environ.get('NEFII_TIER_KAPPA', '0'))
+        self.tier_gate = float(os.environ.get('NEFII_TIER_GATE', '0'))
 
     @staticmethod
     def auto_levels(n_rays, concurrent=False):
@@ -89,6 +99,14 @@ class RayTracing(nn.Module):
         if env:
             return int(env)
         return 4096 if concurrent and n_rays > 1024 else 0
+
+    TIER_DEFAULT = False        # the automatic choice for large batches (tier_for)
+    TIER_MIN_RAYS = 32768
+
+    def tier_for(self, n_rays):
+        if self.trace_tier is not None:
+            return bool(self.trace_tier)
+        return self.TIER_DEFAULT and n_rays >= self.TIER_MIN_RAYS
 
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
@@ -166,7 +184,9 @@ class RayTracing(nn.Module):
                 audit = lambda v: net.note_coarse_audit(v, used, radius)
         params = ops.make_tracer_params(self._cfg(), training, self.precision, levels, coarse_tau=tau,
                                         coarse_cap=self.coarse_cap, minsdf_group=group,
-                                        small_round=self.small_round_for(n_rays, self.concurrent))
+                                        small_round=self.small_round_for(n_rays, self.concurrent),
+                                        trace_tier=self.tier_for(n_rays), tier_kappa=self.tier_kappa,
+                                        tier_gate=self.tier_gate)
         state = None
         if self.adaptive_rounds:      # one guess per (mode, batch size): primary and secondary traces differ
             import math
@@ -176,7 +196,7 @@ class RayTracing(nn.Module):
                              rounds_state=state,
                              groups=1 if group else (self.stream_groups or 1),
                              deferred=self.deferred_checks if state is not None else None,
-                             audit=audit if state is not None else None)
+                             audit=audit)
         if self.collect_counters:
             self.last_counters = res[3]
             cur = res[3]
@@ -185,5 +205,5 @@ class RayTracing(nn.Module):
                 n = max(self.counter_sum.shape[0], cur.shape[0])
                 pad = lambda t: torch.cat([t, t.new_zeros(n - t.shape[0], t.shape[1])]) if t.shape[0] < n else t
                 self.counter_sum, cur = pad(self.counter_sum), pad(cur)
-            self.counter_sum = cur.clone() if self.counter_sum is None else self.counter_sum + cur
+            self.counter_sum = cur.clone() if self.counter_sum is None else ops.sum_counters(self.counter_sum, cur)
         return res[0], res[1], res[2]

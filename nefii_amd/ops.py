@@ -184,6 +184,19 @@ def param_list(module):
     construction (weight_norm included; load_state_dict / .to() / optimizers write in place), and Module.parameters() walks
     the module tree on every call - the per-step version / requires_grad checks cost 0.09 ms of config 1's 0.81-ms host step."""
     plist = module.__dict__.get('_nefii_plist')
+    if plist is not None:
+        # ... but nothing stops a caller from REPLACING them (load_state_dict(assign=True), remove_weight_norm, to_empty):
+        # the version / requires_grad checks would then watch dead objects and serve stale packed weights.  Cheap guard on
+        # every call - the first parameter is still the first (next() stops at the first leaf) - and a full identity
+        # check every 256th.
+        n = module.__dict__['_nefii_plist_calls'] = module.__dict__.get('_nefii_plist_calls', 0) + 1
+        first = next(module.parameters(), None)
+        if (plist[0] if plist else None) is not first:
+            plist = None
+        elif n % 256 == 0:
+            cur = list(module.parameters())
+            if len(cur) != len(plist) or any(a is not b for a, b in zip(cur, plist)):
+                plist = None
     if plist is None:
         plist = module.__dict__['_nefii_plist'] = list(module.parameters())
     return plist
@@ -444,22 +457,25 @@ def algorithmic_evals(counters, n_steps):
     """SDF evaluations the reference's recurrences need for the rounds in `counters` [..., rounds, 9] (what the
     roofline credits): singles + n_steps per dense search entered + bisection steps consumed."""
     c = counters.long()
-    return c[..., 0] + c[..., 6] * n_steps + c[..., 3]
+    return c[..., 0] + c[..., 9] - c[..., 10] + c[..., 6] * n_steps + c[..., 3]
 
 
 def executed_evals(counters, n_steps, tri_nodes=None):
     """(split-precision evaluations, coarse single-pass evaluations) actually executed (tri_nodes: unused, the tracer
     counts its speculative bisection evaluations itself)."""
     c = counters.long()
-    return c[..., 0] + c[..., 1] * n_steps + c[..., 7] + c[..., 4], c[..., 5] * ((n_steps + 3) // 4)
+    return c[..., 0] + c[..., 1] * n_steps + c[..., 7] + c[..., 4], c[..., 5] * ((n_steps + 3) // 4) + c[..., 9]
 
 
 PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}
 
 
 def make_tracer_params(cfg, training, precision='f32', bisect_levels=3, coarse_tau=0.0, coarse_cap=0, minsdf_group=0,
-                       small_round=0):
+                       small_round=0, trace_tier=0, tier_kappa=0.0, tier_gate=0.0):
     p = TracerParams()
+    p.trace_tier = 1 if (trace_tier and coarse_tau > 0.0) else 0
+    p.tier_kappa = float(tier_kappa)
+    p.tier_gate = float(tier_gate)
     p.minsdf_group = int(minsdf_group)
     p.small_round = int(small_round)
     p.precision = PRECISIONS[precision]
@@ -488,7 +504,7 @@ class TraceRounds:
 
 
 _TRACE_STREAMS = {}
-_WORK = [0, 1, 2, 4, 5]      # counter columns that mean "a ray still waits for an evaluation"
+_WORK = [0, 1, 2, 4, 5, 9]   # counter columns that mean "a ray still waits for an evaluation"
 
 
 def _trace_streams(dev, n):
@@ -498,6 +514,22 @@ def _trace_streams(dev, n):
     return pool[:n]
 
 
+AUDIT_COLUMN = 8     # float bits (max), every other column is an additive count
+
+
+def sum_counters(a, b=None):
+    """Counters of several stream groups (a: [groups, rounds, C] -> [rounds, C]) or of two traces (a + b, [rounds, C]):
+    the counts add, column 8 - the bits of a non-negative float, the audit maximum - takes the maximum (the bit patterns
+    of non-negative floats order like the floats)."""
+    if b is None:
+        out = a.sum(dim=0)
+        out[..., AUDIT_COLUMN] = a[..., AUDIT_COLUMN].max(dim=0).values
+        return out
+    out = a + b
+    out[..., AUDIT_COLUMN] = torch.maximum(a[..., AUDIT_COLUMN], b[..., AUDIT_COLUMN])
+    return out
+
+
 def _audit_of(host_counters):
     """Largest |coarse - split| the tracer saw among the coarse samples it re-evaluated (counter column 8: float bits)."""
     col = host_counters[..., 8].contiguous().view(torch.float32)
@@ -505,7 +537,7 @@ def _audit_of(host_counters):
 
 
 def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_steps=None, want_counters=False,
-               rounds_state=None, groups=1, deferred=None, audit=None):
+               rounds_state=None, groups=1, deferred=None, audit=None, keep_workspace=None):
     """RayTracing.forward for per-ray origins.  Returns points [n,3], hit (bool [n]), dists [n] (+ counters).
 
     groups > 1: the rays are cut into that many contiguous chunks that run their rounds on separate HIP streams
@@ -516,6 +548,9 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
 
     audit (a callable, with rounds_state): called with the largest |coarse - split| of this trace's refined samples whenever
     the counters reach the host (the online check of nefii_tracer_params.coarse_tau: ImplicitNetwork.note_coarse_audit).
+
+    keep_workspace (a list): receives (workspace tensor, first ray, rays) per chunk - measurement tools read ray state from it
+    (trace_iterations below).
 
     deferred (a list, with rounds_state): the call enqueues the guessed round prefix and returns WITHOUT reading the
     counters back; it appends a callable that, invoked once the work has completed, tells whether that prefix was the
@@ -528,7 +563,7 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
     hit = torch.empty(n, device=dev, dtype=torch.uint8)
     dist = torch.empty(n, device=dev, dtype=torch.float32)
     rounds = lib.nefii_trace_max_rounds(ctypes.byref(params))
-    need_cnt = want_counters or rounds_state is not None
+    need_cnt = want_counters or rounds_state is not None or audit is not None
     groups = max(1, min(int(groups), n // 64)) if n > 0 else 1
     counters = torch.zeros(groups, rounds, _lib.TRACE_COUNTERS, device=dev, dtype=torch.int32) if need_cnt else None
     if n > 0:
@@ -548,6 +583,8 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
                 nbytes = lib.nefii_trace_workspace_bytes(hi - lo, ctypes.byref(params))
                 work.append((torch.empty(nbytes, device=dev, dtype=torch.uint8), nbytes))
 
+        if keep_workspace is not None:
+            keep_workspace.extend((w, lo, hi - lo) for (w, _), (lo, hi) in zip(work, bounds))
         G = len(bounds)
         begin = (ctypes.c_int64 * (G + 1))(*([lo for lo, _ in bounds] + [n]))
         ws_ptrs = (ctypes.c_void_p * G)(*[w.data_ptr() for w, _ in work])
@@ -581,6 +618,8 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
         if rounds_state is None:
             run(everyone, 0, 0)
             join()
+            if audit is not None:           # (the non-adaptive path has no counter read-back of its own: one host sync)
+                audit(_audit_of(counters.cpu()))
         else:
             guess = rounds if rounds_state.guess is None else max(2, min(rounds, rounds_state.guess))
             run(everyone, 0, guess)
@@ -611,7 +650,7 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
                     return (pts, hit.bool(), dist) if again else None
                 deferred.append(check)
                 if want_counters:
-                    return pts, hit.bool(), dist, counters.sum(dim=0)
+                    return pts, hit.bool(), dist, sum_counters(counters)
                 return pts, hit.bool(), dist
             host = counters.cpu()                            # the one host sync (the caller syncs next anyway)
             if guess < rounds:
@@ -626,8 +665,20 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
             if audit is not None:
                 audit(_audit_of(host))
     if want_counters:
-        return pts, hit.bool(), dist, counters.sum(dim=0)
+        return pts, hit.bool(), dist, sum_counters(counters)
     return pts, hit.bool(), dist
+
+
+def trace_iterations(kept):
+    """Sphere-tracing iterations each ray took, from the workspaces a finished trace_rays(keep_workspace=kept) left: the
+    tracer parks the count in bits 20-23 of a ray's flag word when its sphere tracing ends (csrc/nefii_tracer.hip; the flag
+    array follows 13 float arrays of n rays, each padded to 256 bytes).  Measurement only (tools/tier_parity.py)."""
+    out = []
+    for ws, _lo, n in kept:
+        stride = (4 * n + 255) // 256 * 256
+        flags = ws[13 * stride:13 * stride + 4 * n].view(torch.int32)
+        out.append((flags >> 20) & 0xF)
+    return torch.cat(out)
 
 
 def camera_rays(uv, pose, intrinsics):

@@ -102,7 +102,10 @@ def fibonacci_sphere(n):
     return np.stack([np.cos(th) * r, y, np.sin(th) * r], -1)
 
 
-SCENES = {'bowl': 'scene_bowl_sdf64.npz', 'bowl_dense': 'scene_bowl_sdf64.npz'}
+SCENES = {'bowl': 'scene_bowl_sdf64.npz', 'bowl_dense': 'scene_bowl_sdf64.npz',
+          # TRAINED at the conf's own width by the Step-1 runner (tools/train_scene_sdf.py on a GPU): full-rank weights, no
+          # embedding - the file holds the network itself (weight_v in halves, weight_g / bias in fp32)
+          'bowl_trained': 'scene_bowl_sdf%d.npz', 'frame_trained': 'scene_frame_sdf%d.npz'}
 
 
 def _embed_dense(small, shapes, d0, skip, g):
@@ -151,10 +154,23 @@ def embed_scene_sdf(model, sd, scene, g):
     non-zero weight_v (a zero row would make g*v/|v| NaN) and bias 0, the remaining columns are zero.  Same function,
     full-size compute; the padded hidden units all output Softplus(0)."""
     import os
-    small = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', SCENES[scene])))
     ic = model['implicit_network']
     F = int(model['feature_vector_size'])
     shapes = sdf_layer_dims(ic, F)
+    if scene.endswith('_trained'):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', SCENES[scene] % ic['dims'][0])
+        if not os.path.exists(path):
+            raise FileNotFoundError('%s: no trained stand-in for a %d-wide SDF network (tools/train_scene_sdf.py writes it)'
+                                    % (path, ic['dims'][0]))
+        net = np.load(path)
+        for l, (o, i) in enumerate(shapes):
+            v = net['lin%d.weight_v' % l].astype(np.float32)
+            assert v.shape == (o, i), (scene, l, v.shape, (o, i))
+            sd['implicit_network.lin%d.weight_v' % l] = _t(v)
+            sd['implicit_network.lin%d.weight_g' % l] = _t(net['lin%d.weight_g' % l].reshape(o, 1))
+            sd['implicit_network.lin%d.bias' % l] = _t(net['lin%d.bias' % l])
+        return sd
+    small = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', SCENES[scene])))
     d0 = shapes[0][1]
     skip = tuple(ic.get('skip_in', ()))
     nl = len(shapes)

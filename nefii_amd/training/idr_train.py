@@ -159,9 +159,14 @@ class IDRTrainRunner:
             alpha_milestones=t.get_list('alpha_milestones', default=[]), alpha_factor=t.get_float('alpha_factor', default=0.0),
             roughness_warmup=kwargs.get('roughness_warmup', -1), specular_warmup=kwargs.get('specular_warmup', -1),
             start_iter=self.start_epoch * self.n_batches,
-            # frozen geometry: the tracer's min-SDF search only feeds the VALUE of mask_loss - run it on the iterations whose
-            # loss is read (the log line every log_freq iterations, idr_train.py:784); NEFII_MIN_SDF_EVERY=1: every iteration
-            min_sdf_every=int(os.environ.get('NEFII_MIN_SDF_EVERY', str(self.log_freq))) if self.freeze_geometry else 1)
+            # The reference runs the tracer's min-SDF search on EVERY iteration (ray_tracing.py:71-97) and so does this runner
+            # by default.  Under frozen geometry the search only feeds the VALUE of mask_loss (no gradient); the opt-in
+            # `min_sdf_every=E` (or NEFII_MIN_SDF_EVERY=E) runs it on the iterations with cur_iter % E == 0 only - e.g. E =
+            # log_freq: the logged line is then the reference's, but the losses of the OTHER iterations (returned by the
+            # step, and what the NaN guard sees, idr_train.py:754) carry a mask_loss computed without the search:
+            # they are not the reference's values.  Same gradients, parameters and RNG stream either way (TrainStep).
+            min_sdf_every=(kwargs.get('min_sdf_every') or int(os.environ.get('NEFII_MIN_SDF_EVERY', '1')))
+            if self.freeze_geometry else 1)
         self.loss = self.step.loss
         if saved:
             self.step.idr_optimizer.load_state_dict(saved['idr_opt']['optimizer_state_dict'])
@@ -170,6 +175,7 @@ class IDRTrainRunner:
             self.step.sg_scheduler.load_state_dict(saved['sg_sched']['scheduler_state_dict'])
             self.step.retensor_lr()
         self.history = []
+        self._coarse_events_logged = 0
         # the reference's tensorboardX log (idr_train.py:114-115): an event file in <exps>/<expname>/<timestamp>/, written by
         # this package's own writer (utils/tb_writer.py: tensorboard / tensorboardX are not installable here); rank 0 only
         self.writer = None
@@ -289,6 +295,13 @@ class IDRTrainRunner:
                            'sg_psnr': float(mse2psnr(lo['sg_rgb_loss'].item())),
                            'idr_lr': float(self.step.idr_optimizer.param_groups[0]['lr']),
                            'sg_lr': float(self.step.sg_optimizer.param_groups[0]['lr'])}
+                    # what the online audit of the tracer's coarse bound did since the last line (TrainStep.coarse_events: a
+                    # bound raised, or the coarse pass switched off and the step's batch traced again) goes into the record
+                    if len(self.step.coarse_events) > self._coarse_events_logged:
+                        rec['coarse_audit_events'] = [list(e) for e in self.step.coarse_events[self._coarse_events_logged:]]
+                        self._coarse_events_logged = len(self.step.coarse_events)
+                        if self.rank == 0:
+                            print('{0} coarse-pass audit: {1}'.format(self.expname, rec['coarse_audit_events']))
                     self.history.append(rec)
                     if self.writer is not None:          # the scalars of the reference's log() (idr_train.py:881-895)
                         for k in ('idr_rgb_loss', 'sg_rgb_loss', 'mask_loss', 'normalsmooth_loss', 'background_rgb_loss'):

@@ -5,6 +5,7 @@ Optimiser construction follows idr_train.py:188-196: one Adam over implicit+rend
 envmap/material parameters, both lr 5e-4.  The multi-GPU path shards the pixel batch per rank (the dataset's
 contiguous patch split, scene_dataset.py:268-279) and averages gradients with ONE flat all-reduce over
 RCCL/xGMI (what DistributedDataParallel does for the reference, idr_train.py:308-309), 6.6-13 MB per step."""
+import contextlib
 import os
 
 import torch
@@ -268,6 +269,8 @@ class TrainStep:
         # the other iterations carry a mask_loss computed without the search (finite whenever the true one is).  The
         # search's uniform draw is made on every iteration either way.  Default (None): NEFII_MIN_SDF_EVERY, else 1 - every
         # iteration, the reference's schedule; trainable geometry always runs it.
+        self.coarse_events = []         # (iteration, 'recalibrated' | 'disabled', observed, bound): the coarse bound's audit
+        self.retraced_steps = 0         # batches traced again because the bound their enqueued trace assumed did not hold
         if min_sdf_every is None:
             min_sdf_every = int(os.environ.get('NEFII_MIN_SDF_EVERY', '1'))
         self.min_sdf_every = max(1, int(min_sdf_every))
@@ -434,13 +437,22 @@ class TrainStep:
                 g['lr'] = float(g['lr'])
         return sd
 
-    def _set_min_sdf(self, *iters):
-        """The tracer's schedule for the trace(s) of the given iteration(s) (several: batches traced as one call)."""
+    @contextlib.contextmanager
+    def _min_sdf_schedule(self, *iters):
+        """The tracer's schedule while the trace(s) of the given iteration(s) are enqueued (several: batches traced as one
+        call).  The two switches live on the model's ray tracer, which other callers share (a second TrainStep, a direct
+        training-mode model(...) call, bench.py's side measurements): they are set for the enqueue only and put back."""
         if self.min_sdf_every <= 1 or not getattr(self.model, 'state_freeze_geo', False):
+            yield
             return
         rt = self.model.ray_tracer
+        old = (rt.skip_min_sdf_search, rt.draw_when_skipped)
         rt.skip_min_sdf_search = not any(i % self.min_sdf_every == 0 for i in iters)
         rt.draw_when_skipped = True
+        try:
+            yield
+        finally:
+            rt.skip_min_sdf_search, rt.draw_when_skipped = old
 
     def _pre_iteration(self):
         """idr_train.py:692-713, in the reference's order."""
@@ -562,6 +574,8 @@ class TrainStep:
         cur = torch.cuda.current_stream()
         cur.wait_event(ev)
         ev.synchronize()
+        net = self.model.implicit_network
+        seen = len(net.coarse_audit_events)
         if grp is None or not grp['done']:
             for chk in checks:
                 more = chk()
@@ -575,6 +589,17 @@ class TrainStep:
                         c.pop('hit_idx_src', None)
             if grp is not None:
                 grp['done'] = True
+        # the online audit of the tracer's coarse bound reports with these checks (ImplicitNetwork.note_coarse_audit).  A
+        # bound that did NOT hold for this trace means one of its unrefined samples may have decided differently: the trace -
+        # and every trace already enqueued under the same bound - is dropped and the batch traced again (the coarse pass is
+        # off for these weights by now).  The re-trace draws its min-SDF uniforms anew.  Recorded for the runner's log.
+        fresh = net.coarse_audit_events[seen:]
+        for kind, observed, bound in fresh:
+            self.coarse_events.append((self.cur_iter, kind, observed, bound))
+        if any(kind == 'disabled' for kind, _, _ in fresh):
+            self._prefetch = []
+            self.retraced_steps += 1
+            return None
         for v in list(ctx.values()) + list(ctx.get('pre') or ()):
             if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(cur)          # allocated on the trace stream, consumed here
@@ -582,8 +607,8 @@ class TrainStep:
 
     def _graph_step(self, model_input, ground_truth, ctx=None):
         if ctx is None:
-            self._set_min_sdf(self.cur_iter)
-            ctx = self.model.trace_head(model_input)
+            with self._min_sdf_schedule(self.cur_iter):
+                ctx = self.model.trace_head(model_input)
         idx = _hit_index(ctx)      # no host sync for a trace enqueued ahead; torch.nonzero (the step's one sync) otherwise
         n_hit, n_all = idx.numel(), ctx['points'].shape[0]
         if n_hit == 0:
@@ -632,8 +657,8 @@ class TrainStep:
                 self._prefetch, queued, mine = [], [], False        # the caller changed its mind about the coming batches
                 expected = upcoming
             if not mine and m.training and getattr(m, 'state_freeze_geo', False):
-                self._set_min_sdf(self.cur_iter)
-                ctx = m.trace_head(model_input)         # own trace first: the tracer's random draws keep their order
+                with self._min_sdf_schedule(self.cur_iter):
+                    ctx = m.trace_head(model_input)         # own trace first: the tracer's random draws keep their order
             # enqueued BEFORE this batch's own (earlier enqueued) trace is waited for: the trace streams then always have
             # the next trace(s) queued behind / beside the running one and never idle while the host checks and launches
             todo = expected[len(queued):]
@@ -641,20 +666,20 @@ class TrainStep:
             G = self.trace_group_for(model_input)
             if G <= 1:
                 for inp in todo:
-                    self._set_min_sdf(it_next)
-                    self.prefetch_trace(inp)
+                    with self._min_sdf_schedule(it_next):
+                        self.prefetch_trace(inp)
                     it_next += 1
             else:
                 while len(todo) >= G:
-                    self._set_min_sdf(*range(it_next, it_next + G))
-                    self.prefetch_group(todo[:G])
+                    with self._min_sdf_schedule(*range(it_next, it_next + G)):
+                        self.prefetch_group(todo[:G])
                     todo = todo[G:]
                     it_next += G
                 # never let the queue run dry: when no traced batch would be left for the next call, trace what there is
                 left = len(self._prefetch) - (1 if self._prefetch and self._prefetch[0][0] is model_input else 0)
                 if left == 0 and todo:
-                    self._set_min_sdf(*range(it_next, it_next + len(todo)))
-                    self.prefetch_group(todo)
+                    with self._min_sdf_schedule(*range(it_next, it_next + len(todo))):
+                        self.prefetch_group(todo)
         if ctx is None:
             ctx = self._take_prefetched(model_input)
         if self.graph and self._eager_steps >= self.graph_after and self.model.training:
@@ -668,8 +693,8 @@ class TrainStep:
         if ctx is not None:
             out = self.model.shade_tail(ctx, _hit_index(ctx))
         else:
-            self._set_min_sdf(self.cur_iter)
-            out = self.model(model_input)
+            with self._min_sdf_schedule(self.cur_iter):
+                out = self.model(model_input)
         lo = self.loss(out, ground_truth)
         self._zero_grads()
         if lo['loss'].requires_grad:        # a slice without a single hit (and no background term) has nothing to

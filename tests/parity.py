@@ -6,7 +6,24 @@ same on both sides; rays with a proven discrete difference - a sampled direction
 picks its lobe by a CDF comparison: a uniform within rounding noise of a boundary picks the neighbouring lobe) or a
 secondary ray whose hit flag differs (a grazing re-hit decided by an `sdf <= 5e-5` comparison) - are counted, bounded
 and reported, never silently dropped."""
+import os
+
 import torch
+
+# NEFII_PARITY_SOFT=1 (tools/tier_round.sh: the parity protocol of an arithmetic that is NOT expected to meet every bound):
+# a tolerance that does not hold is printed ("EXCEEDS") instead of raised, so that one run lists every figure; the printed
+# line of figures below is always there
+SOFT = os.environ.get('NEFII_PARITY_SOFT', '0') == '1'
+
+
+def _check(ok, info):
+    if ok:
+        return
+    if SOFT:
+        print('[parity EXCEEDS] %s' % (info,))
+    else:
+        raise AssertionError(info)
+
 
 FLOAT_KEYS = ['points', 'idr_rgb_values', 'sg_rgb_values', 'normal_values', 'sdf_output', 'sg_diffuse_rgb_values',
               'sg_diffuse_albedo_values', 'sg_specular_rgb_values', 'sg_roughness_values',
@@ -49,7 +66,7 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel
     untrimmed."""
     net, rnet = out['network_object_mask'].cpu(), ref['network_object_mask']
     flips = (net != rnet).sum().item()
-    assert flips <= max_flips, (what, 'hit-mask flips', flips)
+    _check(flips <= max_flips, (what, 'hit-mask flips', flips))
     assert torch.equal(out['object_mask'].cpu(), ref['object_mask'])
     agree = net == rnet
     flagged_px = torch.zeros_like(agree)
@@ -58,25 +75,29 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel
         flagged, n_dir, n_vis = mc_flagged_rays(out, ref, ray_hit, ref_ray_hit)
         flagged_px = flagged.reshape(-1, rays_per_pixel).any(1)
         frac = flagged_px.float().mean().item()
-        assert frac <= max_explained_frac, (what, 'pixels with a discrete MC difference', frac, n_dir, n_vis)
+        _check(frac <= max_explained_frac, (what, 'pixels with a discrete MC difference', frac, n_dir, n_vis))
     print('[parity %s] pixels %d, hit-mask flips %d, rays with a differing sampled direction %d / secondary hit flag %d '
           '-> %d pixels compared apart' % (what, net.numel(), flips, n_dir, n_vis, int(flagged_px.sum())))
+    figures = []
     for k in FLOAT_KEYS:
         keep = agree & ~flagged_px if k in MC_KEYS else agree
         a, b = out[k].detach().cpu()[keep], ref[k][keep]
+        figures.append('%s %.2e' % (k.replace('_values', ''), rel_l2(a[rnet[keep]], b[rnet[keep]]) if k in ('points', 'sdf_output')
+                                   else rel_l2(a, b)))
         if k in ('points', 'sdf_output'):
             # rays that miss take the argmin of 100 samples (flat minimum: the winner flips on rounding noise);
             # compare them on hit rays only, misses through sdf_output (the value reached) with a loose bound
             h = rnet[keep]
             if k == 'points':
-                assert rel_l2(a[h], b[h]) < 1e-4, (what, k, rel_l2(a[h], b[h]))
+                figures.append('|d point| max %.2e' % ((a[h] - b[h]).abs().max().item() if h.any() else 0.0))
+                _check(rel_l2(a[h], b[h]) < 1e-4, (what, k, rel_l2(a[h], b[h])))
             else:      # |sdf| <= 5e-5 on the surface: absolute comparison (sdf_outliers: hit rays allowed beyond it -
                 # large samples contain the odd ray whose bisection bracket differs by one sample)
-                assert int(((a[h] - b[h]).abs() >= 2e-4).sum()) <= sdf_outliers, (what, k, (a[h] - b[h]).abs().max().item())
-                assert (a[h] - b[h]).abs().median().item() < 2e-6, (what, k)
+                _check(int(((a[h] - b[h]).abs() >= 2e-4).sum()) <= sdf_outliers, (what, k, (a[h] - b[h]).abs().max().item()))
+                _check((a[h] - b[h]).abs().median().item() < 2e-6, (what, k))
             if k == 'sdf_output' and (~h).any():
-                assert (a[~h] - b[~h]).abs().max().item() < 5e-3, (what, k)
-                assert ((a[~h] - b[~h]).abs() < 2e-5).float().mean().item() > 0.9, (what, k)
+                _check((a[~h] - b[~h]).abs().max().item() < 5e-3, (what, k))
+                _check(((a[~h] - b[~h]).abs() < 2e-5).float().mean().item() > 0.9, (what, k))
             continue
         if k == 'sg_specular_rgb_values':
             # A COMPONENT of the rendered colour: GGX's D = 1 / (pi a^2 ((n.h)^2 + (1 - (n.h)^2) / a^2)^2), a = roughness^2,
@@ -86,10 +107,11 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel
             # tol_rgb at THAT scale, and within 10 tol_rgb of its own.
             total = ref['sg_rgb_values'][keep]
             err = (a.float() - b.float()).norm().item()
-            assert err / (total.norm().item() + 1e-12) < tol_rgb, (what, k, 'vs rgb', err / total.norm().item())
-            assert rel_l2(a, b) < 10 * tol_rgb, (what, k, rel_l2(a, b))
+            _check(err / (total.norm().item() + 1e-12) < tol_rgb, (what, k, 'vs rgb', err / total.norm().item()))
+            _check(rel_l2(a, b) < 10 * tol_rgb, (what, k, rel_l2(a, b)))
             continue
-        assert rel_l2(a, b) < tol_rgb, (what, k, rel_l2(a, b))
+        _check(rel_l2(a, b) < tol_rgb, (what, k, rel_l2(a, b)))
+    print('[parity %s] rel-L2: %s' % (what, ', '.join(figures)))
     # the excluded pixels are not unchecked: everything that does not pass through the sampler still has to agree there
     # (above: normals, albedo, roughness, idr_rgb over all `agree` pixels), and their colours must stay finite
     for k in MC_KEYS:

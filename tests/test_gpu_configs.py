@@ -62,18 +62,23 @@ SHRUNK = {'cfg2': 256, 'cfg3': 48, 'cfg4': 48}
 # (a sampled lobe that differs = a uniform draw within rounding of a CDF boundary: 3 rays of config 3's 3072 with the
 # replicated embedding of the stand-in geometry, whose feature vector - and with it the lobe weights - differs from the
 # zero-padded one's, where it was 0-1 by box)
-PINNED_DISCRETE = {'cfg2': {'flips': 0}, 'cfg3': {'flips': 0, 'dir': 5, 'vis': 0}, 'cfg4': {'flips': 0}}
+PINNED_DISCRETE = {'cfg2': {'flips': 0}, 'cfg3': {'flips': 0, 'dir': 5, 'vis': 0}, 'cfg3-bowl': {'flips': 0, 'dir': 2, 'vis': 0},
+                   'cfg4': {'flips': 0}}
 
 
-@pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg4'])
+@pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg3-bowl', 'cfg4'])
 def test_config_shrunk_in_pixels_vs_oracle(wl):
     """The config's model at full network width, its geometry stand-in, camera and rays per pixel (64 for configs 3-4);
     only the number of pixels is reduced.  Forward + IDRLoss + backward against the CPU oracle with injected draws:
     north-star tolerance on RGB / albedo ray by ray, loss terms, every parameter gradient, and the tracer's
     SDF-evaluation counters against the oracle's evaluation counts."""
     from nefii_amd.model.loss import IDRLoss
+    # 'cfg3-bowl': config 3 on the ZERO-PADDED embedding of its stand-in geometry with round 3's gradient bound (3e-3): the
+    # bound of the replicated embedding (6e-3) follows that embedding's feature vector, and this case keeps the kernels'
+    # arithmetic (half training state included) pinned where the embedding did not move (ADVICE r4)
+    bound_key, wl = wl, wl.split('-')[0]
     w = syn.WORKLOADS[wl]
-    mc, sd = syn.workload_state_dict(wl, seed=0)
+    mc, sd = syn.workload_state_dict(wl, seed=0, scene='bowl' if bound_key.endswith('-bowl') else None)
     lc = syn.loss_conf(w['model'])
     inp, gt = syn.make_inputs(SHRUNK[wl], w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
     flat, gt_flat, R = per_ray_layout(inp, gt)
@@ -108,8 +113,8 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
         wl, n_ray, t_oracle, ref['_ray_hit'].float().mean(), stats))
     # where the measured count of discrete differences IS zero it is asserted to be zero (the allowances above are for
     # workloads with knife-edge rays): hit-mask flips, rays with another sampled lobe, secondary rays hitting on one side only
-    for k, allowed in PINNED_DISCRETE[wl].items():
-        assert stats[k] <= allowed, (wl, k, stats[k], allowed)
+    for k, allowed in PINNED_DISCRETE[bound_key].items():
+        assert stats[k] <= allowed, (bound_key, k, stats[k], allowed)
     if mc_shading:
         sm, rsm = m.last_ray_hit.cpu(), ref['_ray_hit']
         assert ref['secondary_mask'].float().mean().item() > 0.2          # the indirect branch does real work here
@@ -133,8 +138,10 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
             # a difference below ~2e-3 is within the oracle's own distance from the reference.  Config 3's bound follows the
             # replicated embedding of its stand-in geometry (end of round 4): that same bias measures 4.0e-3 there, with the
             # fp32 and with the fp16 training state alike (tools/experiments/grad_probe.py) - the one-pass fp16 backward on
-            # a feature vector of 512 live entries instead of 64
-            assert rel_l2(p.grad, gref) < {'cfg2': 1.5e-3, 'cfg3': 6e-3, 'cfg4': 6e-3}[wl], (name, rel_l2(p.grad, gref))
+            # a feature vector of 512 live entries instead of 64.  The per-parameter table for both embeddings and three
+            # arithmetics of the MLPs' training path: profiles/r05/grad_probe_cfg3.txt (tools/experiments/grad_probe.py)
+            assert rel_l2(p.grad, gref) < {'cfg2': 1.5e-3, 'cfg3': 6e-3, 'cfg3-bowl': 3e-3, 'cfg4': 6e-3}[bound_key], \
+                (name, rel_l2(p.grad, gref))
     print('[%s] worst parameter-gradient rel-L2 %.2e' % (wl, worst))
     # ---- algorithmic SDF evaluations: tracer counters (primary + secondary traces) = the oracle's evaluation counts
     cnt = m.ray_tracer.counter_sum.cpu().long()

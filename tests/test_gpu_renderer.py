@@ -575,6 +575,40 @@ def test_bench_two_processes_share_one_gpu():
     assert not d['invalid']
 
 
+def test_bench_eight_processes_share_one_gpu():
+    """The launch the driver makes on an 8-GPU node - `python bench.py --gpus 8`, no launcher - at the world size it will use,
+    on this box's one GPU over gloo with every workload shrunk (NEFII_BENCH_PIXELS=200: 50 patches, so the contiguous split
+    leaves the last rank a remainder - 6 patches per rank, 8 on rank 7, scene_dataset.py:268-279): spawn_ranks, the flat
+    gradient buffer all-reduced while each rank keeps three traces (whose evaluators claim whole SIMDs) in flight, config 4's
+    strong split at W = 8, and config 5's round-robin plan for ONE row of the frame - 800 pixels in 7 chunks of 128 at level
+    18 - 3, i.e. a rank that renders nothing (render.py:284-295)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NEFII_BENCH_BACKEND='gloo', NEFII_BENCH_PIXELS='200')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '4', '--repeats', '1',
+           '--no-cpu-baseline', '--frame-rows', '1']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 8 and d['config']['parallelism'] == 'dp8' and d['value'] > 0 and d['scaling'] == 'weak'
+    assert d['config']['num_pixels_override'] == 200 and d['config']['primary_rays_per_step_per_gpu'] == 200 * 64
+    assert d['config']['trace_prefetch'] == 3            # three traces in flight beside every step's all-reduce
+    assert d['config']['rank_param_spread'] < 1e-9 and d['config']['nonfinite_steps'] == 0
+    for k in ('cfg2', 'cfg1'):
+        assert d[k]['value'] > 0 and d[k]['config']['rank_param_spread'] < 1e-9, d[k]['config']
+    # strong scaling: 50 patches over 8 ranks = 6 each, rank 0 holds 24 pixels (the remainder of 2 goes to rank 7)
+    assert d['cfg4']['scaling'] == 'strong' and d['cfg4']['config']['primary_rays_per_step_per_gpu'] == 24 * 64
+    assert d['cfg4']['value'] * d['cfg4']['ms_per_step'] * 1e-3 == pytest.approx(200 * 64, rel=1e-6)      # every pixel traced once
+    assert d['cfg4']['config']['rank_param_spread'] < 1e-9
+    assert d['cfg5']['n_gpus'] == 8 and d['cfg5']['config']['finite'] and d['cfg5']['config']['primary_rays_per_frame'] == 800 * 256
+    assert not d['invalid']
+
+
 def _run_bench(args, nproc, port, timeout=600):
     import json
     import os
@@ -686,6 +720,9 @@ def test_min_sdf_on_reporting_iterations_only(graph, lookahead):
             nxt = ([b[0] for b in batches[i + 1:i + 1 + lookahead]] or None) if lookahead else None
             out, lo = st(inp, gt, nxt)
             losses.append({k: v.item() for k, v in lo.items()})
+            # the schedule's two switches live on the SHARED ray tracer: set while a trace is enqueued, put back behind it
+            # (a later TrainStep or a direct model(...) call must not inherit skip = True)
+            assert m.ray_tracer.skip_min_sdf_search is False and m.ray_tracer.draw_when_skipped is False
         state = {k: v.detach().clone() for k, v in m.state_dict().items() if v.dtype.is_floating_point}
         for j, o in enumerate((st.idr_optimizer, st.sg_optimizer)):
             for n_, s_ in enumerate(o.state.values()):
