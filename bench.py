@@ -143,6 +143,9 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None, parity_p
             m.ray_tracer.minsdf_steps_override = over
         if ref['uniforms'] is not None:
             m.uniforms_override = ref['uniforms']
+        # the parity sample is smaller than the batch the headline times: it takes the tracer's tier exactly when THAT batch does
+        if m.ray_tracer.trace_tier is None:
+            m.ray_tracer.trace_tier = bool(m.ray_tracer.tier_for(w['num_pixels'] * R_))
         with torch.no_grad():
             out = m({k: v.to(device) for k, v in inp.items()})
         mask = ref['network_object_mask'] & out['network_object_mask'].cpu()
@@ -156,7 +159,7 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None, parity_p
         parity['tolerance_rel_l2'] = 1e-3
         parity['sample'] = 'the first %d pixels of the workload (%d primary rays), forward only, the oracle\'s draws replayed' % (
             pp, pp * R_)
-        parity['trace_tier'] = bool(m.ray_tracer.tier_for(pp * R_))
+        parity['trace_tier'] = bool(m.ray_tracer.trace_tier)
     return res, parity
 
 
@@ -421,8 +424,11 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                                'fwd+IDRLoss+bwd+2xAdam'
                                % (name + (' (strong scaling: global batch split over the ranks)' if strong else ''),
                                   'robot-like synthetic scene (geometric-init SDF sphere)' if not w.get('scene') else
-                                  'non-convex synthetic scene (fitted ball-in-bowl SDF embedded at full width%s)'
-                                  % (', no zero weights' if w['scene'].endswith('_dense') else ', zero-padded'),
+                                  {'bowl': 'non-convex synthetic scene (fitted ball-in-bowl SDF embedded at full width, zero-padded)',
+                                   'bowl_dense': 'non-convex synthetic scene (fitted ball-in-bowl SDF embedded at full width, no zero weights)',
+                                   'bowl_trained': 'non-convex synthetic scene (ball-in-bowl, the full-width SDF network trained by the Step-1 runner)',
+                                   'frame_trained': 'thin-feature synthetic scene (cube frame + plate + ball, the full-width SDF network '
+                                                    'trained by the Step-1 runner)'}[w['scene']],
                                   {'physg': 'physg.conf', 'conf': 'conf.conf', 'neus': 'conf_neus.conf'}[w['model']],
                                   w['num_pixels'], (' x %d rays/pixel' % w['num_rays']) if w['num_rays'] > 0 else '',
                                   'indirect OFF (closed-form SG)' if not indirect else 'MC direct + near-field indirect ON'),
@@ -676,16 +682,24 @@ def main():
         nested['cfg4'] = run_workload('cfg4', args, max(1, min(args.steps, 10)), min(args.warmup, 2), rank, world, dev, backend,
                                       lib, side=False, scaling='strong' if world > 1 else 'weak', sustained=sustained)
         if world == 1 and headline == 'cfg3':
-            # the same step on the ZERO-PADDED embedding of the same geometry (rounds 2-4's stand-in: 98 % zero weights in the
-            # SDF net): what a power-limited part makes of cheap operands - comparable with earlier rounds' lines, not a headline
+            # the same step on the earlier stand-ins of the same scene: the ZERO-PADDED embedding of an 8 x 64 fit (rounds 2-4:
+            # 98 % zero weights - what a power-limited part makes of cheap operands) and its REPLICATED embedding (round 4's
+            # headline) - comparable with earlier rounds' lines, not headlines
             from nefii_amd import synthetic as syn
             scene = syn.WORKLOADS['cfg3']['scene']
-            syn.WORKLOADS['cfg3']['scene'] = 'bowl'
-            try:
-                nested['cfg3_zero_padded'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
-                                                          dev, backend, lib, side=False, sustained=sustained, power=True)
-            finally:
-                syn.WORKLOADS['cfg3']['scene'] = scene
+            # ... and on the conf's own 8 x 512 network TRAINED by the Step-1 runner (tools/train_scene_sdf.py) on the same
+            # analytic scene ('bowl_trained': full-rank weights instead of a replicated 8 x 64 fit) and on a thin-feature
+            # scene ('frame_trained': the bars of a cube frame, a thin plate, a small ball)
+            for key, alt in (('cfg3_zero_padded', 'bowl'), ('cfg3_replicated', 'bowl_dense'), ('cfg3_trained', 'bowl_trained'),
+                             ('cfg3_frame_trained', 'frame_trained')):
+                if alt == scene:
+                    continue
+                syn.WORKLOADS['cfg3']['scene'] = alt
+                try:
+                    nested[key] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
+                                               dev, backend, lib, side=False, sustained=sustained, power=True)
+                finally:
+                    syn.WORKLOADS['cfg3']['scene'] = scene
         # ... and its render config, bounded: a band of 32 rows through the object (25 600 pixels x 256 rays)
         band = argparse.Namespace(**vars(args))
         band.frame_rows = args.frame_rows or 32
@@ -709,6 +723,28 @@ def main():
                 'nonfinite_steps': zp['config']['nonfinite_steps'],
                 'note': 'same geometry, same kernels; the SDF net holds 98 % zero weights, the matrix cores draw less power and the '
                         'part clocks higher - the stand-in of rounds 2-4, kept for comparison with their lines'}
+        for key, out_key, note in (
+                ('cfg3_replicated', 'cfg3_replicated_stand_in',
+                 'round 4\'s headline geometry: the 8 x 64 fit of the same scene replicated across the 512 columns without a zero '
+                 'weight (rank-64 structure: twice the trained net\'s single-pass error, so a larger coarse_tau and more refined samples)'),
+                ('cfg3_trained', 'cfg3_trained_stand_in',
+                 'the same analytic scene regressed by the conf\'s own 8 x 512 SDF network with this repo\'s Step-1 runner '
+                 '(20 000 iterations, near-surface error 6e-5): full-rank trained weights'),
+                ('cfg3_frame_trained', 'cfg3_thin_feature_scene',
+                 'a thin-feature scene (cube frame of 0.05-thick bars, a 0.024-thick plate, a small ball) regressed the same way: '
+                 'another hit fraction and ray statistics, so ms_per_step is not comparable with the bowl\'s - tau, audit and '
+                 'power are')):
+            t = nested.get(key)
+            if t is not None:
+                r = t['roofline']
+                result[out_key] = {
+                    'ms_per_step': t['ms_per_step'], 'ms_per_step_repeats': t['ms_per_step_repeats'], 'value': t['value'],
+                    'frac': r['frac'], 'frac_executed': r['frac_executed'], 'board_power': r['board_power'],
+                    'coarse_tau': r['coarse_tau'], 'coarse_audit_max': r['coarse_audit_max'],
+                    'coarse_audit_events': r['coarse_audit_events'], 'hit_fraction': r['hit_fraction'],
+                    'secondary_hit_fraction': r['secondary_hit_fraction'], 'sdf_evals_per_primary_ray': r['sdf_evals_per_primary_ray'],
+                    'kernel_ms_per_step': r['kernel_ms_per_step'], 'nonfinite_steps': t['config']['nonfinite_steps'],
+                    'workload': t['config']['workload'], 'note': note}
         near = nested.get('cfg2_near')
         if near is not None:
             # SURVEY.md section 8(d) planned a ~40 % hit fraction for config 2; the geometric-init surface seen from 2.4 gives

@@ -174,6 +174,19 @@ int nefii_mlp_backward_f16h(const nefii_mlp *h_mlp, const float *d_out, int out_
 int nefii_mlp_wgrad_f16h(const void *dz16, int dz_stride, const void *x, int x_stride, int x_half, int64_t n, int n_out,
                          int k_in, float scale, const float *gscale, float *dW, float *db, void *stream);
 
+/* ABI 12 - nefii_mlp_wgrad_f16h for EVERY layer of a net in (at most) one zero-fill and one launch per kernel form: what
+ * autograd does layer by layer behind RenderingNetwork.forward / diffuse_albedo_layers (one mm + one sum per nn.Linear).
+ * Items are independent; results equal the per-layer calls (the same kernels' bodies on a flat grid). */
+#define NEFII_MAX_WGRAD_ITEMS 12
+typedef struct nefii_wgrad_item {
+    const void *dz16;        /* [n][dz_stride] halves: scale[0] * dz of this layer (nefii_mlp_backward_f16h) */
+    const void *x;           /* the layer's input rows: halves holding 16 h (x_half = 1) or floats (x_half = 0) */
+    float *dW, *db;          /* [n_out][k_in]; [n_out] or NULL */
+    int32_t dz_stride, x_stride, x_half, n_out, k_in;
+    float scale;
+} nefii_wgrad_item;
+int nefii_mlp_wgrad_f16h_batch(const nefii_wgrad_item *h_items, int n_items, int64_t n, const float *gscale, void *stream);
+
 /* The reference's layer-0 concatenation [PE(a) | PE(b) | PE(c) | feat] as a dense [n, width] matrix. */
 int nefii_encode_inputs(const nefii_mlp *h_mlp, const float *in_a, const float *in_b, const float *in_c,
                         const float *feat, int64_t n, float *out, int width, void *stream);
@@ -414,6 +427,14 @@ int nefii_assemble_rows(const nefii_row_block *h_blocks, int n_blocks, const int
                         void *stream);
 int nefii_gather_rows(const nefii_row_block *h_blocks, int n_blocks, const int64_t *where, int64_t n_src, int64_t rows,
                       void *stream);
+
+/* ABI 12 - the inputs of get_rbg_value for the compacted hit rays in one launch (implicit_differentiable_renderer.py:358-364:
+ * points[mask], -ray_dirs[mask]; :537-545: gradient / (norm + 1e-6), view / (norm + 1e-6)): row i of the outputs is taken from
+ * row where[i] of points / ray_dirs / grad [rows, 3] (the SDF gradient at the traced points) and, when feat_cols > 0, of
+ * feat_src [rows, feat_cols] -> pts_out, view_out (= -dir, normalised), nrm_out [n, 3], feat_out [n, feat_cols]. */
+int nefii_prepare_hits(const float *points, const float *ray_dirs, const float *grad, const float *feat_src, int feat_cols,
+                       const int64_t *where, int64_t n, int64_t rows, float *pts_out, float *view_out, float *nrm_out,
+                       float *feat_out, void *stream);
 
 /* MEASUREMENT, not part of the reference's path: what the matrix cores of THIS device sustain on dense fp16 MFMAs with
  * random operands and nothing else in the instruction stream (v_mfma_f32_16x16x32_f16, four accumulator chains per wave,

@@ -51,6 +51,15 @@ class PackSource(ctypes.Structure):
                 ('scale', ctypes.c_float), ('skip_f32', ctypes.c_int32)]
 
 
+class WgradItem(ctypes.Structure):
+    _fields_ = [('dz16', ctypes.c_void_p), ('x', ctypes.c_void_p), ('dW', ctypes.c_void_p), ('db', ctypes.c_void_p),
+                ('dz_stride', ctypes.c_int32), ('x_stride', ctypes.c_int32), ('x_half', ctypes.c_int32),
+                ('n_out', ctypes.c_int32), ('k_in', ctypes.c_int32), ('scale', ctypes.c_float)]
+
+
+MAX_WGRAD_ITEMS = 12
+
+
 class RowBlock(ctypes.Structure):
     _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('cols', ctypes.c_int32), ('src_row_stride', ctypes.c_int32),
                 ('fill', ctypes.c_float), ('reserved', ctypes.c_int32)]
@@ -91,6 +100,7 @@ SIGNATURES = {
     'nefii_mlp_forward_f16h': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P, I, P, I, P, P, P]),
     'nefii_mlp_backward_f16h': (I, [ctypes.POINTER(Mlp), P, I, P, I, P, I64, P, I, P, P]),
     'nefii_mlp_wgrad_f16h': (I, [P, I, P, I, I, I64, I, I, F, P, P, P, P]),
+    'nefii_mlp_wgrad_f16h_batch': (I, [ctypes.POINTER(WgradItem), I, I64, P, P]),
     'nefii_encode_inputs': (I, [ctypes.POINTER(Mlp), P, P, P, P, I64, P, I, P]),
     'nefii_sdf_value_grad': (I, [ctypes.POINTER(Mlp), P, I64, P, I, P, I, P, P, P]),
     'nefii_sdf_value_grad_workspace_bytes': (ctypes.c_size_t, [ctypes.POINTER(Mlp), I64]),
@@ -116,6 +126,7 @@ SIGNATURES = {
     'nefii_camera_rays': (I, [P, P, P, I, I64, P, P, P]),
     'nefii_assemble_rows': (I, [ctypes.POINTER(RowBlock), I, P, I64, I64, P]),
     'nefii_gather_rows': (I, [ctypes.POINTER(RowBlock), I, P, I64, I64, P]),
+    'nefii_prepare_hits': (I, [P, P, P, P, I, P, I64, I64, P, P, P, P, P]),
     'nefii_sg_render_forward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P]),
     'nefii_sg_render_backward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P, P, P, P, P]),
     'nefii_env_radiance_forward': (I, [P, I, P, I64, F, P, P]),

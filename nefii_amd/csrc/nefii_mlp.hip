@@ -1379,19 +1379,20 @@ extern "C" int nefii_mlp_backward_f16h(const nefii_mlp *h_mlp, const float *d_ou
 // fragment (lane (n, p-group): 8 consecutive points), B = x fragment (lane (k, p-group)); fp32 loads (coalesced over the
 // 32 lanes of a point row), converted on the fly.  Same block shape / point split / atomics as mlp_wgrad_kernel.
 // DZ16 / X16: operands stored as halves (S dz / 16 h), see mlp_wgrad16t_kernel.
+// (bx, by, bz, gz: the block's place in the layer's own grid - the batched launch below maps one flat grid onto several layers)
 template <bool DZ16, bool X16>
-__global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const void *__restrict__ dz_v, int dz_stride,
-                                                          const void *__restrict__ x_v, int x_stride, int64_t P, int n_out,
-                                                          int k_in, float scale, const float *__restrict__ gscale,
-                                                          float *__restrict__ dW, float *__restrict__ db, int atomic) {
+__device__ __forceinline__ void wgrad16_body(const void *__restrict__ dz_v, int dz_stride, const void *__restrict__ x_v,
+                                             int x_stride, int64_t P, int n_out, int k_in, float scale,
+                                             const float *__restrict__ gscale, float *__restrict__ dW, float *__restrict__ db,
+                                             int atomic, int bx, int by, int bz, int gz) {
     const float *const dz = static_cast<const float *>(dz_v), *const x = static_cast<const float *>(x_v);
     const _Float16 *const dz16 = static_cast<const _Float16 *>(dz_v), *const x16 = static_cast<const _Float16 *>(x_v);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 64 + (wave & 1) * 32;
-    const int k0 = blockIdx.y * 256 + (wave >> 1) * 128;
-    const int64_t chunk = ((P + gridDim.z - 1) / gridDim.z + 15) & ~(int64_t)15;
-    const int64_t p_begin = (int64_t)blockIdx.z * chunk;
+    const int n0 = bx * 64 + (wave & 1) * 32;
+    const int k0 = by * 256 + (wave >> 1) * 128;
+    const int64_t chunk = ((P + gz - 1) / gz + 15) & ~(int64_t)15;
+    const int64_t p_begin = (int64_t)bz * chunk;
     const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;
     const float S = gscale[0];
     f32x16 acc[4];
@@ -1454,7 +1455,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const void *__restrict
                 }
             }
     }
-    if (db && blockIdx.y == 0 && (wave >> 1) == 0) {
+    if (db && by == 0 && (wave >> 1) == 0) {
         bsum += __shfl_xor(bsum, 32);
         if (DZ16) bsum /= S;
         if (h == 0 && n_ok) {
@@ -1462,6 +1463,15 @@ __global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const void *__restrict
             else db[n0 + i] = bsum;
         }
     }
+}
+
+template <bool DZ16, bool X16>
+__global__ __launch_bounds__(256) void mlp_wgrad16_kernel(const void *__restrict__ dz_v, int dz_stride,
+                                                          const void *__restrict__ x_v, int x_stride, int64_t P, int n_out,
+                                                          int k_in, float scale, const float *__restrict__ gscale,
+                                                          float *__restrict__ dW, float *__restrict__ db, int atomic) {
+    wgrad16_body<DZ16, X16>(dz_v, dz_stride, x_v, x_stride, P, n_out, k_in, scale, gscale, dW, db, atomic, blockIdx.x, blockIdx.y,
+                            blockIdx.z, gridDim.z);
 }
 
 // ---- the same product as a blocked GEMM (layers of at least 64 x 64 weights) ---------------------------------------------
@@ -1493,17 +1503,17 @@ __device__ __forceinline__ half8 wg2_fragment(const _Float16 *tile, int col0, in
 // pass's own rounding), x_v = 16 h in halves (the forward's) - and is copied to LDS with 16-byte loads, eight columns per
 // thread, instead of being loaded as fp32 and rounded here: the same operands bit for bit at half the bytes.
 template <bool XVEC, bool DZ16, bool X16>
-__global__ __launch_bounds__(256, 2) void mlp_wgrad16t_kernel(const void *__restrict__ dz_v, int dz_stride,
-                                                              const void *__restrict__ x_v, int x_stride, int64_t P, int n_out,
-                                                              int k_in, float scale, const float *__restrict__ gscale,
-                                                              float *__restrict__ dW, float *__restrict__ db, int splits,
-                                                              int tiles_n, int tiles_k) {
+__device__ __forceinline__ void wgrad16t_body(const void *__restrict__ dz_v, int dz_stride, const void *__restrict__ x_v,
+                                              int x_stride, int64_t P, int n_out, int k_in, float scale,
+                                              const float *__restrict__ gscale, float *__restrict__ dW, float *__restrict__ db,
+                                              int splits, int tiles_n, int tiles_k, unsigned bid) {
     __shared__ __attribute__((aligned(16))) _Float16 A[2][WG2_ROWS * WG2_STRIDE], B[2][WG2_ROWS * WG2_STRIDE];
     const float *const dz = static_cast<const float *>(dz_v), *const x = static_cast<const float *>(x_v);
     const _Float16 *const dz16 = static_cast<const _Float16 *>(dz_v), *const x16 = static_cast<const _Float16 *>(x_v);
     // XCD-aware order: the tiles_n * tiles_k blocks of one point slice get consecutive positions on one XCD
+    // (bid: the block's index within this layer's own blocks - a multiple of 8 of them, so bid & 7 is the XCD in a batch too)
     const int nt = tiles_n * tiles_k;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int xcd = bid & 7, j = bid >> 3;
     const int tile = j % nt, slice = 8 * (j / nt) + xcd;
     if (slice >= splits) return;
     const int tn = tile % tiles_n, tk = tile / tiles_n;
@@ -1677,6 +1687,56 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad16t_kernel(const void *__rest
     }
 }
 
+template <bool XVEC, bool DZ16, bool X16>
+__global__ __launch_bounds__(256, 2) void mlp_wgrad16t_kernel(const void *__restrict__ dz_v, int dz_stride,
+                                                              const void *__restrict__ x_v, int x_stride, int64_t P, int n_out,
+                                                              int k_in, float scale, const float *__restrict__ gscale,
+                                                              float *__restrict__ dW, float *__restrict__ db, int splits,
+                                                              int tiles_n, int tiles_k) {
+    wgrad16t_body<XVEC, DZ16, X16>(dz_v, dz_stride, x_v, x_stride, P, n_out, k_in, scale, gscale, dW, db, splits, tiles_n, tiles_k,
+                                   blockIdx.x);
+}
+
+// ---- every layer of a net in one launch (nefii_mlp_wgrad_f16h_batch) -----------------------------------------------------
+// The weight gradients of a net's layers are independent GEMMs over the same points; one launch per layer (plus one zero-fill
+// each) is 2 L dependent launches in the step's tail - config 1's five 18-us launches ran one after the other.  Here one
+// grid covers all layers of a group (same kernel, same operand forms): block -> (layer, block of that layer's own grid).
+struct WgradBatch {
+    nefii_wgrad_item it[NEFII_MAX_WGRAD_ITEMS];
+    unsigned first[NEFII_MAX_WGRAD_ITEMS + 1];      // first flat block of item i; first[n] = total
+    int aux0[NEFII_MAX_WGRAD_ITEMS], aux1[NEFII_MAX_WGRAD_ITEMS], aux2[NEFII_MAX_WGRAD_ITEMS];
+    int n;
+};
+__device__ __forceinline__ int wgrad_batch_item(const WgradBatch &b, unsigned bid) {
+    int i = 0;
+    while (i + 1 < b.n && bid >= b.first[i + 1]) ++i;
+    return __builtin_amdgcn_readfirstlane(i);
+}
+// aux0 / aux1 / aux2 = splits / tiles_n / tiles_k
+template <bool XVEC, bool X16>
+__global__ __launch_bounds__(256, 2) void mlp_wgrad16t_batch_kernel(WgradBatch b, int64_t P, const float *__restrict__ gscale) {
+    const int i = wgrad_batch_item(b, blockIdx.x);
+    const nefii_wgrad_item &w = b.it[i];
+    wgrad16t_body<XVEC, true, X16>(w.dz16, w.dz_stride, w.x, w.x_stride, P, w.n_out, w.k_in, w.scale, gscale, w.dW, w.db, b.aux0[i],
+                                   b.aux1[i], b.aux2[i], blockIdx.x - b.first[i]);
+}
+// aux0 / aux1 / aux2 = grid x / grid y / point splits (grid z)
+template <bool X16>
+__global__ __launch_bounds__(256) void mlp_wgrad16_batch_kernel(WgradBatch b, int64_t P, const float *__restrict__ gscale) {
+    const int i = wgrad_batch_item(b, blockIdx.x);
+    const nefii_wgrad_item &w = b.it[i];
+    const int local = blockIdx.x - b.first[i], gx = b.aux0[i], gy = b.aux1[i], gz = b.aux2[i];
+    wgrad16_body<true, X16>(w.dz16, w.dz_stride, w.x, w.x_stride, P, w.n_out, w.k_in, w.scale, gscale, w.dW, w.db, gz > 1 ? 1 : 0,
+                            local % gx, (local / gx) % gy, local / (gx * gy), gz);
+}
+__global__ void zero_fill_batch_kernel(WgradBatch b) {
+    const int i = wgrad_batch_item(b, blockIdx.x);
+    const nefii_wgrad_item &w = b.it[i];
+    const size_t e = (size_t)(blockIdx.x - b.first[i]) * blockDim.x + threadIdx.x, nw = (size_t)w.n_out * w.k_in;
+    if (e < nw) w.dW[e] = 0.f;
+    else if (w.db && e - nw < (size_t)w.n_out) w.db[e - nw] = 0.f;
+}
+
 // NEFII_WGRAD_TR=0: keep the scalar-load kernel (A/B measurements)
 static bool wgrad_tr_enabled() {
     static const bool v = [] {
@@ -1768,6 +1828,80 @@ extern "C" int nefii_mlp_wgrad_f16h(const void *dz16, int dz_stride, const void 
         hipLaunchKernelGGL((mlp_wgrad16_kernel<true, false>), grid, dim3(256), 0, st, dz16, dz_stride, x, x_stride, n, n_out, k_in,
                            scale, gscale, dW, db, split > 1 ? 1 : 0);
     HIP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int nefii_mlp_wgrad_f16h_batch(const nefii_wgrad_item *h_items, int n_items, int64_t n, const float *gscale,
+                                          void *stream) {
+    if (!h_items || !gscale || n_items < 1 || n_items > NEFII_MAX_WGRAD_ITEMS) return NEFII_E_ARG;
+    for (int i = 0; i < n_items; ++i) {
+        const nefii_wgrad_item &w = h_items[i];
+        if (!w.dz16 || !w.x || !w.dW || w.n_out <= 0 || w.k_in <= 0) return NEFII_E_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int split = (int)((n + 255) / 256);       // the scalar-load kernel: <= 256 points per workgroup
+    if (split < 1) split = 1;
+    if (split > 64) split = 64;
+    // one zero-fill for every accumulated output (the blocked kernel always accumulates, the scalar one when it splits the points)
+    {
+        WgradBatch z;
+        z.n = 0;
+        unsigned at = 0;
+        for (int i = 0; i < n_items; ++i) {
+            const nefii_wgrad_item &w = h_items[i];
+            const bool blocked = wgrad_tr_enabled() && w.n_out >= 64 && w.k_in >= 64 && n >= 1024 && (w.dz_stride & 7) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(w.dz16) & 15) == 0;
+            if (!(blocked || split > 1 || n <= 0)) continue;
+            z.it[z.n] = w;
+            z.first[z.n++] = at;
+            at += (unsigned)(((size_t)w.n_out * w.k_in + (w.db ? w.n_out : 0) + 255) / 256);
+        }
+        z.first[z.n] = at;
+        if (z.n > 0) {
+            hipLaunchKernelGGL(zero_fill_batch_kernel, dim3(at), dim3(256), 0, st, z);
+            HIP_CHECK_LAUNCH();
+        }
+    }
+    if (n <= 0) return 0;
+    // groups: (blocked GEMM | scalar-load kernel) x (x in halves | floats) x (x rows 16-byte loadable | not)
+    for (int kind = 0; kind < 8; ++kind) {
+        const bool want_blocked = kind & 4, want_half = kind & 2, want_vec = kind & 1;
+        WgradBatch b;
+        b.n = 0;
+        unsigned at = 0;
+        for (int i = 0; i < n_items; ++i) {
+            const nefii_wgrad_item &w = h_items[i];
+            const bool blocked = wgrad_tr_enabled() && w.n_out >= 64 && w.k_in >= 64 && n >= 1024 && (w.dz_stride & 7) == 0 &&
+                                 (reinterpret_cast<uintptr_t>(w.dz16) & 15) == 0;
+            const bool xvec = (w.x_stride & (w.x_half ? 7 : 3)) == 0 && (reinterpret_cast<uintptr_t>(w.x) & 15) == 0;
+            if (blocked != want_blocked || (w.x_half != 0) != want_half) continue;
+            if (blocked ? xvec != want_vec : want_vec) continue;      // (the scalar-load kernel has no vector form: one group)
+            b.it[b.n] = w;
+            b.first[b.n] = at;
+            if (blocked) {
+                int splits = (int)((n + WG2_POINTS - 1) / WG2_POINTS);
+                splits = (splits + 7) / 8 * 8;
+                b.aux0[b.n] = splits, b.aux1[b.n] = (w.n_out + 127) / 128, b.aux2[b.n] = (w.k_in + 127) / 128;
+                at += (unsigned)(b.aux1[b.n] * b.aux2[b.n] * splits);
+            } else {
+                b.aux0[b.n] = (w.n_out + 63) / 64, b.aux1[b.n] = (w.k_in + 255) / 256, b.aux2[b.n] = split;
+                at += (unsigned)(b.aux0[b.n] * b.aux1[b.n] * split);
+            }
+            ++b.n;
+        }
+        b.first[b.n] = at;
+        if (b.n == 0) continue;
+        if (want_blocked) {
+            if (want_half && want_vec) hipLaunchKernelGGL((mlp_wgrad16t_batch_kernel<true, true>), dim3(at), dim3(256), 0, st, b, n, gscale);
+            else if (want_half) hipLaunchKernelGGL((mlp_wgrad16t_batch_kernel<false, true>), dim3(at), dim3(256), 0, st, b, n, gscale);
+            else if (want_vec) hipLaunchKernelGGL((mlp_wgrad16t_batch_kernel<true, false>), dim3(at), dim3(256), 0, st, b, n, gscale);
+            else hipLaunchKernelGGL((mlp_wgrad16t_batch_kernel<false, false>), dim3(at), dim3(256), 0, st, b, n, gscale);
+        } else {
+            if (want_half) hipLaunchKernelGGL((mlp_wgrad16_batch_kernel<true>), dim3(at), dim3(256), 0, st, b, n, gscale);
+            else hipLaunchKernelGGL((mlp_wgrad16_batch_kernel<false>), dim3(at), dim3(256), 0, st, b, n, gscale);
+        }
+        HIP_CHECK_LAUNCH();
+    }
     return 0;
 }
 

@@ -1023,6 +1023,51 @@ extern "C" int nefii_assemble_rows(const nefii_row_block *h_blocks, int n_blocks
     return 0;
 }
 
+// The inputs of get_rbg_value for the compacted hit rays (implicit_differentiable_renderer.py:358-364,533-545) in ONE launch:
+// the reference masks points / ray_dirs with the hit mask, negates the directions, evaluates the SDF gradient and divides
+// both by (their norm + 1e-6) - ten eager ops on [n_hit, 3] tensors.  One thread per hit ray; the feature rows (feat_src:
+// [rows, feat_cols], or NULL) are copied by the same grid (feat_cols / 4 more threads per ray when feat_cols > 0).
+__global__ __launch_bounds__(256) void prepare_hits_kernel(const float *__restrict__ points, const float *__restrict__ ray_dirs,
+                                                           const float *__restrict__ grad, const float *__restrict__ feat_src,
+                                                           int feat_cols, const int64_t *__restrict__ where, int64_t n,
+                                                           int64_t rows, float *__restrict__ pts_out, float *__restrict__ view_out,
+                                                           float *__restrict__ nrm_out, float *__restrict__ feat_out) {
+    const int per = 1 + (feat_cols + 3) / 4;
+    const int64_t total = n * per;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / per;
+        const int part = (int)(i - r * per);
+        int64_t w = where[r];
+        w = w < 0 ? 0 : (w >= rows ? rows - 1 : w);
+        if (part == 0) {
+            const float px = points[w * 3], py = points[w * 3 + 1], pz = points[w * 3 + 2];
+            pts_out[r * 3] = px, pts_out[r * 3 + 1] = py, pts_out[r * 3 + 2] = pz;
+            const float vx = -ray_dirs[w * 3], vy = -ray_dirs[w * 3 + 1], vz = -ray_dirs[w * 3 + 2];
+            const float vn = __fadd_rn(sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz))), 1e-6f);
+            view_out[r * 3] = vx / vn, view_out[r * 3 + 1] = vy / vn, view_out[r * 3 + 2] = vz / vn;
+            const float gx = grad[w * 3], gy = grad[w * 3 + 1], gz = grad[w * 3 + 2];
+            const float gn = __fadd_rn(sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz))), 1e-6f);
+            nrm_out[r * 3] = gx / gn, nrm_out[r * 3 + 1] = gy / gn, nrm_out[r * 3 + 2] = gz / gn;
+        } else {
+            const int c0 = 4 * (part - 1);
+            for (int c = c0; c < c0 + 4 && c < feat_cols; ++c) feat_out[r * feat_cols + c] = feat_src[w * feat_cols + c];
+        }
+    }
+}
+
+extern "C" int nefii_prepare_hits(const float *points, const float *ray_dirs, const float *grad, const float *feat_src,
+                                  int feat_cols, const int64_t *where, int64_t n, int64_t rows, float *pts_out, float *view_out,
+                                  float *nrm_out, float *feat_out, void *stream) {
+    if (!points || !ray_dirs || !grad || !pts_out || !view_out || !nrm_out || feat_cols < 0) return NEFII_E_ARG;
+    if ((feat_cols > 0) != (feat_src != nullptr) || (feat_cols > 0) != (feat_out != nullptr)) return NEFII_E_ARG;
+    if (rows < 1 || n < 0 || (n > 0 && !where)) return NEFII_E_SHAPE;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(prepare_hits_kernel, dim3(grid_for(n * (1 + (feat_cols + 3) / 4))), dim3(256), 0, (hipStream_t)stream, points,
+                       ray_dirs, grad, feat_src, feat_cols, where, n, rows, pts_out, view_out, nrm_out, feat_out);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int nefii_gather_rows(const nefii_row_block *h_blocks, int n_blocks, const int64_t *where, int64_t n_src,
                                  int64_t rows, void *stream) {
     RowBlocks blocks;

@@ -452,9 +452,15 @@ class IDRNetwork(nn.Module):
                   ('sg_specular_reflection_values', 'sg_specular_reflectance', 3, 0.0))
         ret = {}
         if idx.numel() > 0:
-            if pre is not None:
-                pre = (None, pre[1].index_select(0, idx) if pre[1] is not None else None, pre[2].index_select(0, idx))
-            ret = self.get_rbg_value(points.index_select(0, idx), -ray_dirs.index_select(0, idx), surface=pre)
+            if pre is not None and os.environ.get('NEFII_PREPARE_HITS', '1') != '0':
+                # the gathers of the hit rays and both normalisations in one launch (ops.prepare_hits) instead of ten eager ops
+                with torch.no_grad():
+                    p_h, v_h, n_h, f_h = ops.prepare_hits(points, ray_dirs, pre[2], pre[1], idx)
+                ret = self.get_rbg_value(p_h, v_h, surface=(None, f_h, None), unit=(n_h, v_h))
+            else:
+                if pre is not None:
+                    pre = (None, pre[1].index_select(0, idx) if pre[1] is not None else None, pre[2].index_select(0, idx))
+                ret = self.get_rbg_value(points.index_select(0, idx), -ray_dirs.index_select(0, idx), surface=pre)
             where = idx if dst is None else dst
             # all eight buffers in two launches (+ one for all their gradients) instead of fill / expand / index_put each
             bufs = ops.assemble_rows(where, rows, [f for _, _, _, f in layout], [c for _, _, c, _ in layout],
@@ -513,16 +519,33 @@ class IDRNetwork(nn.Module):
                 'sg_rgb_values': self.mean_pixel(ret['sg_rgb'], N, R)}
 
     # ---- get_rbg_value (:529-599) ------------------------------------------------------------------
-    def get_rbg_value(self, points, view_dirs, multi_ray_data_shape=None, surface=None):
+    def get_rbg_value(self, points, view_dirs, multi_ray_data_shape=None, surface=None, unit=None):
+        """unit (optional): (normals, view_dirs) already normalised (shade_tail's one-launch preparation of the hit rays)."""
         with torch.no_grad():
             # one fused pass replaces the reference's three SDF evaluations of the same points (:354, :533, :537)
             if surface is None:
                 surface = self.implicit_network.value_feature_gradient(points)
             _, feature_vectors, g = surface
-            normals = g / (torch.norm(g, dim=-1, keepdim=True) + 1e-6)
-            view_dirs = view_dirs / (torch.norm(view_dirs, dim=-1, keepdim=True) + 1e-6)
+            if unit is not None:
+                normals, view_dirs = unit
+            else:
+                normals = g / (torch.norm(g, dim=-1, keepdim=True) + 1e-6)
+                view_dirs = view_dirs / (torch.norm(view_dirs, dim=-1, keepdim=True) + 1e-6)
         ret = {'normals': normals}
-        idr_rgb = self.rendering_network(points, normals, view_dirs, feature_vectors)
+        rn = self.rendering_network
+        side = None
+        if rn.outputs_detached and points.is_cuda and torch.is_grad_enabled() and os.environ.get('NEFII_RADIANCE_SIDE', '1') != '0':
+            # A radiance colour that nothing differentiates (physg.conf weights it with 0) is a constant of the step: its
+            # forward runs on a side stream beside the material network's instead of ahead of it in the tail's serial chain
+            # (config 1: 67 us of an 820-us chain).  Inputs were produced on the current stream (the side stream waits for it),
+            # the colour is consumed after the join below.
+            cur = torch.cuda.current_stream()
+            side = ops.side_stream(points.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                idr_rgb = rn(points, normals, view_dirs, feature_vectors)
+        else:
+            idr_rgb = rn(points, normals, view_dirs, feature_vectors)
         mat = self.envmap_material_network(points, feature_vectors, normals)
         ret['idr_rgb'] = idr_rgb
         if self.render_type in ('pt_render_indirect_mlp', 'pt_render_indirect_mlp_memsave'):
@@ -537,6 +560,10 @@ class IDRNetwork(nn.Module):
         ret.update(sg_ret)
         ret.update({'sg_roughness': mat['sg_roughness'], 'sg_specular_reflectance': mat['sg_specular_reflectance'],
                     'sg_blending_weights': mat['sg_blending_weights']})
+        if side is not None:
+            cur.wait_stream(side)
+            if not torch.cuda.is_current_stream_capturing():     # (a capture's pool outlives the graph: nothing to record)
+                idr_rgb.record_stream(cur)
         return ret
 
     def get_background_rgb(self, light_dir):

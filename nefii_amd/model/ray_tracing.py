@@ -100,7 +100,12 @@ class RayTracing(nn.Module):
             return int(env)
         return 4096 if concurrent and n_rays > 1024 else 0
 
-    TIER_DEFAULT = False        # the automatic choice for large batches (tier_for)
+    # The automatic choice (tier_for): on from 32768 rays per tracer call - where evaluations, not round latency, make the
+    # trace (config 3: 226 -> 203 ms per step, config 4: 166 -> 154; config 2's 4096 rays: 2.85 -> 2.74 for up to twice the
+    # rounds of a lone trace) - after the parity protocol of DESIGN.md section 4f: 0 hit-mask flips, depths within 7e-5,
+    # RGB / albedo 5e-5 .. 2.5e-4 of the oracle on the shrunk configs (north-star bound 1e-3).  Results of a batch therefore
+    # depend, at that level, on whether it is big enough to take the tier.
+    TIER_DEFAULT = True
     TIER_MIN_RAYS = 32768
 
     def tier_for(self, n_rays):

@@ -331,6 +331,27 @@ class FusedMLPFn(torch.autograd.Function):
         lib = _lib.lib()
         n = d_out.shape[0]
         gw, gb = [], []
+        if h16 and n > 0 and os.environ.get('NEFII_WGRAD_BATCH', '1') != '0':
+            # every layer's weight gradient in one zero-fill + one launch per kernel form (nefii_mlp_wgrad_f16h_batch): the
+            # per-layer calls below are 2 L dependent launches in the step's tail
+            s0 = pm.specs[0]
+            k_img = stash.x0.shape[1]
+            items = (_lib.WgradItem * L)()
+            outs = []
+            for l, s in enumerate(pm.specs):
+                k = k_img if l == 0 else s.k_in
+                g = torch.empty(s.n_out, k, device=d_out.device, dtype=torch.float32)
+                b = torch.empty(s.n_out, device=d_out.device, dtype=torch.float32)
+                xin, xs = (stash.x0, k_img) if l == 0 else (stash.h[l - 1], pm.hidden_stride)
+                items[l] = _lib.WgradItem(_ptr(dz[l]), _ptr(xin), _ptr(g), _ptr(b), pm.hidden_stride, xs, 1, s.n_out, k, s.scale)
+                outs.append((g, b))
+            _lib.check(lib.nefii_mlp_wgrad_f16h_batch(items, L, n, _ptr(gscale), _stream()), 'nefii_mlp_wgrad_f16h_batch')
+            g_img = outs[0][0]      # layer 0 comes in the image's column order (features | encodings): back to the Linear's
+            kx = lib.nefii_padded_width(s0.x_len)
+            parts = sorted([(s0.x_src0, g_img[:, :s0.x_len]), (s0.e_src0, g_img[:, kx:kx + s0.e_len])], key=lambda t: t[0])
+            gw = [torch.cat([t[1] for t in parts if t[1].shape[1]], dim=1)] + [g for g, _ in outs[1:]]
+            gb = [b for _, b in outs]
+            return (None, None, None, None, None) + tuple(gw) + tuple(gb)
         if h16:     # layer 0's input left by the forward: no encoded matrix to rebuild, dW0 comes in the image's column order
             s0 = pm.specs[0]
             k_img = stash.x0.shape[1]
@@ -505,6 +526,19 @@ class TraceRounds:
 
 _TRACE_STREAMS = {}
 _WORK = [0, 1, 2, 4, 5, 9]   # counter columns that mean "a ray still waits for an evaluation"
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(dev):
+    """One process-wide side stream per device for work that may run beside the caller's serial chain (a detached radiance
+    forward, model/implicit_differentiable_renderer.py:get_rbg_value)."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=key)
+    return st
 
 
 def _trace_streams(dev, n):
@@ -749,6 +783,24 @@ class AssembleRowsFn(torch.autograd.Function):
                 r = r.sum(dim=1, keepdim=True) if shapes[k][-1] == 1 and cols[k] != 1 else r
                 res[k] = r.reshape(shapes[k])
         return (None, None, None, None) + tuple(res)
+
+
+def prepare_hits(points, ray_dirs, grad, feat, idx):
+    """(points[idx], view = -ray_dirs[idx] / (norm + 1e-6), normals = grad[idx] / (norm + 1e-6), feat[idx] or None) in one
+    launch (nefii_prepare_hits); constants of the autograd graph (frozen geometry)."""
+    n = idx.shape[0]
+    dev = points.device
+    pts = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    view = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    nrm = torch.empty(n, 3, device=dev, dtype=torch.float32)
+    fcols = 0 if feat is None else feat.shape[1]
+    fout = None if feat is None else torch.empty(n, fcols, device=dev, dtype=torch.float32)
+    if n > 0:
+        p_, d_, g_ = _f32(points), _f32(ray_dirs), _f32(grad)
+        f_ = None if feat is None else _f32(feat)
+        _lib.check(_lib.lib().nefii_prepare_hits(_ptr(p_), _ptr(d_), _ptr(g_), _ptr(f_), fcols, _ptr(idx), n, p_.shape[0],
+                                                 _ptr(pts), _ptr(view), _ptr(nrm), _ptr(fout), _stream()), 'nefii_prepare_hits')
+    return pts, view, nrm, fout
 
 
 def assemble_rows(where, rows, fills, cols, srcs):

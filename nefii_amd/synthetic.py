@@ -349,16 +349,19 @@ WORKLOADS = {
     # rays go through the min-SDF search); a side measurement of bench.py, not a BASELINE config
     'cfg2_near': dict(model='physg', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 1.6), num_rays=-1,
                       scene=None),
-    # configs 3-5: the non-convex stand-in, embedded WITHOUT zero weights ('bowl_dense'; rounds 2-4 used the zero-padded
-    # 'bowl', whose 98 % zero weights cost a power-limited part 18 % less time per step than a dense network does: DESIGN 4d)
+    # configs 3-5: the non-convex stand-in (a ball in a tilted bowl) as the conf's OWN network trained at full width by the
+    # Step-1 runner ('bowl_trained', round 5: tools/train_scene_sdf.py).  Before: the 8 x 64 fit replicated across the wide
+    # layers without zero weights ('bowl_dense', end of round 4: rank-64 structure - its single-pass error, hence coarse_tau,
+    # is twice the trained net's, and config 3 takes 6 % longer on it) and, in rounds 2-4, zero-padded ('bowl': 98 % zero
+    # weights cost a power-limited part 18 % less time per step than a dense network does: DESIGN 4d)
     'cfg3': dict(model='conf', num_pixels=4096, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64,
-                 scene='bowl_dense'),
+                 scene='bowl_trained'),
     'cfg4': dict(model='neus', num_pixels=8192, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=64,
-                 scene='bowl_dense'),
+                 scene='bowl_trained'),
     # config 5: eval-mode full-frame render (render.py: 800 x 800 pixels in raster order, 256 rays per pixel,
     # memory_capacity_level 18, chunks dealt round-robin over the ranks); num_pixels = pixels per frame
     'cfg5': dict(model='conf', num_pixels=640000, image_hw=(800, 800), focal=1111.0, cam_pos=(0., 0., 2.4), num_rays=256,
-                 scene='bowl_dense', eval=True, memory_capacity_level=18),
+                 scene='bowl_trained', eval=True, memory_capacity_level=18),
 }
 
 

@@ -56,14 +56,20 @@ def mc_flagged_rays(out, ref, hit, rhit, dir_tol=1e-3):
     return dflag | mflag, int(dflag.sum()), int(mflag.sum())
 
 
+NORTH_STAR_KEYS = ('sg_rgb_values', 'sg_diffuse_albedo_values')
+
+
 def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel=1, ray_hit=None, ref_ray_hit=None,
-                    max_explained_frac=0.0, sdf_outliers=0):
+                    max_explained_frac=0.0, sdf_outliers=0, tol_aux=None, tol_points=1e-4):
     """`out` (HIP path) against `ref` (oracle output or reference-generated fixture), per pixel.
 
     ray_hit / ref_ray_hit: the per-ray hit masks of both sides (model.last_ray_hit, oracle '_ray_hit' / fixture
     'ray_hit'); with them, pixels containing a ray with a discrete Monte-Carlo difference (mc_flagged_rays) are excluded
     from the three MC-shaded colour keys - at most max_explained_frac of the pixels - and every other pixel is compared
-    untrimmed."""
+    untrimmed.  tol_aux (default tol_rgb): the bound of every key OTHER than the two the north star names (rendered RGB, albedo)
+    - the tiered sphere tracing moves hit points by up to ~sdf_threshold / cos, and the random-weight material network of the
+    synthetic workloads (PE10: 2^9 x position) turns that into 2-3e-3 on the roughness channel."""
+    tol_aux = tol_rgb if tol_aux is None else tol_aux
     net, rnet = out['network_object_mask'].cpu(), ref['network_object_mask']
     flips = (net != rnet).sum().item()
     _check(flips <= max_flips, (what, 'hit-mask flips', flips))
@@ -90,7 +96,7 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel
             h = rnet[keep]
             if k == 'points':
                 figures.append('|d point| max %.2e' % ((a[h] - b[h]).abs().max().item() if h.any() else 0.0))
-                _check(rel_l2(a[h], b[h]) < 1e-4, (what, k, rel_l2(a[h], b[h])))
+                _check(rel_l2(a[h], b[h]) < tol_points, (what, k, rel_l2(a[h], b[h])))
             else:      # |sdf| <= 5e-5 on the surface: absolute comparison (sdf_outliers: hit rays allowed beyond it -
                 # large samples contain the odd ray whose bisection bracket differs by one sample)
                 _check(int(((a[h] - b[h]).abs() >= 2e-4).sum()) <= sdf_outliers, (what, k, (a[h] - b[h]).abs().max().item()))
@@ -108,9 +114,9 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel
             total = ref['sg_rgb_values'][keep]
             err = (a.float() - b.float()).norm().item()
             _check(err / (total.norm().item() + 1e-12) < tol_rgb, (what, k, 'vs rgb', err / total.norm().item()))
-            _check(rel_l2(a, b) < 10 * tol_rgb, (what, k, rel_l2(a, b)))
+            _check(rel_l2(a, b) < 10 * tol_aux, (what, k, rel_l2(a, b)))
             continue
-        _check(rel_l2(a, b) < tol_rgb, (what, k, rel_l2(a, b)))
+        _check(rel_l2(a, b) < (tol_rgb if k in NORTH_STAR_KEYS else tol_aux), (what, k, rel_l2(a, b)))
     print('[parity %s] rel-L2: %s' % (what, ', '.join(figures)))
     # the excluded pixels are not unchecked: everything that does not pass through the sampler still has to agree there
     # (above: normals, albedo, roughness, idr_rgb over all `agree` pixels), and their colours must stay finite

@@ -91,3 +91,37 @@ def test_sdf_dataset_items_and_collate():
     loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, collate_fn=ds.collate_fn)
     pts, sdf = next(iter(loader))
     assert pts.shape == (256, 3) and sdf.shape == (256, 1)
+
+
+def test_trained_stand_in_geometries_load_and_are_the_scenes_they_were_trained_on():
+    """nefii_amd/assets/scene_{bowl,frame}_sdf512.npz, scene_bowl_sdf256.npz: the conf's own SDF network trained at full width
+    by the Step-1 runner on an analytic scene (tools/train_scene_sdf.py, round 5; weight_v stored in halves).  They load into
+    the confs' shapes through synthetic.make_state_dict(scene='..._trained'), every effective weight keeps a full fp32 mantissa
+    (the row scale g / |v| is an fp32 number: no all-zero lo fragments that would flatter the evaluators), and the
+    oracle's SDF on them is the analytic scene's to the fit's accuracy, with the signs of the landmark points right."""
+    import os
+    import sys
+    import torch
+    from nefii_amd import synthetic as syn
+    from oracle import nets
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import scenes
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(4000, 3, generator=g) * 0.45
+    x = x[x.norm(dim=1) < 1.0]
+    for scene, model in (('bowl_trained', 'conf'), ('frame_trained', 'conf'), ('bowl_trained', 'neus'), ('bowl_trained', 'physg')):
+        mc = syn.model_conf(model)
+        sd = syn.make_state_dict(mc, seed=0, scene=scene)
+        cfg = mc['implicit_network']
+        with torch.no_grad():
+            y = nets.sdf_forward(sd, cfg, x)[:, 0]
+        t = scenes.SCENES[scene.split('_')[0]](x)
+        err = (y - t).abs()
+        assert err.mean().item() < 5e-4 and err.max().item() < 2e-2, (scene, model, err.mean().item(), err.max().item())
+        assert ((y > 0) == (t > 0))[t.abs() > 2e-3].all()
+        w, _ = nets.linear_params(sd, 'implicit_network.lin3')
+        assert ((w * 64).half().float() == w * 64).float().mean().item() < 0.01      # lo halves are live
+        for k, v in sd.items():
+            assert torch.isfinite(v).all(), k
+    with pytest.raises(FileNotFoundError):
+        syn.make_state_dict(syn.model_conf('physg', hidden=128), seed=0, scene='bowl_trained')      # (no 128-wide asset)

@@ -62,11 +62,14 @@ SHRUNK = {'cfg2': 256, 'cfg3': 48, 'cfg4': 48}
 # (a sampled lobe that differs = a uniform draw within rounding of a CDF boundary: 3 rays of config 3's 3072 with the
 # replicated embedding of the stand-in geometry, whose feature vector - and with it the lobe weights - differs from the
 # zero-padded one's, where it was 0-1 by box)
-PINNED_DISCRETE = {'cfg2': {'flips': 0}, 'cfg3': {'flips': 0, 'dir': 5, 'vis': 0}, 'cfg3-bowl': {'flips': 0, 'dir': 2, 'vis': 0},
-                   'cfg4': {'flips': 0}}
+PINNED_DISCRETE = {'cfg2': {'flips': 0}, 'cfg3': {'flips': 0, 'dir': 2, 'vis': 0}, 'cfg3-bowl': {'flips': 0, 'dir': 2, 'vis': 0},
+                   'cfg3-dense': {'flips': 0, 'dir': 5, 'vis': 0}, 'cfg4': {'flips': 0}, 'cfg4-dense': {'flips': 0},
+                   'cfg3-tier': {'flips': 0, 'dir': 20, 'vis': 0}, 'cfg4-tier': {'flips': 0},
+                   'cfg3-dense-tier': {'flips': 0, 'dir': 30, 'vis': 0}, 'cfg3-frame': {'flips': 2, 'dir': 8, 'vis': 2}}
 
 
-@pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg3-bowl', 'cfg4'])
+@pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg3-bowl', 'cfg3-dense', 'cfg4', 'cfg4-dense', 'cfg3-tier', 'cfg4-tier',
+                                'cfg3-dense-tier', 'cfg3-frame'])
 def test_config_shrunk_in_pixels_vs_oracle(wl):
     """The config's model at full network width, its geometry stand-in, camera and rays per pixel (64 for configs 3-4);
     only the number of pixels is reduced.  Forward + IDRLoss + backward against the CPU oracle with injected draws:
@@ -76,11 +79,25 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
     # 'cfg3-bowl': config 3 on the ZERO-PADDED embedding of its stand-in geometry with round 3's gradient bound (3e-3): the
     # bound of the replicated embedding (6e-3) follows that embedding's feature vector, and this case keeps the kernels'
     # arithmetic (half training state included) pinned where the embedding did not move
+    # '-tier': the tiered sphere tracing FORCED on (the full-size configs take it by default, these shrunk ones - 3072 rays -
+    # would not): the one arithmetic of the path that changes values, held here to its parity table:
+    # no hit-mask flip, hit points within 1e-4, RGB and albedo at the north-star 1e-3 (measured 5e-5 .. 2.5e-4), the other
+    # channels at 4e-3 (roughness of the random-weight material net 2.1e-3), at most 30 rays with another sampled lobe
+    # (measured 15), gradients at the untiered bound, evaluation counts within 1 % of the oracle's
+    tier = wl.endswith('-tier')
     bound_key, wl = wl, wl.split('-')[0]
     w = syn.WORKLOADS[wl]
-    mc, sd = syn.workload_state_dict(wl, seed=0, scene='bowl' if bound_key.endswith('-bowl') else None)
+    # the configs' own stand-in is the network TRAINED at full width by the Step-1 runner (tools/train_scene_sdf.py;
+    # nefii_amd/assets/scene_*_sdf512.npz); '-dense' / '-bowl': round 4's replicated / rounds 2-4's zero-padded embedding of the
+    # 8 x 64 fit; '-frame': the network trained on the thin-feature scene
+    scene = None
+    for part in bound_key.split('-')[1:]:
+        scene = {'bowl': 'bowl', 'dense': 'bowl_dense', 'frame': 'frame_trained'}.get(part, scene)
+    mc, sd = syn.workload_state_dict(wl, seed=0, scene=scene)
     lc = syn.loss_conf(w['model'])
-    inp, gt = syn.make_inputs(SHRUNK[wl], w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
+    # (the 12 patches of seed 1 all miss the thin frame; seed 4's see bars, plate and ball: hit fraction 0.24)
+    inp, gt = syn.make_inputs(SHRUNK[wl], w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'],
+                              seed=4 if scene == 'frame_trained' else 1)
     flat, gt_flat, R = per_ray_layout(inp, gt)
     n_ray = flat['uv'].shape[1]
     g = torch.Generator().manual_seed(5)
@@ -106,9 +123,14 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
     m.ray_tracer.minsdf_steps_override = [steps1, steps2] if mc_shading else steps1
     m.ray_tracer.collect_counters = True
     m.ray_tracer.counter_sum = None
+    m.ray_tracer.trace_tier = tier
     out = gpu_forward_with_per_ray_draws(m, to_dev(flat), uniforms)
-    stats = compare_outputs(out, ref, max_flips=max(2, n_ray // 1000), what=wl + ' shrunk', rays_per_pixel=1,
-                            ray_hit=m.last_ray_hit, ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02)
+    stats = compare_outputs(out, ref, max_flips=max(2, n_ray // 1000), what=bound_key + ' shrunk', rays_per_pixel=1,
+                            ray_hit=m.last_ray_hit, ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02,
+                            tol_aux=4e-3 if tier else None)
+    if tier:
+        c9 = m.ray_tracer.counter_sum[:, 9].sum().item()
+        assert c9 > 0.3 * (c9 + m.ray_tracer.counter_sum[:, 0].sum().item()), 'the tier did not run'
     print('[%s] %d rays, oracle %.1f s, hit fraction %.3f, discrete differences %s' % (
         wl, n_ray, t_oracle, ref['_ray_hit'].float().mean(), stats))
     # where the measured count of discrete differences IS zero it is asserted to be zero (the allowances above are for
@@ -117,7 +139,8 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
         assert stats[k] <= allowed, (bound_key, k, stats[k], allowed)
     if mc_shading:
         sm, rsm = m.last_ray_hit.cpu(), ref['_ray_hit']
-        assert ref['secondary_mask'].float().mean().item() > 0.2          # the indirect branch does real work here
+        # the indirect branch does real work here (the thin frame re-hits itself less often than the bowl)
+        assert ref['secondary_mask'].float().mean().item() > (0.03 if scene == 'frame_trained' else 0.2)
         if torch.equal(sm, rsm):
             assert (out['secondary_mask'].cpu() != ref['secondary_mask']).float().mean().item() < 0.005
     # ---- loss and gradients (rays with a discrete MC difference are part of both sums: bounded above at 2 % of the rays)
@@ -135,13 +158,18 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
             # backward or the weight-gradient GEMM no longer hides inside a 5e-2 bound.  What this check can NOT resolve:
             # the oracle itself sits 1.8e-3 from the reference on `rendering_network.lin0.bias` of the full-width fixture
             # (forward_conf512_train: CPU fp32 against CPU fp32, the summation order of a tiny gradient) - on such biases
-            # a difference below ~2e-3 is within the oracle's own distance from the reference.  Config 3's bound follows the
-            # replicated embedding of its stand-in geometry (end of round 4): that same bias measures 4.0e-3 there, with the
-            # fp32 and with the fp16 training state alike (tools/experiments/grad_probe.py) - the one-pass fp16 backward on
-            # a feature vector of 512 live entries instead of 64.  The per-parameter table for both embeddings and three
-            # arithmetics of the MLPs' training path: profiles/r05/grad_probe_cfg3.txt (tools/experiments/grad_probe.py)
-            assert rel_l2(p.grad, gref) < {'cfg2': 1.5e-3, 'cfg3': 6e-3, 'cfg3-bowl': 3e-3, 'cfg4': 6e-3}[bound_key], \
-                (name, rel_l2(p.grad, gref))
+            # a difference below ~2e-3 is within the oracle's own distance from the reference.  The bounds of the
+            # replicated embedding ('-dense': 6e-3) follow what it measures - 4.9e-3 on the radiance net's first layers - and
+            # round 5's per-parameter table (profiles/r05/grad_probe_cfg3.txt, tools/experiments/grad_probe.py) says what that
+            # is: the SAME figure with the exact-fp32 MLP kernels and with either training state, i.e. not the fp16 backward,
+            # and the fp32 oracle itself 2.4e-3 from the same oracle in fp64 on those parameters (1.1e-3 on the zero-padded
+            # embedding, where everything measures < 1e-3): gradients that are sums with heavy cancellation.  On the trained
+            # network (the configs' own stand-in now) the worst parameter measures 1.5e-3.
+            # ('-tier': hit points move within ~sdf_threshold / cos and the radiance net's first-layer gradients - sums with heavy
+            # cancellation, on which the fp32 oracle itself is 2.4e-3 from an fp64 one - follow: 8.2e-3 measured)
+            assert rel_l2(p.grad, gref) < {'cfg2': 1.5e-3, 'cfg3': 3e-3, 'cfg3-bowl': 3e-3, 'cfg3-dense': 6e-3, 'cfg4': 6e-3,
+                                           'cfg4-dense': 6e-3, 'cfg3-tier': 1.5e-2, 'cfg4-tier': 1.2e-2, 'cfg3-dense-tier': 1.5e-2,
+                                           'cfg3-frame': 6e-3}[bound_key], (name, rel_l2(p.grad, gref))
     print('[%s] worst parameter-gradient rel-L2 %.2e' % (wl, worst))
     # ---- algorithmic SDF evaluations: tracer counters (primary + secondary traces) = the oracle's evaluation counts
     cnt = m.ray_tracer.counter_sum.cpu().long()
@@ -153,7 +181,7 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
     if R > 1:
         m.ray_tracer._calls = 0
         ctx = m.trace_head(to_dev(inp))
-        assert torch.equal(ctx['network_object_mask'], m.last_ray_hit)
+        assert torch.equal(ctx['network_object_mask'], m.last_ray_hit)      # (same rays, same tier: the same trace)
         m.uniforms_override = uniforms.to(DEV)[ctx['network_object_mask']]
         with torch.no_grad():
             multi = m.shade_tail(ctx, torch.nonzero(ctx['network_object_mask']).flatten())

@@ -1,6 +1,7 @@
 """Parity protocol of the tiered sphere tracing (nefii_tracer_params.trace_tier; VERDICT r4 next #1a), part A: the tracer alone.
 
-For each geometry (config 3's dense stand-in, config 4's 256-wide one, the geometric-init sphere, a bumpy one) and each ray
+For each geometry (the trained stand-ins of configs 3 / 4, the thin-feature scene, round 4's replicated stand-in, the geometric-init
+sphere, a bumpy one) and each ray
 set (primary rays of the config's camera; secondary rays from the primary hits into a random hemisphere, as
 pt_render_indirect_mlp starts them) the same rays are traced three ways -
 
@@ -29,7 +30,7 @@ from oracle import nets, tracer
 
 DEV = 'cuda:0'
 ORACLE_RAYS = int(os.environ.get('TIER_ORACLE_RAYS', '3072'))
-TIERS = [(2.0, 4.0), (2.0, 8.0), (3.0, 4.0), (1.05, 2.0)]
+TIERS = [(2.0, 4.0), (2.0, 8.0), (3.0, 4.0), (2.0, 2.0)]
 
 
 def build_sdf(mc, sd):
@@ -87,8 +88,10 @@ def work(c, ns=100):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
     torch.manual_seed(0)
-    cases = [('cfg3 geometry (conf 8x512, dense stand-in)', 'conf', dict(scene='bowl_dense'), 'cfg3'),
-             ('cfg4 geometry (neus 8x256, dense stand-in)', 'neus', dict(scene='bowl_dense'), 'cfg4'),
+    cases = [('cfg3 geometry (conf 8x512 TRAINED on the bowl scene: the headline stand-in)', 'conf', dict(scene='bowl_trained'), 'cfg3'),
+             ('cfg4 geometry (neus 8x256 TRAINED on the bowl scene)', 'neus', dict(scene='bowl_trained'), 'cfg4'),
+             ('thin-feature scene (conf 8x512 trained on the cube frame)', 'conf', dict(scene='frame_trained'), 'cfg3'),
+             ('round 4\'s cfg3 geometry (conf 8x512, 8x64 fit replicated: bowl_dense)', 'conf', dict(scene='bowl_dense'), 'cfg3'),
              ('cfg2 geometry (physg 8x512, geometric-init sphere)', 'physg', dict(), 'cfg2'),
              ('bumpy 8x512 (physg, bumpy 0.004)', 'physg', dict(bumpy=0.004), 'cfg2')]
     for title, name, kw, wl in cases:
