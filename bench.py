@@ -352,7 +352,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     # committed under profiles/ (tools/profile_round.sh; separate FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied
     # by tools/pmc_traffic.py), and only quoted for the workload / kernels it was measured on
     traffic, traffic_source = None, None
-    for rnd in ('r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
         tpath = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic_%s.json' % name)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))

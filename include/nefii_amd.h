@@ -436,6 +436,17 @@ int nefii_prepare_hits(const float *points, const float *ray_dirs, const float *
                        const int64_t *where, int64_t n, int64_t rows, float *pts_out, float *view_out, float *nrm_out,
                        float *feat_out, void *stream);
 
+/* ABI 12 - EnvmapMaterialNetwork.forward's head for GLOBAL roughness / specular parameters (physg.conf;
+ * sg_envmap_material.py:381-414) in one launch each way: rough_out [1] = (1 - 0.089) sigmoid(rough_param[0]) + 0.089,
+ * spec_out [3] = 0.16 sigmoid(spec_param)^2 (n_spec = 1: white specular, the value repeated; 3: per channel); fake_rough /
+ * fake_spec (the warm-up flags, idr_train.py:705-713) put 0.5 in place of the sigmoid.  Backward: d_rough [1], d_spec [3]
+ * (either may be NULL) -> g_rough_param [1], g_spec_param [n_spec] (overwritten). */
+int nefii_material_head_global(const float *rough_param, const float *spec_param, int n_spec, int fake_rough, int fake_spec,
+                               float *rough_out, float *spec_out, void *stream);
+int nefii_material_head_global_backward(const float *rough_param, const float *spec_param, int n_spec, int fake_rough,
+                                        int fake_spec, const float *d_rough, const float *d_spec, float *g_rough_param,
+                                        float *g_spec_param, void *stream);
+
 /* MEASUREMENT, not part of the reference's path: what the matrix cores of THIS device sustain on dense fp16 MFMAs with
  * random operands and nothing else in the instruction stream (v_mfma_f32_16x16x32_f16, four accumulator chains per wave,
  * one wave per SIMD, every CU): runs `groups` groups of 8 MFMAs per wave on 256 workgroups, synchronises, and returns the

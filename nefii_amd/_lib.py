@@ -127,6 +127,8 @@ SIGNATURES = {
     'nefii_assemble_rows': (I, [ctypes.POINTER(RowBlock), I, P, I64, I64, P]),
     'nefii_gather_rows': (I, [ctypes.POINTER(RowBlock), I, P, I64, I64, P]),
     'nefii_prepare_hits': (I, [P, P, P, P, I, P, I64, I64, P, P, P, P, P]),
+    'nefii_material_head_global': (I, [P, P, I, I, I, P, P, P]),
+    'nefii_material_head_global_backward': (I, [P, P, I, I, I, P, P, P, P, P]),
     'nefii_sg_render_forward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P]),
     'nefii_sg_render_backward': (I, [P, I, P, P, P, P, P, I64, P, P, P, P, P, P, P, P]),
     'nefii_env_radiance_forward': (I, [P, I, P, I64, F, P, P]),

@@ -1023,6 +1023,56 @@ extern "C" int nefii_assemble_rows(const nefii_row_block *h_blocks, int n_blocks
     return 0;
 }
 
+// EnvmapMaterialNetwork.forward's scalar head for GLOBAL roughness / specular parameters (physg.conf; sg_envmap_material.py:
+// 381-414): roughness = (1 - 0.089) sigmoid(r) + 0.089, specular = 0.16 sigmoid(s)^2 (white_specular: one value for the three
+// channels), each replaced by 0.5 (before the remap) while its warm-up flag is set - six eager ops on one- to three-element
+// tensors forward and eight backward, in the serial chain of a launch-latency-bound step.  One thread each way.
+__global__ void material_head_global_fwd_kernel(const float *__restrict__ rough_param, const float *__restrict__ spec_param,
+                                                int n_spec, int fake_rough, int fake_spec, float *__restrict__ rough_out,
+                                                float *__restrict__ spec_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float r = 1.f / (1.f + expf(-rough_param[0]));
+    rough_out[0] = fake_rough ? 0.5f : (1.f - 0.089f) * r + 0.089f;
+    for (int c = 0; c < 3; ++c) {
+        const float sg = 1.f / (1.f + expf(-spec_param[n_spec == 3 ? c : 0]));
+        const float v = fake_spec ? 0.5f : sg;
+        spec_out[c] = 0.16f * v * v;
+    }
+}
+__global__ void material_head_global_bwd_kernel(const float *__restrict__ rough_param, const float *__restrict__ spec_param,
+                                                int n_spec, int fake_rough, int fake_spec, const float *__restrict__ d_rough,
+                                                const float *__restrict__ d_spec, float *__restrict__ g_rough_param,
+                                                float *__restrict__ g_spec_param) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float r = 1.f / (1.f + expf(-rough_param[0]));
+    g_rough_param[0] = (fake_rough || !d_rough) ? 0.f : d_rough[0] * (1.f - 0.089f) * r * (1.f - r);
+    for (int c = 0; c < n_spec; ++c) g_spec_param[c] = 0.f;
+    if (!fake_spec && d_spec)
+        for (int c = 0; c < 3; ++c) {
+            const int k = n_spec == 3 ? c : 0;
+            const float sg = 1.f / (1.f + expf(-spec_param[k]));
+            g_spec_param[k] += d_spec[c] * 0.32f * sg * sg * (1.f - sg);
+        }
+}
+
+extern "C" int nefii_material_head_global(const float *rough_param, const float *spec_param, int n_spec, int fake_rough,
+                                          int fake_spec, float *rough_out, float *spec_out, void *stream) {
+    if (!rough_param || !spec_param || !rough_out || !spec_out || (n_spec != 1 && n_spec != 3)) return NEFII_E_ARG;
+    hipLaunchKernelGGL(material_head_global_fwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rough_param, spec_param, n_spec,
+                       fake_rough, fake_spec, rough_out, spec_out);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int nefii_material_head_global_backward(const float *rough_param, const float *spec_param, int n_spec, int fake_rough,
+                                                   int fake_spec, const float *d_rough, const float *d_spec, float *g_rough_param,
+                                                   float *g_spec_param, void *stream) {
+    if (!rough_param || !spec_param || !g_rough_param || !g_spec_param || (n_spec != 1 && n_spec != 3)) return NEFII_E_ARG;
+    hipLaunchKernelGGL(material_head_global_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rough_param, spec_param, n_spec,
+                       fake_rough, fake_spec, d_rough, d_spec, g_rough_param, g_spec_param);
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 // The inputs of get_rbg_value for the compacted hit rays (implicit_differentiable_renderer.py:358-364,533-545) in ONE launch:
 // the reference masks points / ray_dirs with the hit mask, negates the directions, evaluates the SDF gradient and divides
 // both by (their norm + 1e-6) - ten eager ops on [n_hit, 3] tensors.  One thread per hit ray; the feature rows (feat_src:

@@ -534,11 +534,14 @@ class IDRNetwork(nn.Module):
         ret = {'normals': normals}
         rn = self.rendering_network
         side = None
-        if rn.outputs_detached and points.is_cuda and torch.is_grad_enabled() and os.environ.get('NEFII_RADIANCE_SIDE', '1') != '0':
-            # A radiance colour that nothing differentiates (physg.conf weights it with 0) is a constant of the step: its
-            # forward runs on a side stream beside the material network's instead of ahead of it in the tail's serial chain
-            # (config 1: 67 us of an 820-us chain).  Inputs were produced on the current stream (the side stream waits for it),
-            # the colour is consumed after the join below.
+        if rn.outputs_detached and points.is_cuda and torch.is_grad_enabled() and os.environ.get('NEFII_RADIANCE_SIDE', '0') == '1':
+            # MEASURED AND NOT KEPT (round 5; NEFII_RADIANCE_SIDE=1 for A/B runs).  A radiance colour that nothing
+            # differentiates (physg.conf weights it with 0) is a constant of the step, so its forward could run on a side
+            # stream beside the material network's instead of ahead of it in the tail's serial chain (config 1: 67 us of an
+            # 820-us chain) - and the chain did shrink to 514 us, but the step got SLOWER: config 1 0.89 -> 0.98 ms, config 2
+            # 2.76 -> 3.31 (profiles/r05/tail_fusion_ab.txt).  A fifth stream (the graph's parallel branch) lands on a hardware
+            # queue that one of the trace streams already uses, and the tail then waits behind a trace (round 4's
+            # aliased-queues finding again).
             cur = torch.cuda.current_stream()
             side = ops.side_stream(points.device)
             side.wait_stream(cur)

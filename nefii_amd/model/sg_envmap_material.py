@@ -6,6 +6,8 @@ State-dict keys kept: ``diffuse_albedo_layers.{0,2,...}.weight/.bias``, ``lgtSGs
 fix_specular_albedo) and physg.conf (global roughness / specular).  Options no shipped conf enables
 (num_base_materials > 1, separate roughness/specular MLPs, use_normal, 2-D envmap light, correct_normal)
 raise NotImplementedError."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -181,6 +183,14 @@ class EnvmapMaterialNetwork(nn.Module):
         bs = [m.bias for m in lins]
         brdf = ops.FusedMLPFn.apply(self.packed(p.device), p, None, None, feat, *ws, *bs)   # sigmoid head in-kernel
         diffuse_albedo = brdf[..., :3]
+        if (not self.roughness_mlp and not self.specular_mlp and not self.fix_specular_albedo and p.is_cuda and
+                self.specular_reflectance.numel() == (1 if self.white_specular else 3) and
+                os.environ.get('NEFII_MATERIAL_HEAD', '1') != '0'):
+            # global roughness / specular parameters (physg.conf): the whole scalar head in one launch each way
+            roughness, spec = ops.MaterialHeadGlobalFn.apply(self.roughness, self.specular_reflectance, self.fake_roughness,
+                                                             self.fake_specular)
+            return {'sg_lgtSGs': self.get_lgtSGs(), 'sg_specular_reflectance': spec, 'sg_roughness': roughness,
+                    'sg_diffuse_albedo': diffuse_albedo, 'sg_blending_weights': None}
         offset = 3
         if self.roughness_mlp:
             roughness = brdf[..., offset:offset + 1]

@@ -785,6 +785,38 @@ class AssembleRowsFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(res)
 
 
+class MaterialHeadGlobalFn(torch.autograd.Function):
+    """(roughness [1,1], specular [1,3]) from the GLOBAL roughness / specular parameters of physg.conf's material network
+    (nefii_material_head_global): sigmoid, TINNY_ROUGHNESS blend, white-specular expand, warm-up flags and the 0.16 s^2 remap
+    in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, rough_param, spec_param, fake_rough, fake_spec):
+        r_, s_ = _f32(rough_param), _f32(spec_param)
+        rough = torch.empty(1, 1, device=r_.device, dtype=torch.float32)
+        spec = torch.empty(1, 3, device=r_.device, dtype=torch.float32)
+        _lib.check(_lib.lib().nefii_material_head_global(_ptr(r_), _ptr(s_), s_.numel(), int(bool(fake_rough)), int(bool(fake_spec)),
+                                                         _ptr(rough), _ptr(spec), _stream()), 'nefii_material_head_global')
+        ctx.save_for_backward(r_, s_)
+        ctx.flags = (int(bool(fake_rough)), int(bool(fake_spec)))
+        ctx.shapes = (rough_param.shape, spec_param.shape)
+        ctx.set_materialize_grads(False)
+        return rough, spec
+
+    @staticmethod
+    def backward(ctx, d_rough, d_spec):
+        r_, s_ = ctx.saved_tensors
+        if d_rough is None and d_spec is None:
+            return None, None, None, None
+        dr = _f32(d_rough) if d_rough is not None else None
+        ds = _f32(d_spec) if d_spec is not None else None
+        gr, gs = torch.empty_like(r_), torch.empty_like(s_)
+        _lib.check(_lib.lib().nefii_material_head_global_backward(_ptr(r_), _ptr(s_), s_.numel(), ctx.flags[0], ctx.flags[1],
+                                                                  _ptr(dr), _ptr(ds), _ptr(gr), _ptr(gs), _stream()),
+                   'nefii_material_head_global_backward')
+        return gr.reshape(ctx.shapes[0]), gs.reshape(ctx.shapes[1]), None, None
+
+
 def prepare_hits(points, ray_dirs, grad, feat, idx):
     """(points[idx], view = -ray_dirs[idx] / (norm + 1e-6), normals = grad[idx] / (norm + 1e-6), feat[idx] or None) in one
     launch (nefii_prepare_hits); constants of the autograd graph (frozen geometry)."""

@@ -398,6 +398,35 @@ def test_prepare_hits_equals_the_eager_ops(n, rows, F):
         assert f is None
 
 
+@pytest.mark.parametrize('white', [True, False])
+@pytest.mark.parametrize('fake', [(False, False), (True, False), (False, True)])
+def test_material_head_for_global_parameters_equals_the_eager_ops(white, fake):
+    """nefii_material_head_global (+ backward) against EnvmapMaterialNetwork.forward's eager head for global roughness /
+    specular parameters (sg_envmap_material.py:381-414): values and both parameter gradients, with and without the warm-up
+    flags, white and coloured specular."""
+    g = torch.Generator().manual_seed(3)
+    rp = torch.randn(1, 1, generator=g).to(DEV).requires_grad_(True)
+    sp = torch.randn(1, 1 if white else 3, generator=g).to(DEV).requires_grad_(True)
+    w_r, w_s = torch.randn(1, 1, generator=g).to(DEV), torch.randn(1, 3, generator=g).to(DEV)
+    rough, spec = ops.MaterialHeadGlobalFn.apply(rp, sp, fake[0], fake[1])
+    (rough * w_r).sum().add((spec * w_s).sum()).backward()
+    got = (rough.detach(), spec.detach(), rp.grad.clone(), sp.grad.clone())
+    rp.grad = sp.grad = None
+    r = (1 - 0.089) * torch.sigmoid(rp) + 0.089
+    s = torch.sigmoid(sp)
+    if white:
+        s = s.expand((-1, 3))
+    if fake[0]:
+        r = 0 * r + 0.5
+    if fake[1]:
+        s = 0 * s + 0.5
+    s = 0.16 * s ** 2
+    (r * w_r).sum().add((s * w_s).sum()).backward()
+    want = (r.detach(), s.detach(), rp.grad, sp.grad)
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 1e-6 * max(1.0, b.abs().max().item()), (a, b)
+
+
 def test_half_state_entry_points_refuse_what_they_cannot_run():
     """nefii_mlp_*_f16h: a net off the streamed kernels (64-wide hidden layers) is NEFII_E_SHAPE (-2) - ops.py then keeps the
     fp32 stash and the old entry points, which the gradient tests of the hidden = 64 models exercise; a missing array is

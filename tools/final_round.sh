@@ -2,7 +2,7 @@
 # Everything profiles/rNN/ holds for a round, in one gpurun call:  tools/final_round.sh <tag>
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-T=${1:-r04}; O=gpurun_out/$T
+T=${1:-r05}; O=gpurun_out/$T
 mkdir -p $O
 for w in cfg2 cfg3 cfg4; do
     bash tools/profile_round.sh $T $w eval_kernel16 $([ $w = cfg2 ] && echo 20 || echo 10) > $O/log_$w.txt 2>&1
@@ -24,5 +24,12 @@ python3 tools/trace_rounds.py cfg3 2> /dev/null | grep -v "Warning\|WeightNorm\|
 python3 tools/trace_rounds.py cfg2 2> /dev/null | grep -v "Warning\|WeightNorm\|amdgpu" > $O/rounds_cfg2.txt
 (bash tools/pmc_microbench.sh 12) > $O/pmc_microbench_eval_tile.txt 2>&1
 tools/probes/slot_probe > $O/slot_probe.txt 2>&1
+tools/probes/fp8_probe > $O/fp8_probe.txt 2>&1
+python3 tools/tier_parity.py 32768 2>&1 | grep -v "Warning\|WeightNorm\|amdgpu\|warn" > $O/tier_parity_tracer.txt
+python3 tools/experiments/grad_probe.py 2>&1 | grep -v "Warning\|WeightNorm\|amdgpu\|warn" > $O/grad_probe_cfg3.txt
+for tier in 0 1; do
+    NEFII_TRACE_TIER=$tier python3 bench.py --workload cfg3 --steps 10 --warmup 3 --no-cpu-baseline --no-side-measurement 2> /dev/null | tail -1 > $O/bench_cfg3_tier$tier.json
+    NEFII_TRACE_TIER=$tier python3 bench.py --workload cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-side-measurement 2> /dev/null | tail -1 > $O/bench_cfg4_tier$tier.json
+done
 bash tools/power_probe.sh 2>&1 | grep -v "Warn\|amdgpu.ids" | tr ";" "\n" | grep -v "=====" > $O/power_probe.txt
 tail -c 300 $O/bench_default.json
