@@ -1,6 +1,6 @@
 """Per-tile cost of the tracer's SDF tile evaluators - split precision (nefii_sdf_eval) and single pass
 (nefii_sdf_eval_coarse) interleaved in one process: n points = tiles_per_cu x 256 CUs x 64 rows.
-Usage: python tools/eval_microbench.py [tiles_per_cu ...]   (NEFII_LIB_PATH selects an A/B build; MODEL=neus: 8x256 net)"""
+Usage: python tools/eval_microbench.py [tiles_per_cu ...]   (NEFII_LIB_PATH selects an A/B build; MODEL=neus: 8x256 net; SCENE=bowl_trained|frame_trained|bowl_dense|bowl: that geometry's weights)"""
 import os
 import sys
 
@@ -10,7 +10,9 @@ from nefii_amd import ops, synthetic as syn
 from oracle import nets
 
 mc = syn.model_conf(os.environ.get('MODEL', 'physg'))
-sd = syn.make_state_dict(mc, seed=0, bumpy=0.004)
+scene = os.environ.get('SCENE')          # e.g. bowl_trained / frame_trained / bowl_dense / bowl: the tile time follows the operands
+sd = syn.make_state_dict(mc, seed=0, bumpy=0.0 if scene else 0.004, scene=scene)
+print('SDF net: %s, %s' % (os.environ.get('MODEL', 'physg'), scene or 'geometric-init sphere, bumpy 0.004'))
 specs, enc = ops.sdf_specs(mc['implicit_network'], mc['feature_vector_size'])
 pm = ops.PackedMLP(specs, ops.ACT_SOFTPLUS100, ops.HEAD_NONE, enc, 0, 'cuda', f16x3=True)
 ws, bs = zip(*[nets.linear_params(sd, 'implicit_network.lin%d' % l) for l in range(len(specs))])

@@ -12,13 +12,16 @@ for w in cfg3 cfg4; do
     NEFII_BENCH_PREFETCH=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/np -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-side-measurement > $O/bench_${w}_noprefetch_under_rocprof.json 2> /dev/null
     cp $(find /tmp/np -name "*kernel_stats.csv" | head -1) $O/bench_${w}_noprefetch_kernel_stats.csv
 done
-python3 bench.py --workload cfg1 --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_cfg1.json 2> /dev/null
+python3 bench.py --workload cfg1 --steps 60 --warmup 15 --no-cpu-baseline > $O/bench_cfg1.json 2> /dev/null
+rm -rf /tmp/c1; rocprofv3 --kernel-trace --output-format csv -d /tmp/c1 -- python3 bench.py --workload cfg1 --steps 60 --warmup 15 --no-cpu-baseline --no-side-measurement > /dev/null 2>&1
+python3 tools/queue_listing.py $(find /tmp/c1 -name "*kernel_trace.csv" | head -1) 5 > $O/cfg1_tail_listing_after.txt 2>&1
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 (python3 tools/mlp_microbench.py 4096 139264; MODEL=neus python3 tools/mlp_microbench.py 139264; echo "== NEFII_MLP_STREAM=0"
  NEFII_MLP_STREAM=0 python3 tools/mlp_microbench.py 4096 139264; MODEL=neus NEFII_MLP_STREAM=0 python3 tools/mlp_microbench.py 139264
  echo "== NEFII_MLP_H16=0 (fp32 stash and dz)"; NEFII_MLP_H16=0 python3 tools/mlp_microbench.py 4096 139264) 2>&1 | grep -v amdgpu > $O/mlp_microbench.txt
 (python3 tools/wgrad_microbench.py; echo "== NEFII_WGRAD_TR=0"; NEFII_WGRAD_TR=0 python3 tools/wgrad_microbench.py) 2>&1 | grep -v amdgpu > $O/wgrad_microbench.txt
-(python3 tools/eval_microbench.py 1 3 12; MODEL=neus python3 tools/eval_microbench.py 1 3 12) 2>&1 | grep -v amdgpu > $O/eval_microbench.txt
+(python3 tools/eval_microbench.py 1 3 12; MODEL=neus python3 tools/eval_microbench.py 1 3 12
+ for sc in bowl_trained frame_trained bowl_dense bowl; do MODEL=conf SCENE=$sc python3 tools/eval_microbench.py 12; done) 2>&1 | grep -v amdgpu > $O/eval_microbench.txt
 python3 tools/render_bench.py 2> /dev/null | tail -1 > $O/render_cfg5_crop.json
 python3 tools/trace_rounds.py cfg3 2> /dev/null | grep -v "Warning\|WeightNorm\|amdgpu" > $O/rounds_cfg3.txt
 python3 tools/trace_rounds.py cfg2 2> /dev/null | grep -v "Warning\|WeightNorm\|amdgpu" > $O/rounds_cfg2.txt
