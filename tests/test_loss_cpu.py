@@ -74,3 +74,71 @@ def test_train_step_iteration_hooks_follow_the_reference_loop():
     # resuming at iteration 6 re-applies the alpha milestones already passed (idr_train.py:325-327)
     st2 = TrainStep(m, lc, alpha_milestones=[2, 5], alpha_factor=2.0, start_iter=6)
     assert st2.loss.alpha == 4 * a0
+
+
+def test_min_sdf_schedule_sets_the_tracers_switches_for_the_enqueue_only():
+    """TrainStep(min_sdf_every=E) used to leave skip_min_sdf_search / draw_when_skipped set on the SHARED ray
+    tracer - a later TrainStep, or a direct training-mode model(...) call, inherited skip = True.  The switches now exist only
+    inside the context that encloses a trace's enqueue, for the iterations the schedule names, and whatever the caller had set
+    comes back (bench.py's side measurement sets skip itself); E <= 1 and trainable geometry touch nothing."""
+    from nefii_amd import conf, synthetic as syn
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    from nefii_amd.training.step import TrainStep
+    mc = syn.model_conf('physg', hidden=64)
+    m = IDRNetwork(conf.from_dict(mc))
+    m.freeze_geometry()
+    rt = m.ray_tracer
+    st = TrainStep(m, syn.loss_conf('physg'), min_sdf_every=5)
+    seen = {}
+    for it in (0, 1, 4, 5, 7):
+        with st._min_sdf_schedule(it):
+            seen[it] = (rt.skip_min_sdf_search, rt.draw_when_skipped)
+        assert (rt.skip_min_sdf_search, rt.draw_when_skipped) == (False, False)
+    assert seen == {0: (False, True), 1: (True, True), 4: (True, True), 5: (False, True), 7: (True, True)}
+    with st._min_sdf_schedule(6, 7, 8):             # batches traced as one call: none of them reports
+        assert rt.skip_min_sdf_search is True
+    with st._min_sdf_schedule(9, 10, 11):           # iteration 10 reports: the search runs for the group
+        assert rt.skip_min_sdf_search is False
+    rt.skip_min_sdf_search = True                   # a caller's own setting survives
+    with st._min_sdf_schedule(5):
+        assert rt.skip_min_sdf_search is False
+    assert rt.skip_min_sdf_search is True
+    st1 = TrainStep(m, syn.loss_conf('physg'))      # the default: the reference's schedule, nothing is touched
+    assert st1.min_sdf_every == 1
+    with st1._min_sdf_schedule(3):
+        assert rt.skip_min_sdf_search is True and rt.draw_when_skipped is False
+    rt.skip_min_sdf_search = False
+    m.unfreeze_geometry()
+    with st._min_sdf_schedule(1):
+        assert rt.skip_min_sdf_search is False
+
+
+def test_counter_sums_keep_the_audit_column_a_maximum_and_the_parameter_list_cache_notices_replacements():
+    """ADVICE r4 lows.  (1) Column 8 of the tracer's counters holds the BITS of a float (the audit's largest difference):
+    summed over stream groups or traces it must take the maximum, every other column adds.  (2) ops.param_list caches
+    list(module.parameters()); a replaced Parameter object (load_state_dict(assign=True), remove_weight_norm) must not leave
+    the version checks watching dead objects."""
+    from nefii_amd import ops
+    f = lambda x: torch.tensor([x], dtype=torch.float32).view(torch.int32).item()
+    a = torch.zeros(2, 3, 11, dtype=torch.int32)
+    a[0, 1, 0], a[1, 1, 0] = 5, 7
+    a[0, 1, 8], a[1, 1, 8] = f(2.5e-4), f(6.0e-4)
+    a[0, 2, 9], a[1, 2, 9] = 10, 1
+    s = ops.sum_counters(a)
+    assert s.shape == (3, 11) and s[1, 0] == 12 and s[2, 9] == 11
+    assert s[1, 8].to(torch.int32).view(torch.float32).item() == pytest.approx(6.0e-4)
+    b = torch.zeros(3, 11, dtype=torch.int64)
+    b[1, 0], b[1, 8] = 1, f(9.0e-4)
+    t = ops.sum_counters(s, b)
+    assert t[1, 0] == 13 and t[1, 8].to(torch.int32).view(torch.float32).item() == pytest.approx(9.0e-4)
+    assert ops._audit_of(t.unsqueeze(0).to(torch.int32)) == pytest.approx(9.0e-4)
+    lin = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))
+    p0 = ops.param_list(lin)
+    assert ops.param_list(lin) is p0 and len(p0) == 4
+    lin[0].weight = torch.nn.Parameter(torch.zeros(4, 4))          # the FIRST parameter replaced: noticed at once
+    p1 = ops.param_list(lin)
+    assert p1 is not p0 and p1[0] is lin[0].weight
+    lin[1].bias = torch.nn.Parameter(torch.zeros(2))               # a later one: noticed by the periodic full check
+    for _ in range(300):
+        p2 = ops.param_list(lin)
+    assert p2[3] is lin[1].bias

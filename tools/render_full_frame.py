@@ -85,11 +85,17 @@ def main():
         with torch.no_grad():
             ref = Ro.forward(flat, None, uniforms, None)
         res['oracle_seconds'] = time.perf_counter() - t2
+        # the frame's chunks (2^level rays per tracer call) take the tracer's tier; the sample below (n_check x R rays) would
+        # not on its own: it is traced with the same arithmetic as the frame it is compared with
+        tier = bool(m.ray_tracer.tier_for(1 << w['memory_capacity_level']))
+        m.ray_tracer.trace_tier = tier
+        res['trace_tier'] = tier
         with torch.no_grad():
             out = gpu_forward_with_per_ray_draws(m, {k: v.to(dev) for k, v in flat.items()}, uniforms)
+        m.ray_tracer.trace_tier = None
         stats = compare_outputs(out, ref, max_flips=max(4, n_ray // 2000), what='cfg5 frame sample', rays_per_pixel=1,
                                 ray_hit=m.last_ray_hit, ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02,
-                                sdf_outliers=max(1, n_ray // 8000))
+                                sdf_outliers=max(1, n_ray // 8000) + (n_ray // 2000 if tier else 0), tol_aux=4e-3 if tier else None)
         both = (out['network_object_mask'].cpu() == ref['network_object_mask'])
         res['oracle_check'] = {'pixels': int(pick.numel()), 'rays': n_ray, 'hit_ray_fraction': ref['_ray_hit'].float().mean().item(),
                                'rgb_rel_l2': rel_l2(out['sg_rgb_values'][both.to(dev)], ref['sg_rgb_values'][both]),
