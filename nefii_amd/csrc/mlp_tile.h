@@ -1686,6 +1686,230 @@ __device__ __forceinline__ void sdf_tile16s2(const nefii_mlp &m, LdsS2<FT, 16 * 
     }
 }
 
+// ================================================================================================
+// "16d": the single-pass tile on FOUR waves - two independent four-wave GROUPS per workgroup (round 5).
+// "16s" keeps all eight waves of a CU in lockstep: a layer is k-loop -> epilogue -> barrier for every wave, so the two
+// waves of a SIMD want the matrix pipe together and the vector ALU together (pipe busy 54 %, vector issue 50 %,
+// co-execution 17 %), and its two activation images fill the LDS.  Here a group is 4 waves (one per SIMD) over ONE
+// activation image (75 KB), written in place behind a barrier; the two groups of a workgroup work on different tiles and
+// nothing synchronises them - a group's barriers are its own (GroupBarrier: an LDS counter, not s_barrier) - so one group's
+// epilogue and waits sit in the other's k-loop.  (Two 4-wave workgroups per CU do the same, but a CU that holds only one of
+// them has room for foreign waves on its SIMDs: section 4b's register claim needs all eight waves in one workgroup.)
+// A wave owns 128 features (the streams of "16s" waves 2w and 2w + 1, read alternately: unit u = stream u & 1, k-step
+// u >> 1; same 4 KiB unit, same 4 register stages), so an activation fragment read feeds 8 MFMAs instead of 4: half the LDS
+// reads per query.  The accumulation order of every output and the last layer's eight K partitions are those of "16s": the
+// values are bit-identical.
+// ================================================================================================
+// barrier of one four-wave group: every wave adds 1 to the group's LDS counter and waits for 4 x (barriers so far).  LDS
+// operations of a wave complete in order, so the stores before the add are visible to whoever sees the add.
+typedef __attribute__((address_space(3))) unsigned lds_u32;
+struct GroupBarrier {
+    lds_u32 *ctr;
+    unsigned phase;
+    __device__ __forceinline__ GroupBarrier(unsigned *shared_counter) : ctr((lds_u32 *)shared_counter), phase(0u) {}
+    __device__ __forceinline__ void sync() {
+        __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): this wave's LDS stores are done (the prefetches stay in flight)
+        asm volatile("" ::: "memory");
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        phase += 4;
+        while ((int)(__builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)ctr) - phase) < 0) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    }
+    // end of a group's work: its waves stay resident (and keep their registers: section 4b's claim) until all eight are done
+    static __device__ __forceinline__ void hold(unsigned *shared_done) {
+        lds_u32 *d = (lds_u32 *)shared_done;
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(d, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__builtin_amdgcn_readfirstlane(*(volatile lds_u32 *)d) < 8u) __builtin_amdgcn_s_sleep(8);
+    }
+};
+
+template <int QT, int J>
+__device__ __forceinline__ void dstep(SStage<4> (&b)[4], SAct<QT> (&a)[2], PCursor (&cur)[2], const _Float16 *ah, int s32,
+                                      f32x4 (&acc)[8 * QT]) {
+    constexpr int HALF = J & 1, AB = (J >> 1) & 1;
+    sload<4>(b[(J + 3) % 4], cur[(J + 3) & 1]);
+    if constexpr (HALF == 0) sload_a<QT, QGeo<4>::XP>(a[AB ^ 1], ah, s32 + 1);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 &c = acc[(4 * HALF + ft) * QT + qt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[ft], a[AB].h[qt], c, 0, 0, 0);
+        }
+#define NEFII_DGROUP(i)                                                                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, QT / 2, 0);                                       \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                            \
+    __builtin_amdgcn_sched_group_barrier(0x008, QT - QT / 2, 0);                                  \
+    if constexpr (HALF == 0) __builtin_amdgcn_sched_group_barrier(0x100, (QT * ((i) + 1)) / 4 - (QT * (i)) / 4, 0);
+    NEFII_DGROUP(0)
+    NEFII_DGROUP(1)
+    NEFII_DGROUP(2)
+    NEFII_DGROUP(3)
+#undef NEFII_DGROUP
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int QT>
+__device__ __forceinline__ void prime16d(const nefii_mlp &m, SStage<4> (&b)[4], PCursor (&cur)[2]) {
+    const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3), lane = threadIdx.x & 63;
+    int before, G;
+    s_stream_geometry<4>(m, before, G);
+    const half8 *base = reinterpret_cast<const half8 *>(m.w_stream) + (size_t)8 * before * 256;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        cur[h].bytes = (unsigned)G * 4 * 1024;
+        cur[h].base = base + (size_t)(2 * wave + h) * G * 4 * 64 + lane;
+        cur[h].off = 0;
+    }
+    sload<4>(b[0], cur[0]);
+    sload<4>(b[1], cur[1]);
+    sload<4>(b[2], cur[0]);
+}
+
+#ifdef NEFII_STAMPS     /* wave 0 of every workgroup, its third tile: 5 stamps per layer + the hardware id of its CU */
+__device__ unsigned long long g_dstamps[512 * 12 * 5];
+__device__ unsigned g_dhwid[512 * 2];
+#define NEFII_DSTAMP(i)                                                                                  \
+    if (tile_seq == 2 && tl == 0 && blockIdx.x < 256)                                                     \
+        g_dstamps[((2 * blockIdx.x + (threadIdx.x >> 8)) * 12 + l) * 5 + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define NEFII_DSTAMP(i)
+#endif
+template <int QT>
+__device__ __forceinline__ void sdf_tile16d(const nefii_mlp &m, _Float16 *X, float *raw, float *const *dest,
+                                            SStage<4> (&b)[4], PCursor (&cur)[2], GroupBarrier &gb, int tile_seq = 0) {
+    // X, raw, dest: this group's activation image, decoded queries and destinations
+    constexpr int RT = (QT + 1) / 2, XP = QGeo<4>::XP, EP = QGeo<4>::HW, EW = QGeo<4>::EW, RMAX = 16 * QT;
+    const int wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3), lane = threadIdx.x & 63;
+    const int tl = threadIdx.x & 255;
+    const int NH = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    const float k16 = inv_scale * A16_SCALE;
+    const int boff = 128 * wave + lane;
+    float bnext0 = m.layer[0].bias[boff], bnext1 = m.layer[0].bias[boff + 64];   // biases run one layer ahead
+    {
+        const int w0 = enc_width(m.enc_freqs[0]);
+        for (int i = tl; i < RMAX * EW; i += 256) {
+            const int p = i / EW, c = i - p * EW;
+            X[p * XP + EP + c] = (_Float16)((c < w0 ? enc_value(raw + p * 9, c) : 0.f) * A16_SCALE);
+        }
+    }
+    gb.sync();
+    const int qoff = (lane & 15) * XP + 8 * (lane >> 4);
+    for (int l = 0; l < NH; ++l) {
+        const nefii_layer &L = m.layer[l];
+        const int units = s_units(L);
+        const _Float16 *ah = X + qoff + (EP - L.k_x);
+        _Float16 *xh = X + (EP - L.n_pad);
+        const float *bp = m.layer[l + 1 < NH ? l + 1 : l].bias + boff;
+        asm volatile("" ::"s"(units), "v"(ah), "v"(xh), "v"(bp));
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see 16p)
+        __builtin_amdgcn_sched_barrier(0);
+        const float bvec0 = bnext0, bvec1 = bnext1;
+        f32x4 acc[8 * QT];
+#pragma unroll
+        for (int j = 0; j < 8 * QT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+        SAct<QT> a[2];
+        NEFII_DSTAMP(0);
+        sload_a<QT, XP>(a[0], ah, 0);
+        for (int s = 0; s < units; s += 2) {
+            dstep<QT, 0>(b, a, cur, ah, s, acc);
+            dstep<QT, 1>(b, a, cur, ah, s, acc);
+            dstep<QT, 2>(b, a, cur, ah, s + 1, acc);
+            dstep<QT, 3>(b, a, cur, ah, s + 1, acc);
+        }
+        bnext0 = bp[0];
+        bnext1 = bp[64];
+        __builtin_amdgcn_sched_barrier(0);
+        NEFII_DSTAMP(1);
+        gb.sync();        // every wave is done reading the image: the epilogue writes it in place
+        NEFII_DSTAMP(2);
+        auto body = [&](auto fast) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int bsrc = __builtin_bit_cast(int, (h ? bvec1 : bvec0) * A16_SCALE);
+#pragma unroll
+                for (int ft = 0; ft < 4; ++ft) {
+                    const int f0 = 128 * wave + 64 * h + 16 * ft + 4 * (lane >> 4);
+                    float4v bs;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        bs[k] = __builtin_bit_cast(float,
+                                                   __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const f32x4 &av = acc[(4 * h + ft) * QT + qt];
+                        half4 packed;
+                        if constexpr (decltype(fast)::value) {
+                            packed = softplus100_s16_pk4(av, k16, bs);
+                        } else {
+                            float4v hs;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float zs = __builtin_fmaf(av[k], k16, bs[k]);
+                                hs[k] = act_fwd(zs * (1.f / A16_SCALE), m.act) * A16_SCALE;
+                            }
+                            packed = __builtin_convertvector(hs, half4);
+                        }
+                        *reinterpret_cast<half4 *>(xh + (16 * qt + (lane & 15)) * XP + f0) = packed;
+                    }
+                }
+            }
+        };
+        if (m.act == NEFII_ACT_SOFTPLUS100)
+            body(std::true_type{});
+        else
+            body(std::false_type{});
+        NEFII_DSTAMP(3);
+        gb.sync();
+        NEFII_DSTAMP(4);
+    }
+    // last layer, column 0 only: the eight K partitions of "16s", two per wave, summed in its order
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const nefii_layer &L = m.layer[NH];
+        const int NT = L.n_pad >> 5;
+        const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
+        const _Float16 *ah = X + r * XP + 8 * h + (EP - L.k_x);
+        const int ksw = (L.k_x >> 4) / 8;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int part = 2 * wave + p;
+            f32x16 acc2[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
+            for (int u = 0; u < ksw; ++u) {
+                const int s = part * ksw + u;
+                const half8 wh = wl[(size_t)s * NT * 128];
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+                    const half8 xh8 = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP + 16 * s);
+                    acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh8, acc2[rt], 0, 0, 0);
+                }
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    if (32 * rt + r < RMAX) raw[part * RMAX + 32 * rt + r] = acc2[rt][0];
+            }
+        }
+        gb.sync();
+        if (tl < 16 * QT) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += raw[w * RMAX + tl];
+            float *d = dest[tl];
+            if (d) *d = sum * inv_scale + L.bias[0];
+        }
+        gb.sync();
+    }
+}
+
 // accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
 #define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \

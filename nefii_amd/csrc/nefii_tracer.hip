@@ -818,8 +818,7 @@ __device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const
 // queries [0, n_rows): the quarter rows' samples; [n_rows, total): the sphere-tracing queries of the tier (csingles)
 template <int ROWS>
 __device__ __forceinline__ void decode_tile_coarse(const Params &P, int64_t tile, int64_t n_rows, int64_t total, float *raw,
-                                                   float **dest) {
-    const int tid = threadIdx.x;
+                                                   float **dest, int tid = threadIdx.x) {
     if (tid >= ROWS) return;
     const int ns = P.p.n_steps, cw = coarse_window(ns);
     const int64_t q = tile * ROWS + tid;
@@ -1154,6 +1153,85 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16s(nefii_mlp m, cons
     }
 }
 
+// "16d" (mlp_tile.h): the single-pass tile on four waves; a workgroup is two independent four-wave groups, each a persistent
+// worker over its own tiles (tile = 2 x workgroup + group, stride 2 x grid), image, decode buffers and barrier counter
+template <int QT>
+__global__ __launch_bounds__(512, 2) void eval_kernel16d(Params P, nefii_mlp m, int round) {
+    NEFII_CLAIM_SIMD_2();
+    constexpr int ROWS = 16 * QT;
+    __shared__ LdsS2<4, ROWS> lds;
+    __shared__ float raw[2 * ROWS * 9];
+    __shared__ float *dest[2 * ROWS];
+    __shared__ unsigned bar[3];
+    const int64_t n_rows = (int64_t)P.counters[round * NCNT + 5] * coarse_window(P.p.n_steps);
+    const int64_t total = n_rows + P.counters[round * NCNT + 9];
+    const int64_t n_tiles = (total + ROWS - 1) / ROWS;
+    if (blockIdx.x >= n_tiles) return;
+    if (threadIdx.x < 3) bar[threadIdx.x] = 0u;
+    zero_lds_any(lds);      // (ends with the one workgroup barrier of this kernel)
+    const int g = threadIdx.x >> 8;
+    // group 0 takes tiles [0, grid), group 1 [grid, 2 grid), ...: a round of no more tiles than workgroups runs one group per CU
+    if (blockIdx.x + g * (int64_t)gridDim.x < n_tiles) {
+        GroupBarrier gb(&bar[g]);
+        SStage<4> b[4];
+        PCursor cur[2];
+        prime16d<QT>(m, b, cur);
+        for (int64_t tile = blockIdx.x + g * (int64_t)gridDim.x; tile < n_tiles; tile += 2 * (int64_t)gridDim.x) {
+            decode_tile_coarse<ROWS>(P, tile, n_rows, total, raw + g * ROWS * 9, dest + g * ROWS, threadIdx.x & 255);
+            gb.sync();
+            sdf_tile16d<QT>(m, lds.X[g], raw + g * ROWS * 9, dest + g * ROWS, b, cur, gb);
+        }
+    }
+    GroupBarrier::hold(&bar[2]);
+}
+
+template <int QT>
+__global__ __launch_bounds__(512, 2) void sdf_points_kernel16d(nefii_mlp m, const float *__restrict__ x, int64_t n,
+                                                              float *__restrict__ out) {
+    NEFII_CLAIM_SIMD_2();
+    constexpr int ROWS = 16 * QT;
+    __shared__ LdsS2<4, ROWS> lds;
+    __shared__ float raw[2 * ROWS * 9];
+    __shared__ float *dest[2 * ROWS];
+    __shared__ unsigned bar[3];
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
+    if (threadIdx.x < 3) bar[threadIdx.x] = 0u;
+    zero_lds_any(lds);
+    const int g = threadIdx.x >> 8, tl = threadIdx.x & 255;
+    if (blockIdx.x + g * (int64_t)gridDim.x >= n_tiles) {
+        GroupBarrier::hold(&bar[2]);
+        return;
+    }
+    GroupBarrier gb(&bar[g]);
+    SStage<4> b[4];
+    PCursor cur[2];
+    prime16d<QT>(m, b, cur);
+#ifdef NEFII_STAMPS
+    if (tl == 0 && blockIdx.x < 256) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_dhwid[2 * (2 * blockIdx.x + g)] = hw, g_dhwid[2 * (2 * blockIdx.x + g) + 1] = xcc;
+    }
+#endif
+    int seq = 0;
+    float *rawg = raw + g * ROWS * 9;
+    float **destg = dest + g * ROWS;
+    for (int64_t tile = blockIdx.x + g * (int64_t)gridDim.x; tile < n_tiles; tile += 2 * (int64_t)gridDim.x, ++seq) {
+        if (tl < ROWS) {
+            const int64_t q = tile * ROWS + tl;
+            float *rw = rawg + tl * 9;
+            const bool live = q < n;
+            rw[0] = live ? x[q * 3] : 0.f, rw[1] = live ? x[q * 3 + 1] : 0.f, rw[2] = live ? x[q * 3 + 2] : 0.f;
+            rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
+            destg[tl] = live ? out + q : nullptr;
+        }
+        gb.sync();
+        sdf_tile16d<QT>(m, lds.X[g], rawg, destg, b, cur, gb, seq);
+    }
+    GroupBarrier::hold(&bar[2]);
+}
+
 template <int FT>
 __global__ __launch_bounds__(512, 2) void sdf_points_kernel16q(nefii_mlp m, const float *__restrict__ x, int64_t n,
                                                               float *__restrict__ out) {
@@ -1216,6 +1294,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 1 : 2) void sdf_points_kernel16p
 }
 
 #ifdef NEFII_STAMPS
+extern "C" int nefii_debug_dstamps(unsigned long long *host_out, unsigned *hwid_out) {
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_dstamps), sizeof(unsigned long long) * 512 * 12 * 5);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyFromSymbol(hwid_out, HIP_SYMBOL(g_dhwid), sizeof(unsigned) * 1024);
+    return (int)e;
+}
 extern "C" int nefii_debug_stamps(unsigned long long *host_out) {
     int zero = 0;
     hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 2 * 8 * 12 * 5);
@@ -1907,6 +1991,28 @@ int value_grad_stream_launch(const nefii_mlp *m, const float *x, int64_t n, floa
 }
 }  // namespace nefii
 
+// NEFII_COARSE_D=1: 512-wide nets' 64-query single-pass tiles on the two-group form ("16d", mlp_tile.h; bit-identical values).
+// Round 5, same box: 59.6 -> 58.2 us per tile on full rounds, 71.2 -> 84.6 at one tile per CU; config 3 184.1 -> 183.9 ms per
+// step, config 2 2.72 -> 2.75, config 1 0.815 -> 0.849: the tile gains in cycles (layer period 16.0 k -> 11.4 k per tile) what
+// the chip takes back in clock (profiles/r05/two_group_tile/).  As two 4-wave workgroups per CU (no register claim: the
+// packed-fp32 canary fails beside it) config 3 went 185.6 -> 178.7.  Default: the eight-wave form "16s".
+// workgroups of the two-group form: group 0 takes tiles [0, grid), group 1 [grid, 2 grid): one per CU keeps both groups of every
+// CU busy from 257 tiles on
+static unsigned coarse_d_grid() {
+    static const unsigned v = [] {
+        const char *e = getenv("NEFII_COARSE_D_GRID");
+        const int g = e ? atoi(e) : 0;
+        return (unsigned)(g > 0 ? g : 256);
+    }();
+    return v;
+}
+static int coarse_two_groups() {
+    static const int v = [] {
+        const char *e = getenv("NEFII_COARSE_D");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
 // queries per tile of the single-pass evaluator, 16 * QT.  512-wide nets: QT 4 (default) / 6 / 8 (NEFII_COARSE_QT; the big
 // tiles read activation fragments single-buffered and run their epilogue behind the barrier to fit 256 registers).
 // Measured per 64 queries at 12 tiles per CU: 62.0 / 58.9 / 58.3 us, at one tile per CU 77 / 100 / 123 us - the tile is
@@ -1927,11 +2033,14 @@ static int coarse_rows(int ft) {
     return 16 * (q ? q : 4);
 }
 // launches KERNEL<QT, FT, DB> for the configured tile
-#define NEFII_COARSE_LAUNCH(KERNEL, ft, grid, st, ...)                                                              \
+#define NEFII_COARSE_LAUNCH(KERNEL, KERNEL_D, ft, grid, st, ...)                                                    \
     do {                                                                                                            \
         const int rows_ = coarse_rows(ft);                                                                          \
         if ((ft) == 2)                                                                                              \
             hipLaunchKernelGGL((KERNEL<6, 2>), grid, dim3(512), 0, st, __VA_ARGS__);                                \
+        else if (rows_ == 64 && coarse_two_groups())                                                                \
+            hipLaunchKernelGGL((KERNEL_D<4>), dim3((grid).x < coarse_d_grid() ? (grid).x : coarse_d_grid()), dim3(512), 0, st, \
+                               __VA_ARGS__);                                                                    \
         else if (rows_ == 64)                                                                                       \
             hipLaunchKernelGGL((KERNEL<4, 4>), grid, dim3(512), 0, st, __VA_ARGS__);                                \
         else if (rows_ == 96)                                                                                       \
@@ -1952,7 +2061,7 @@ extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int
     const int rows = coarse_rows(ft);
     const int64_t n_tiles = (n + rows - 1) / rows;
     const dim3 grid((int)(n_tiles < 512 ? n_tiles : 512));
-    NEFII_COARSE_LAUNCH(sdf_points_kernel16s, ft, grid, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
+    NEFII_COARSE_LAUNCH(sdf_points_kernel16s, sdf_points_kernel16d, ft, grid, (hipStream_t)stream, *h_sdf, x, n, sdf_out);
     HIP_CHECK_LAUNCH();
     return 0;
 }
@@ -2176,7 +2285,7 @@ int launch_round(const TraceJob &J, int r, bool profile) {
             const int ft = J.pipelined == 2 ? 2 : 4, rows = coarse_rows(ft);
             const int64_t t = (J.P.n * (int64_t)(4 * coarse_window(J.P.p.n_steps) + 2) + rows - 1) / rows;
             const dim3 grid((int)(t < J.eval_blocks_w ? t : J.eval_blocks_w));
-            NEFII_COARSE_LAUNCH(eval_kernel16s, ft, grid, st, J.P, *J.sdf, r);
+            NEFII_COARSE_LAUNCH(eval_kernel16s, eval_kernel16d, ft, grid, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();
         }
         if (profile) (void)hipEventRecord(e1, st);

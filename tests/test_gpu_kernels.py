@@ -1021,6 +1021,28 @@ def test_sdf_eval_coarse_stays_within_its_bound():
         assert 2e-5 < err < 0.5 * tau
 
 
+def test_two_group_single_pass_tile_is_bit_identical(tmp_path):
+    """NEFII_COARSE_D=1 (mlp_tile.h "16d": two independent four-wave groups per workgroup, LDS-counter barriers, one activation
+    image each) against the default eight-wave tile: the same accumulation order, so the same bits - on a point count that
+    leaves a ragged last tile and gives the groups different numbers of tiles.  The switch is read once per process, hence two
+    child processes (each loads the library itself; nothing here touches the GPU before they start)."""
+    import os
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for d in ('0', '1'):
+        out = str(tmp_path / ('coarse_d%s.npy' % d))
+        env = dict(os.environ, NEFII_COARSE_D=d, SCENE='bowl_trained')
+        r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'experiments', 'coarse_d_dump.py'), out, '70001'],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(out))
+    assert np.isfinite(outs[0]).all()
+    assert (outs[0].view(np.uint32) == outs[1].view(np.uint32)).all()
+
+
 @pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg4', 'cfg3:bowl_trained', 'cfg3:frame_trained', 'cfg4:bowl_trained'])
 def test_coarse_bound_holds_where_the_tracer_samples(wl):
     """The coarse pass's identical-decisions argument rests on |single pass - split| < tau for every sample it takes; tau is
