@@ -330,7 +330,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     queries = int(ops.algorithmic_evals(cnt, n_steps).sum().item())
     ex_split, ex_coarse = ops.executed_evals(cnt, n_steps)
     executed, executed_coarse = int(ex_split.sum().item()), int(ex_coarse.sum().item())
-    launches = int((cnt[:, [0, 1, 2, 4, 5, 9]].sum(dim=1) > 0).sum().item())
+    launches = int((cnt[:, [0, 1, 2, 4, 5, 9, 11]].sum(dim=1) > 0).sum().item())
     tier_queries, tier_repeats = int(cnt[:, 9].sum().item()), int(cnt[:, 10].sum().item())
     f_eval = mlp_flops(model.implicit_network.specs)
     achieved = queries * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
@@ -417,6 +417,14 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                 # single-pass evaluator, and how many of them had to be repeated in split precision
                 'trace_tier': bool(model.ray_tracer.tier_for(rays_per_rank)),
                 'tier_queries_single_pass': tier_queries, 'tier_queries_repeated': tier_repeats,
+                # staged min-SDF search (nefii_tracer_params.minsdf_lipschitz): the measured slope bound in use (0: off), the
+                # depths its second stage evaluated one by one (the first stage's are a quarter row per search, counted with
+                # the single-pass evaluations), dense searches entered (bracket + min-SDF; the reference evaluates n_steps depths
+                # for each), and the audit: the largest amount a second-stage depth lay below the bound that kept it (0 = held)
+                'minsdf_lipschitz': float(model.implicit_network.minsdf_lipschitz(model.ray_tracer.object_bounding_sphere))
+                if (model.ray_tracer.minsdf_staged and coarse_tau > 0) else 0.0,
+                'minsdf_second_stage_depths': int(cnt[:, 11].sum().item()), 'dense_searches_entered': int(cnt[:, 6].sum().item()),
+                'minsdf_lipschitz_violation': float(cnt[:, 12].contiguous().int().view(torch.float32).max().item()) if cnt.numel() else 0.0,
                 # the online audit of that bound (every refined sample is evaluated both ways): the largest |single pass -
                 # split| the tracer saw in this run, and what ImplicitNetwork.note_coarse_audit did about it (nothing, if empty)
                 'coarse_audit_max': float(model.implicit_network.coarse_audit_max),

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 12
+#define NEFII_ABI_VERSION 13
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -247,8 +247,22 @@ typedef struct nefii_tracer_params {
                                 / cos of the split-precision trace; measured: DESIGN.md, "tiered sphere tracing").  0: off. */
     float tier_kappa;        /* <= 0: 2 */
     float tier_gate;         /* <= 0: 4 */
+    float minsdf_lipschitz;  /* ABI 13 - staged min-SDF search (needs coarse_tau > 0, 16 <= n_steps <= 128; ignored otherwise).
+                                > 0: the caller's bound L on |sdf(p) - sdf(q)| / |p - q| along a ray inside the bounding sphere
+                                (rays have unit directions).  The search (ray_tracing.py:309-337: argmin over n_steps depths)
+                                then evaluates ceil(n_steps / 4) of the depths - evenly spread over their SORTED order, both
+                                ends included - in the single-pass evaluator first; a depth s between evaluated neighbours
+                                a < s < b whose lower bound  max(v_a - L (t_s - t_a), v_b - L (t_b - t_s)) - coarse_tau  exceeds
+                                (lowest value seen) + coarse_tau cannot be the argmin and is NEVER evaluated; the others go to
+                                the single-pass evaluator one by one, and the refinement in split precision proceeds as
+                                before over the depths that were evaluated.  The argmin (first index of the exact minimum) is
+                                the full search's PROVIDED L holds: like coarse_tau a measured claim about this net (largest
+                                |grad sdf| seen on a sample of the ball, with a safety factor), not a proof.  Audited online:
+                                every depth of the second stage - plus, per search, ONE of the skipped depths picked by a
+                                hash and evaluated after all - is checked against the lower bound it was given,
+                                counters[r][12].  0: off (all n_steps depths are evaluated). */
 } nefii_tracer_params;
-#define NEFII_TRACE_COUNTERS 11  /* int32 counters per round, see nefii_trace_rays */
+#define NEFII_TRACE_COUNTERS 13  /* int32 counters per round, see nefii_trace_rays */
 
 /* The pipelined evaluator behind nefii_trace_rays (precision 2) and nefii_sdf_eval reads the hidden layers' fragments as
  * ONE stream per wave, 4 KiB per 16-deep unit of the layer sequence: [8 waves][units][4 fragments][64 lanes][8 halves];
@@ -304,9 +318,12 @@ int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
  * coarse-pass samples this round re-evaluated in split precision: the online audit of coarse_tau - every refined sample
  * is evaluated both ways anyway; a value above coarse_tau means the caller's bound does not hold for this net;
  * [r][9] (ABI 12, trace_tier) sphere-tracing queries in the single-pass evaluator, [r][10] single queries of [r][0] that
- * repeat such a query in split precision (they take part in the audit of [r][8]).
+ * repeat such a query in split precision (they take part in the audit of [r][8]);
+ * [r][11] (ABI 13, minsdf_lipschitz) depths of staged min-SDF searches evaluated one by one in the single-pass evaluator (the
+ * first stage's depths are a quarter row of [r][5]); [r][12] (the bits of a float >= 0) the largest amount by which such a
+ * depth's value fell below the lower bound that minsdf_lipschitz gave it: above 0 the bound does not hold for this net.
  * Algorithmic evaluations (what the reference's recurrences need) = [0] + [9] - [10] + n_steps*[6] + [3]; executed in split
- * precision = [0] + n_steps*[1] + [7] + [4]; executed in the coarse evaluator = ceil(n_steps / 4)*[5] + [9]. */
+ * precision = [0] + n_steps*[1] + [7] + [4]; executed in the coarse evaluator = ceil(n_steps / 4)*[5] + [9] + [11]. */
 int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,
                      const float *origins, const float *dirs, const uint8_t *object_mask, int64_t n_rays,
                      const float *lin_steps, const float *minsdf_steps,

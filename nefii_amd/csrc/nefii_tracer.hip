@@ -49,7 +49,11 @@ struct RayState {            // SoA views into the workspace
     unsigned *refine;        // [n * cap]  (ray << 7 | sample): coarse samples to re-evaluate in split precision
     unsigned *csingles;      // [2n]  (ray << 2 | kind): sphere-tracing queries for the coarse evaluator (tiered sphere tracing)
     int *block_live;         // [ceil(n / 256)]  advance_kernel: does this block still hold a ray that is not done?
+    unsigned *crefine;       // [n * CREF_CAP]  (ray << 7 | sample): single samples for the COARSE evaluator (staged min-SDF search)
+    unsigned char *ord;      // [groups][n_steps]  staged min-SDF search: ord[k] = index of the k-th smallest of the group's draws
 };
+// staged min-SDF search: most second-stage depths of one ray (a ray with more takes its whole row, as without the staging)
+constexpr int CREF_CAP = 48;
 
 // flags layout
 constexpr int F_PHASE = 0x7;          // bits 0-2
@@ -59,7 +63,10 @@ constexpr int F_SPH = 1 << 8, F_SAMP = 1 << 9, F_HIT = 1 << 10;
 constexpr int F_IT_SHIFT = 12, F_IT_MASK = 0xFF;     // sphere-tracing iteration / bisection step
 constexpr int F_K_SHIFT = 20, F_K_MASK = 0xF;        // back-off count
 // PH_SAMPLER_C only: 0 = the whole row is with the coarse evaluator; w = 1..4: windowed search, the first w quarter rows are
+// PH_MINSDF_C: 0 = the row's coarse values are in, 1 = second stage of the two-stage refinement, 2 / 3 = first / second stage
+// of the staged search (minsdf_lipschitz) is with the coarse evaluator
 constexpr int F_WIN_SHIFT = 24, F_WIN_MASK = 0x7;
+constexpr int CWIN_STAGE1 = 4;        // cdense window code: the first stage's depths of a staged min-SDF search
 // Tiered sphere tracing (nefii_tracer_params.trace_tier), PH_TRACE only.  F_CRS_x: the pending result of that end comes from
 // the single-pass evaluator.  F_AUD_x: that end's query is being REPEATED in split precision this round and res_x still
 // holds the coarse value (the split evaluator compares the two: the online audit of coarse_tau).
@@ -88,8 +95,17 @@ struct Params {
     int window;              //              bracket searches inside the object mask take their coarse samples a quarter row at a time
     float tier_band;         // tiered sphere tracing: a coarse value v16 decides (v > thr, sign) when |v16| > tier_band; 0: off
     float tier_gate;         //              a step / back-off query goes to the coarse evaluator when the step that led to it is > tier_gate
+    float lip;               // staged min-SDF search: Lipschitz bound of the SDF along a ray (0: off)
     RayState s;
 };
+
+// first stage of the staged min-SDF search: sorted position of its j-th depth, j < stage1_count (both ends included)
+__host__ __device__ __forceinline__ int stage1_count(int ns) { return coarse_window(ns); }
+__host__ __device__ __forceinline__ int stage1_pos(int ns, int j) { return (j * (ns - 1)) / (stage1_count(ns) - 1); }
+__device__ __forceinline__ int minsdf_row(const Params &P, int64_t r) {
+    const int g = P.p.minsdf_group;
+    return g > 0 ? (int)(r / g) : 0;
+}
 
 // uniform draw i of ray r's min-SDF search: one row for the whole call, or one row per minsdf_group consecutive rays
 // (several batches traced as one call keep their own draws)
@@ -106,9 +122,11 @@ __device__ __forceinline__ float minsdf_step(const Params &P, int64_t r, int i) 
 // this ray that repeat a coarse one
 __device__ __forceinline__ void append_queries(const Params &P, int round, bool qs, bool qe, bool qt, bool qd, int nc, int cwin,
                                                unsigned ray, unsigned dense_which, int consumed, int n_alg, int n_ref,
-                                               const unsigned (&cmask)[4], bool qcs = false, bool qce = false, int n_rep = 0) {
-    __shared__ int wtot[9][4];
-    __shared__ int base[6];
+                                               const unsigned (&cmask)[4], bool qcs = false, bool qce = false, int n_rep = 0,
+                                               bool ref_coarse = false) {
+    // ref_coarse: this ray's n_ref samples go to the COARSE evaluator's list (crefine: staged min-SDF search)
+    __shared__ int wtot[10][4];
+    __shared__ int base[7];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long bs = __ballot(qs), be = __ballot(qe), bt = __ballot(qt), bd = __ballot(qd);
     const unsigned long long bcs = __ballot(qcs), bce = __ballot(qce);
@@ -116,13 +134,14 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
     int cons = consumed, alg = n_alg, rep = n_rep;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cons += __shfl_xor(cons, o), alg += __shfl_xor(alg, o), rep += __shfl_xor(rep, o);
-    int incl = n_ref;               // inclusive prefix sum of the refine counts over the wave
+    int incl = ref_coarse ? 0 : n_ref;      // inclusive prefix sums of the two refine counts over the wave
+    int incl2 = ref_coarse ? n_ref : 0;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
+        const int t = __shfl_up(incl, o), t2 = __shfl_up(incl2, o);
+        if (lane >= o) incl += t, incl2 += t2;
     }
-    const int wref = __shfl(incl, 63);
+    const int wref = __shfl(incl, 63), wref2 = __shfl(incl2, 63);
     int cincl = nc;                 // ... and of the coarse window counts
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -140,11 +159,12 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
         wtot[6][wave] = alg;
         wtot[7][wave] = __popcll(bcs) + __popcll(bce);
         wtot[8][wave] = rep;
+        wtot[9][wave] = wref2;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        int t[9];
-        for (int i = 0; i < 9; ++i) t[i] = wtot[i][0] + wtot[i][1] + wtot[i][2] + wtot[i][3];
+        int t[10];
+        for (int i = 0; i < 10; ++i) t[i] = wtot[i][0] + wtot[i][1] + wtot[i][2] + wtot[i][3];
         int *cnt = P.counters + round * NCNT;
         for (int i = 0; i < 3; ++i) base[i] = t[i] ? atomicAdd(&cnt[i], t[i]) : 0;
         if (t[3]) atomicAdd(&cnt[3], t[3]);
@@ -154,10 +174,12 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
         if (t[2]) atomicAdd(&cnt[7], t[2] * P.tri_nodes);      // speculative bisection evaluations executed
         base[5] = t[7] ? atomicAdd(&cnt[9], t[7]) : 0;
         if (t[8]) atomicAdd(&cnt[10], t[8]);
+        base[6] = t[9] ? atomicAdd(&cnt[11], t[9]) : 0;
     }
     __syncthreads();
-    int off_s = base[0], off_d = base[1], off_t = base[2], off_r = base[3], off_c = base[4], off_cs = base[5];
+    int off_s = base[0], off_d = base[1], off_t = base[2], off_r = base[3], off_c = base[4], off_cs = base[5], off_r2 = base[6];
     for (int w = 0; w < wave; ++w) {
+        off_r2 += wtot[9][w];
         off_s += wtot[0][w];
         off_d += wtot[1][w];
         off_t += wtot[2][w];
@@ -174,14 +196,15 @@ __device__ __forceinline__ void append_queries(const Params &P, int round, bool 
     for (int k = 0; k < nc; ++k)
         P.s.cdense[off_c + cincl - nc + k] = ((unsigned)(cwin + k) << 29) | (ray << 1) | dense_which;
     if (n_ref > 0) {
-        size_t o = (size_t)off_r + incl - n_ref;
+        size_t o = ref_coarse ? (size_t)off_r2 + incl2 - n_ref : (size_t)off_r + incl - n_ref;
+        unsigned *list = ref_coarse ? P.s.crefine : P.s.refine;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             unsigned mbits = cmask[w];
             while (mbits) {
                 const int bit = __ffs(mbits) - 1;
                 mbits &= mbits - 1;
-                P.s.refine[o++] = (ray << 7) | (unsigned)(32 * w + bit);
+                list[o++] = (ray << 7) | (unsigned)(32 * w + bit);
             }
         }
     }
@@ -213,6 +236,20 @@ __device__ __forceinline__ void finish(const Params &P, int64_t r, float dist, b
     P.out_pts[r * 3 + 2] = fadd(oz, fmul(dist, dz));
 }
 
+// staged min-SDF search: sorted order of every row of draws (rank by value, ties by index), once per call
+__global__ __launch_bounds__(128) void minsdf_order_kernel(Params P) {
+    const int ns = P.p.n_steps, i = threadIdx.x;
+    if (i >= ns) return;
+    const float *st = P.steps + (size_t)blockIdx.x * ns;
+    const float si = st[i];
+    int rank = 0;
+    for (int j = 0; j < ns; ++j) {
+        const float sj = st[j];
+        rank += (sj < si || (sj == si && j < i)) ? 1 : 0;
+    }
+    P.s.ord[(size_t)blockIdx.x * ns + rank] = (unsigned char)i;
+}
+
 // ---- the per-ray state machine ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -226,6 +263,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
     unsigned cmask[4] = {0u, 0u, 0u, 0u};
     bool cs = false, ce = false;       // tiered sphere tracing: qs / qe go to the coarse evaluator
     int n_rep = 0;                     //                         split-precision singles that repeat a coarse one
+    bool ref_coarse = false;           // staged min-SDF search: the n_ref samples of cmask go to the coarse evaluator
     const bool tier = P.tier_band > 0.f;
     const bool coarse = P.tau > 0.f;
     const nefii_tracer_params &tp = P.p;
@@ -624,9 +662,18 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                 } else {
                     if (hit && out_m) P.s.t_min[r] = dist;
                     fl = (fl & ~F_PHASE) | (coarse ? PH_MINSDF_C : PH_MINSDF);
-                    P.s.flags[r] = fl;
                     qd = !coarse;
                     nc = coarse ? 4 : 0;
+                    if (coarse && P.lip > 0.f) {
+                        // staged search: a quarter row's worth of the depths, spread over their sorted order, first; whatever
+                        // no evaluator writes stays +inf: neither a minimum nor within any band of one
+                        float *v = P.s.big + (size_t)r * tp.n_steps;
+                        for (int i = 0; i < tp.n_steps; ++i) v[i] = __builtin_inff();
+                        fl = (fl & ~(F_WIN_MASK << F_WIN_SHIFT)) | (2 << F_WIN_SHIFT);
+                        nc = 1;
+                        cwin = CWIN_STAGE1;
+                    }
+                    P.s.flags[r] = fl;
                     n_alg = 1;
                     dense_which = 1;
                     done = false;
@@ -640,7 +687,70 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         ph = -1;
     }
 
-    if (valid && ph == PH_MINSDF_C && ((fl >> F_WIN_SHIFT) & F_WIN_MASK) != 0) {
+    if (valid && ph == PH_MINSDF_C && ((fl >> F_WIN_SHIFT) & F_WIN_MASK) >= 2) {
+        // staged search (nefii_tracer_params.minsdf_lipschitz).  Walk the depths in sorted order between the first stage's
+        // ones: lower bound of depth s between evaluated neighbours a < s < b from the Lipschitz bound L and the coarse
+        // values c (|c - v| < tau):  v_s >= max(c_a - L (t_s - t_a), c_b - L (t_b - t_s)) - tau.
+        //   stage 1 done (2): s is skipped for good when that bound exceeds best + tau >= the exact value at the lowest
+        //     first-stage depth - it is not the argmin; the others go to the coarse evaluator one by one;
+        //   stage 2 done (3): each of those is audited against the bound that kept it (c_s > bound - tau must hold).
+        const int stage = (fl >> F_WIN_SHIFT) & F_WIN_MASK;
+        const int ns = tp.n_steps, n1 = stage1_count(ns);
+        float *v = P.s.big + (size_t)r * ns;
+        const unsigned char *ord = P.s.ord + (size_t)minsdf_row(P, r) * ns;
+        const float Llen = fmul(P.lip, fsub(P.s.t_max[r], P.s.t_min[r]));
+        float best = __builtin_inff();
+        for (int j = 0; j < n1; ++j) best = fminf(best, v[ord[stage1_pos(ns, j)]]);
+        const float lim = fadd(best, P.tau);
+        int ja = 0, k = 0;
+        float worst = 0.f;
+        int probe = -1;             // one of the SKIPPED depths, picked by a hash of (ray, position): evaluated after all, so that
+        unsigned probe_h = ~0u;     // the audit also sees the bound where it was relied upon (a ray costs one evaluation more)
+        for (int kk = 1; kk < ns - 1; ++kk) {
+            if (kk == stage1_pos(ns, ja + 1)) {
+                ++ja;
+                continue;
+            }
+            const int ia = ord[stage1_pos(ns, ja)], ib = ord[stage1_pos(ns, ja + 1)], is = ord[kk];
+            const float sa = minsdf_step(P, r, ia), sb = minsdf_step(P, r, ib), ss = minsdf_step(P, r, is);
+            const float lb = fsub(fmaxf(fsub(v[ia], fmul(Llen, fsub(ss, sa))), fsub(v[ib], fmul(Llen, fsub(sb, ss)))), P.tau);
+            if (stage == 2) {
+                if (!(fsub(lb, 1e-6f) > lim)) {
+                    cmask[is >> 5] |= 1u << (is & 31);
+                    ++k;
+                } else {
+                    const unsigned h = ((unsigned)r * 2654435761u) ^ ((unsigned)(kk + 1) * 0x9E3779B1u);
+                    const unsigned hh = (h ^ (h >> 15)) * 0x85EBCA6Bu;
+                    if (hh < probe_h) probe_h = hh, probe = is;
+                }
+            } else if (v[is] < __builtin_inff()) {
+                worst = fmaxf(worst, fsub(fsub(lb, P.tau), v[is]));
+            }
+        }
+        fl &= ~(F_WIN_MASK << F_WIN_SHIFT);
+        if (stage == 2 && probe >= 0) {
+            cmask[probe >> 5] |= 1u << (probe & 31);
+            ++k;
+        }
+        if (stage == 2 && k > 0) {
+            if (k <= CREF_CAP) {
+                n_ref = k;
+                ref_coarse = true;
+                fl |= 3 << F_WIN_SHIFT;
+            } else {        // too many to list: the whole row, as without the staging
+                cmask[0] = cmask[1] = cmask[2] = cmask[3] = 0u;
+                nc = 4;
+                dense_which = 1;
+            }
+            P.s.flags[r] = fl;
+            ph = -1;
+        } else {
+            if (worst > 0.f) atomicMax(P.counters + round * NCNT + 12, __float_as_int(worst));
+            cmask[0] = cmask[1] = cmask[2] = cmask[3] = 0u;      // the row's coarse values are in: go on below
+        }
+    }
+
+    if (valid && ph == PH_MINSDF_C && ((fl >> F_WIN_SHIFT) & F_WIN_MASK) == 1) {
         // second stage of the two-stage refinement below: sample a (kept in the iteration bits) now holds its EXACT value
         // v*.  The exact argmin m has exact_m <= v*, hence coarse_m <= v* + tau: only such samples are refined; every other
         // one has exact > v* and keeps a coarse value > v* + tau - the exact stage's argmin over the mixed row is the
@@ -722,7 +832,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
     }
 
     append_queries(P, round, qs && !cs, qe && !ce, qt, qd, nc, cwin, (unsigned)r, dense_which, consumed, n_alg, n_ref, cmask,
-                   qs && cs, qe && ce, n_rep);
+                   qs && cs, qe && ce, n_rep, ref_coarse);
     const int alive = __syncthreads_or(valid && (P.s.flags[r] & F_PHASE) != PH_DONE);
     if (threadIdx.x == 0) P.s.block_live[blockIdx.x] = alive;
 }
@@ -817,8 +927,8 @@ __device__ __forceinline__ void decode_tile(const Params &P, int64_t tile, const
 // the same for the coarse evaluator's list: rays x n_steps samples
 // queries [0, n_rows): the quarter rows' samples; [n_rows, total): the sphere-tracing queries of the tier (csingles)
 template <int ROWS>
-__device__ __forceinline__ void decode_tile_coarse(const Params &P, int64_t tile, int64_t n_rows, int64_t total, float *raw,
-                                                   float **dest, int tid = threadIdx.x) {
+__device__ __forceinline__ void decode_tile_coarse(const Params &P, int round, int64_t tile, int64_t n_rows, int64_t total,
+                                                   float *raw, float **dest, int tid = threadIdx.x) {
     if (tid >= ROWS) return;
     const int ns = P.p.n_steps, cw = coarse_window(ns);
     const int64_t q = tile * ROWS + tid;
@@ -826,8 +936,23 @@ __device__ __forceinline__ void decode_tile_coarse(const Params &P, int64_t tile
     float px = 0.f, py = 0.f, pz = 0.f;
     const int64_t di = q / cw;
     const unsigned e = q < n_rows ? P.s.cdense[di] : 0u;
-    const int i = (int)(e >> 29) * cw + (int)(q - di * cw);
-    if (q >= n_rows && q < total) {
+    int i = (int)(e >> 29) * cw + (int)(q - di * cw);
+    if (q < n_rows && (e >> 29) == CWIN_STAGE1) {     // first stage of a staged min-SDF search: slot j -> sorted position -> sample
+        const int j = (int)(q - di * cw);
+        const int64_t r = (e & 0x1FFFFFFFu) >> 1;
+        i = j < stage1_count(ns) ? P.s.ord[(size_t)minsdf_row(P, r) * ns + stage1_pos(ns, j)] : ns;
+    }
+    const int64_t n_cs = P.counters[round * NCNT + 9];
+    if (q >= n_rows + n_cs && q < total) {            // second stage: single depths
+        const unsigned s = P.s.crefine[q - n_rows - n_cs];
+        const int64_t r = s >> 7;
+        const int si = (int)(s & 127u);
+        const float t = dense_depth(P, r, si, true);
+        dst = &P.s.big[(size_t)r * ns + si];
+        px = fadd(P.o[r * 3], fmul(t, P.d[r * 3]));
+        py = fadd(P.o[r * 3 + 1], fmul(t, P.d[r * 3 + 1]));
+        pz = fadd(P.o[r * 3 + 2], fmul(t, P.d[r * 3 + 2]));
+    } else if (q >= n_rows && q < total) {
         const unsigned s = P.s.csingles[q - n_rows];
         const int64_t r = s >> 2;
         const bool end = (s & 3) == Q_END;
@@ -1101,7 +1226,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, 
     __shared__ float raw[RMAX * 9];
     __shared__ float *dest[RMAX];
     const int64_t n_rows = (int64_t)P.counters[round * NCNT + 5] * coarse_window(P.p.n_steps);
-    const int64_t total = n_rows + P.counters[round * NCNT + 9];
+    const int64_t total = n_rows + P.counters[round * NCNT + 9] + P.counters[round * NCNT + 11];
     const int64_t n_tiles = (total + ROWS - 1) / ROWS;
     if (blockIdx.x >= n_tiles) return;
     zero_lds_any(lds);      // the K-padded stream multiplies what follows a layer's own columns by zero weights: keep it finite
@@ -1109,7 +1234,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16s(Params P, nefii_mlp m, 
     PCursor cur;
     prime16s<FT>(m, b, cur);
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        decode_tile_coarse<ROWS>(P, tile, n_rows, total, raw, dest);
+        decode_tile_coarse<ROWS>(P, round, tile, n_rows, total, raw, dest);
         __syncthreads();
         if constexpr (DB)
             sdf_tile16s2<QT, FT>(m, lds, raw, dest, b, cur);
@@ -1164,7 +1289,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16d(Params P, nefii_mlp m, 
     __shared__ float *dest[2 * ROWS];
     __shared__ unsigned bar[3];
     const int64_t n_rows = (int64_t)P.counters[round * NCNT + 5] * coarse_window(P.p.n_steps);
-    const int64_t total = n_rows + P.counters[round * NCNT + 9];
+    const int64_t total = n_rows + P.counters[round * NCNT + 9] + P.counters[round * NCNT + 11];
     const int64_t n_tiles = (total + ROWS - 1) / ROWS;
     if (blockIdx.x >= n_tiles) return;
     if (threadIdx.x < 3) bar[threadIdx.x] = 0u;
@@ -1177,7 +1302,7 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16d(Params P, nefii_mlp m, 
         PCursor cur[2];
         prime16d<QT>(m, b, cur);
         for (int64_t tile = blockIdx.x + g * (int64_t)gridDim.x; tile < n_tiles; tile += 2 * (int64_t)gridDim.x) {
-            decode_tile_coarse<ROWS>(P, tile, n_rows, total, raw + g * ROWS * 9, dest + g * ROWS, threadIdx.x & 255);
+            decode_tile_coarse<ROWS>(P, round, tile, n_rows, total, raw + g * ROWS * 9, dest + g * ROWS, threadIdx.x & 255);
             gb.sync();
             sdf_tile16d<QT>(m, lds.X[g], raw + g * ROWS * 9, dest + g * ROWS, b, cur, gb);
         }
@@ -1819,7 +1944,12 @@ __global__ __launch_bounds__(512, 2) void sdf_points_kernel16w(nefii_mlp m, cons
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-size_t carve(RayState &s, char *base, int64_t n, int ns, int cap) {
+// rows of min-SDF draws of a call (nefii_tracer_params.minsdf_group)
+int64_t minsdf_rows(int64_t n, const nefii_tracer_params *p) {
+    return p->minsdf_group > 0 ? (n + p->minsdf_group - 1) / p->minsdf_group : 1;
+}
+
+size_t carve(RayState &s, char *base, int64_t n, int ns, int cap, int64_t step_rows) {
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char *p = base ? base + off : nullptr;
@@ -1838,6 +1968,8 @@ size_t carve(RayState &s, char *base, int64_t n, int ns, int cap) {
     s.refine = (unsigned *)take(sizeof(unsigned) * (size_t)n * (cap > 0 ? cap : 0));
     s.csingles = (unsigned *)take(sizeof(unsigned) * 2 * n);
     s.block_live = (int *)take(sizeof(int) * ((n + 255) / 256));
+    s.crefine = (unsigned *)take(step_rows > 0 ? sizeof(unsigned) * (size_t)n * CREF_CAP : 0);
+    s.ord = (unsigned char *)take(step_rows > 0 ? (size_t)step_rows * ns : 0);
     return off;
 }
 
@@ -2102,6 +2234,11 @@ static int coarse_cap(const nefii_tracer_params *p) {
     return c > 100 ? 100 : c;
 }
 
+// the staged min-SDF search runs (the coarse pass itself may still be refused for the net: then it is simply not used)
+static bool minsdf_staged(const nefii_tracer_params *p) {
+    return p->training && p->coarse_tau > 0.f && p->minsdf_lipschitz > 0.f && p->n_steps >= 16 && p->n_steps <= 128;
+}
+
 extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     if (!p) return 0;
     // initial eval + iters*(step + back-offs) -> sampler -> bisection (L levels per round) -> min-SDF -> bookkeeping
@@ -2111,14 +2248,15 @@ extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
     // up to three more for the quarter rows of its coarse pass, the min-SDF search one more for its two-stage refinement
     // tiered sphere tracing: every sphere-tracing evaluation may take a second round (the coarse value, then the exact one)
     const int trace = 1 + p->sphere_tracing_iters * (1 + p->line_step_iters);
+    // staged min-SDF search: its two stages take the place of the one coarse round
     return trace + 1 + (p->n_rootfind_steps + L - 1) / L + 1 + 2 +
-           (p->coarse_tau > 0.f ? 3 + 3 + 1 + (p->trace_tier ? trace : 0) : 0);
+           (p->coarse_tau > 0.f ? 3 + 3 + 1 + (p->trace_tier ? trace : 0) : 0) + (minsdf_staged(p) ? 1 : 0);
 }
 
 extern "C" size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *p) {
     if (!p || n_rays <= 0) return 0;
     RayState s;
-    size_t bytes = carve(s, nullptr, n_rays, p->n_steps, coarse_cap(p));
+    size_t bytes = carve(s, nullptr, n_rays, p->n_steps, coarse_cap(p), minsdf_staged(p) ? minsdf_rows(n_rays, p) : 0);
     bytes += align256(sizeof(int) * NCNT * (size_t)nefii_trace_max_rounds(p));
     return bytes;
 }
@@ -2212,7 +2350,12 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
         // 197.3 / 174.0, gate 4: 196.7 / 173.2, 2: 195.5 / 172.0, 1: 195.1 / 171.6, 0.7: 193.9 / 171.1, 0.35: 194.2 / 171.5
         P.chunk_gate = g ? (float)atof(g) : 1.0f;
     }
-    size_t off = carve(P.s, (char *)workspace, n_rays, h_params->n_steps, P.cap);
+    if (h_params->minsdf_lipschitz < 0.f || h_params->minsdf_lipschitz > 1e6f) return NEFII_E_ARG;
+    const bool staged = J.coarse && minsdf_staged(h_params);
+    P.lip = staged ? h_params->minsdf_lipschitz : 0.f;
+    // (the workspace is laid out by the PARAMETERS, as nefii_trace_workspace_bytes sized it, whether or not the net takes the coarse pass)
+    const int64_t step_rows = minsdf_staged(h_params) ? minsdf_rows(n_rays, &P.p) : 0;
+    size_t off = carve(P.s, (char *)workspace, n_rays, h_params->n_steps, P.cap, step_rows);
     P.counters = (int *)((char *)workspace + off);
     P.levels = levels;
     P.tri_nodes = (1 << levels) - 1;
@@ -2221,6 +2364,10 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
         if (e != hipSuccess) return (int)e;
         e = hipMemsetAsync(P.s.flags, 0, sizeof(int) * n_rays, J.st);
         if (e != hipSuccess) return (int)e;
+        if (staged) {
+            hipLaunchKernelGGL(minsdf_order_kernel, dim3((int)minsdf_rows(n_rays, &P.p)), dim3(128), 0, J.st, P);
+            HIP_CHECK_LAUNCH();
+        }
     }
     J.adv_blocks = (int)((n_rays + 255) / 256);
     // eval grid: enough workgroups for the largest possible round, capped at 2 per CU (grid-stride beyond)

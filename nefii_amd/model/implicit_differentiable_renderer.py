@@ -78,7 +78,8 @@ class ImplicitNetwork(nn.Module):
         self._pm_fit = None
         self._tau = None          # (packed version, radius, error bound of the tracer's coarse pass for these weights)
         self.coarse_audit_max = 0.0       # largest |coarse - split| the tracer has reported for a refined sample
-        self.coarse_audit_events = []     # ('recalibrated' | 'disabled', observed, bound in use): what note_coarse_audit did
+        self.coarse_audit_events = []     # ('recalibrated' | 'disabled' | 'lipschitz_disabled', observed, bound in use): what note_coarse_audit did
+        self._lip = None                  # (packed version, radius, L): Lipschitz bound for the tracer's staged min-SDF search
 
     def coarse_tau(self, radius=1.0):
         """Error bound of the tracer's single-pass evaluator for the current weights (ops.calibrate_coarse_tau), measured
@@ -87,6 +88,29 @@ class ImplicitNetwork(nn.Module):
         if self._tau is None or self._tau[0] != self._pm_version or self._tau[1] != radius:
             self._tau = (self._pm_version, radius, ops.calibrate_coarse_tau(pm, radius))
         return self._tau[2]
+
+    def minsdf_lipschitz(self, radius=1.0):
+        """Bound on the SDF's slope along a ray for the current weights (ops.calibrate_lipschitz: 1.5 x the largest |grad sdf|
+        over 65 536 points of the bounding sphere), measured once per packed version; 0.0 after the tracer's audit has seen it
+        fail (note_coarse_audit)."""
+        self.packed(f16x3=True)
+        if self._lip is None or self._lip[0] != self._pm_version or self._lip[1] != radius:
+            with torch.no_grad():
+                self._lip = (self._pm_version, radius, ops.calibrate_lipschitz(self.gradient, _plist(self)[0].device, radius))
+        return self._lip[2]
+
+    def note_lipschitz_audit(self, violation, lip_used):
+        """The tracer's report on nefii_tracer_params.minsdf_lipschitz for one trace (counter 12): the largest amount by which
+        a depth of a staged search's second stage fell below the lower bound that kept it.  Above 0 the claimed constant
+        does not hold for these weights - a depth that was skipped might have been the argmin - so the staged search is
+        switched off for them (every depth is evaluated again), with a warning."""
+        if violation <= 0.0 or lip_used <= 0.0 or self._lip is None or self._lip[0] != self._pm_version or self._lip[2] <= 0.0:
+            return
+        import warnings
+        warnings.warn('staged min-SDF search of the tracer disabled for this network: a depth lay %.3e below the lower bound '
+                      'its claimed Lipschitz constant %.3f gives' % (violation, lip_used))
+        self._lip = (self._pm_version, self._lip[1], 0.0)
+        self.coarse_audit_events.append(('lipschitz_disabled', float(violation), float(lip_used)))
 
     def note_coarse_audit(self, observed, tau_used, radius=1.0):
         """The tracer's report for one trace: the largest |single pass - split| among the coarse samples it re-evaluated

@@ -75,6 +75,13 @@ class RayTracing(nn.Module):
         self.trace_tier = None if env is None or env == '' else env != '0'
         self.tier_kappa = float(os.environ.get('NEFII_TIER_KAPPA', '0'))
         self.tier_gate = float(os.environ.get('NEFII_TIER_GATE', '0'))
+        # Staged min-SDF search (nefii_tracer_params.minsdf_lipschitz; needs the coarse pass): a quarter of the search's depths,
+        # spread over their sorted order, first; a depth whose lower bound from its evaluated neighbours and the network's
+        # measured slope bound L (ImplicitNetwork.minsdf_lipschitz) already exceeds the lowest value seen is never evaluated.
+        # Same argmin - bit-identical outputs - provided L holds (audited by the tracer).  NEFII_MINSDF_STAGED=0 turns it off;
+        # minsdf_lipschitz_override pins L (tests).
+        self.minsdf_staged = os.environ.get('NEFII_MINSDF_STAGED', '1') != '0'
+        self.minsdf_lipschitz_override = None
 
     @staticmethod
     def auto_levels(n_rays, concurrent=False):
@@ -182,16 +189,31 @@ class RayTracing(nn.Module):
         if self.coarse and self.precision == 'f16x3w' and n_rays > 1024 and (frozen or self.coarse_tau_override is not None):
             tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
                 net.coarse_tau(self.object_bounding_sphere)
-            if self.coarse_tau_override is None and tau > 0:
+            lip = 0.0
+            if tau > 0 and training and self.minsdf_staged:
+                lip = self.minsdf_lipschitz_override if self.minsdf_lipschitz_override is not None else \
+                    net.minsdf_lipschitz(self.object_bounding_sphere)
+            if tau > 0 and (self.coarse_tau_override is None or (lip > 0 and self.minsdf_lipschitz_override is None)):
                 # every refined sample is evaluated both ways: the tracer reports the largest difference it saw and the
-                # network compares it with the bound it claimed (ImplicitNetwork.note_coarse_audit)
-                radius, used = self.object_bounding_sphere, tau
-                audit = lambda v: net.note_coarse_audit(v, used, radius)
+                # network compares it with the bound it claimed (ImplicitNetwork.note_coarse_audit); likewise for the
+                # slope bound of the staged min-SDF search (note_lipschitz_audit)
+                radius, used, lip_used = self.object_bounding_sphere, tau, lip
+                check_tau, check_lip = self.coarse_tau_override is None, self.minsdf_lipschitz_override is None
+
+                def audit(v, lip_violation=0.0):
+                    if check_tau:
+                        net.note_coarse_audit(v, used, radius)
+                    # (the slope check presumes |coarse - exact| < tau: a trace whose tau audit failed says nothing about L -
+                    # and without the coarse pass there is no staged search to switch off)
+                    if check_lip and not v > used:
+                        net.note_lipschitz_audit(lip_violation, lip_used)
+        else:
+            lip = 0.0
         params = ops.make_tracer_params(self._cfg(), training, self.precision, levels, coarse_tau=tau,
                                         coarse_cap=self.coarse_cap, minsdf_group=group,
                                         small_round=self.small_round_for(n_rays, self.concurrent),
                                         trace_tier=self.tier_for(n_rays), tier_kappa=self.tier_kappa,
-                                        tier_gate=self.tier_gate)
+                                        tier_gate=self.tier_gate, minsdf_lipschitz=lip)
         state = None
         if self.adaptive_rounds:      # one guess per (mode, batch size): primary and secondary traces differ
             import math

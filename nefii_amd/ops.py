@@ -474,6 +474,23 @@ def calibrate_coarse_tau(pm, radius=1.0, n=65536, safety=COARSE_TAU_SAFETY, seed
     return max(1e-4, safety * err)
 
 
+LIPSCHITZ_SAFETY = 1.5
+
+
+def calibrate_lipschitz(grad_fn, device, radius=1.0, n=65536, safety=LIPSCHITZ_SAFETY, seed=1):
+    """Bound on |sdf(p) - sdf(q)| / |p - q| inside the bounding sphere for THIS network, for the tracer's staged min-SDF search
+    (nefii_tracer_params.minsdf_lipschitz): `safety` x the largest |grad sdf| over n points drawn uniformly in the sphere,
+    at least 1.  grad_fn: points [n, 3] -> gradients [n, 3] (ImplicitNetwork.gradient).  Like coarse_tau a MEASURED bound, not
+    a proven one; the tracer audits it (counter column 12).  One host sync; cached per packed weight version."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 3, generator=g)
+    x = x / x.norm(dim=1, keepdim=True) * (torch.rand(n, 1, generator=g) ** (1.0 / 3.0)) * (radius * 1.02)
+    gn = grad_fn(x.to(device)).reshape(-1, 3).norm(dim=1).max().item()
+    if not math.isfinite(gn):
+        return 0.0
+    return max(1.0, safety * gn)
+
+
 def algorithmic_evals(counters, n_steps):
     """SDF evaluations the reference's recurrences need for the rounds in `counters` [..., rounds, 9] (what the
     roofline credits): singles + n_steps per dense search entered + bisection steps consumed."""
@@ -485,15 +502,16 @@ def executed_evals(counters, n_steps, tri_nodes=None):
     """(split-precision evaluations, coarse single-pass evaluations) actually executed (tri_nodes: unused, the tracer
     counts its speculative bisection evaluations itself)."""
     c = counters.long()
-    return c[..., 0] + c[..., 1] * n_steps + c[..., 7] + c[..., 4], c[..., 5] * ((n_steps + 3) // 4) + c[..., 9]
+    return c[..., 0] + c[..., 1] * n_steps + c[..., 7] + c[..., 4], c[..., 5] * ((n_steps + 3) // 4) + c[..., 9] + c[..., 11]
 
 
 PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}
 
 
 def make_tracer_params(cfg, training, precision='f32', bisect_levels=3, coarse_tau=0.0, coarse_cap=0, minsdf_group=0,
-                       small_round=0, trace_tier=0, tier_kappa=0.0, tier_gate=0.0):
+                       small_round=0, trace_tier=0, tier_kappa=0.0, tier_gate=0.0, minsdf_lipschitz=0.0):
     p = TracerParams()
+    p.minsdf_lipschitz = float(minsdf_lipschitz) if coarse_tau > 0.0 else 0.0
     p.trace_tier = 1 if (trace_tier and coarse_tau > 0.0) else 0
     p.tier_kappa = float(tier_kappa)
     p.tier_gate = float(tier_gate)
@@ -525,7 +543,7 @@ class TraceRounds:
 
 
 _TRACE_STREAMS = {}
-_WORK = [0, 1, 2, 4, 5, 9]   # counter columns that mean "a ray still waits for an evaluation"
+_WORK = [0, 1, 2, 4, 5, 9, 11]   # counter columns that mean "a ray still waits for an evaluation"
 
 
 _SIDE_STREAMS = {}
@@ -548,7 +566,8 @@ def _trace_streams(dev, n):
     return pool[:n]
 
 
-AUDIT_COLUMN = 8     # float bits (max), every other column is an additive count
+AUDIT_COLUMN = 8     # float bits (max); so is LIP_AUDIT_COLUMN; every other column is an additive count
+LIP_AUDIT_COLUMN = 12
 
 
 def sum_counters(a, b=None):
@@ -557,11 +576,20 @@ def sum_counters(a, b=None):
     of non-negative floats order like the floats)."""
     if b is None:
         out = a.sum(dim=0)
-        out[..., AUDIT_COLUMN] = a[..., AUDIT_COLUMN].max(dim=0).values
+        for col in (AUDIT_COLUMN, LIP_AUDIT_COLUMN):
+            out[..., col] = a[..., col].max(dim=0).values
         return out
     out = a + b
-    out[..., AUDIT_COLUMN] = torch.maximum(a[..., AUDIT_COLUMN], b[..., AUDIT_COLUMN])
+    for col in (AUDIT_COLUMN, LIP_AUDIT_COLUMN):
+        out[..., col] = torch.maximum(a[..., col], b[..., col])
     return out
+
+
+def _lip_audit_of(host_counters):
+    """Largest amount by which a second-stage depth of a staged min-SDF search fell below the lower bound the claimed
+    Lipschitz constant gave it (counter column 12: float bits; 0 = the bound held wherever it was checked)."""
+    col = host_counters[..., LIP_AUDIT_COLUMN].contiguous().view(torch.float32)
+    return float(col.max()) if col.numel() else 0.0
 
 
 def _audit_of(host_counters):
@@ -653,7 +681,7 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
             run(everyone, 0, 0)
             join()
             if audit is not None:           # (the non-adaptive path has no counter read-back of its own: one host sync)
-                audit(_audit_of(counters.cpu()))
+                (lambda h: audit(_audit_of(h), _lip_audit_of(h)))(counters.cpu())
         else:
             guess = rounds if rounds_state.guess is None else max(2, min(rounds, rounds_state.guess))
             run(everyone, 0, guess)
@@ -680,7 +708,7 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
                     busy = torch.nonzero(host[:, :, _WORK].sum(dim=(0, 2))).flatten()
                     rounds_state.guess = (int(busy[-1]) if busy.numel() else 0) + 3
                     if audit is not None:
-                        audit(_audit_of(host))
+                        audit(_audit_of(host), _lip_audit_of(host))
                     return (pts, hit.bool(), dist) if again else None
                 deferred.append(check)
                 if want_counters:
@@ -697,7 +725,7 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
             last = int(busy[-1]) if busy.numel() else 0
             rounds_state.guess = last + 3                    # last emitting round + its consumer + one spare
             if audit is not None:
-                audit(_audit_of(host))
+                audit(_audit_of(host), _lip_audit_of(host))
     if want_counters:
         return pts, hit.bool(), dist, sum_counters(counters)
     return pts, hit.bool(), dist

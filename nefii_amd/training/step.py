@@ -596,7 +596,7 @@ class TrainStep:
         fresh = net.coarse_audit_events[seen:]
         for kind, observed, bound in fresh:
             self.coarse_events.append((self.cur_iter, kind, observed, bound))
-        if any(kind == 'disabled' for kind, _, _ in fresh):
+        if any(kind in ('disabled', 'lipschitz_disabled') for kind, _, _ in fresh):
             self._prefetch = []
             self.retraced_steps += 1
             return None

@@ -863,6 +863,68 @@ def test_tracer_tiered_sphere_tracing(case):
         assert 0.0 < aud < tau, (aud, tau)
 
 
+@pytest.mark.parametrize('case', ['conf512-trained', 'conf512-frame', 'neus256-trained', 'conf512-bowl', 'physg512-bumpy',
+                                  'physg512-smooth', 'neus256-bumpy'])
+def test_tracer_staged_min_sdf_search(case):
+    """nefii_tracer_params.minsdf_lipschitz (ABI 13): the min-SDF search evaluates a quarter row of its depths - spread over
+    their sorted order - first and never evaluates a depth whose lower bound (its evaluated neighbours' values minus L x the
+    distance to them) already exceeds the lowest value seen.  With an L that really bounds the slope the argmin - first index of
+    the exact minimum - is the full search's: points, hit mask and depths are BIT-IDENTICAL to the trace without the staging,
+    for L from a tight 1.0 x to 4 x the largest |grad sdf| of the net, with the tier on and off, with one row of draws per
+    call and one per 500 rays; the single-pass evaluations fall, the audit column stays 0.  With an L far BELOW the slope the
+    audit must notice (that is what keeps a wrong claim from going unseen), and without the coarse pass, or in eval mode, the
+    parameter changes nothing at all."""
+    name, geo = case.split('-')
+    mc = syn.model_conf({'physg512': 'physg', 'conf512': 'conf', 'neus256': 'neus'}[name])
+    sd = syn.make_state_dict(mc, seed=2, bumpy={'bumpy': 0.004}.get(geo, 0.0),
+                             scene={'bowl': 'bowl_dense', 'trained': 'bowl_trained', 'frame': 'frame_trained'}.get(geo))
+    pm = build_sdf(mc, sd, f16x3=True)
+    pm32 = build_sdf(mc, sd)
+    tau = ops.calibrate_coarse_tau(pm)
+    gmax = ops.calibrate_lipschitz(lambda x: ops.sdf_value_grad(pm32, x)[2], DEV, safety=1.0)
+    n = 6000
+    o, d, om, steps = _trace_batch(n, 37, spread=0.6 if geo in ('bowl', 'trained', 'frame') else 0.45)
+    rows = torch.rand(12, 100, generator=torch.Generator().manual_seed(5))
+    plain = run_gpu_trace(mc, sd, o, d, om, True, steps, 'f16x3w', pm=pm)
+    ignored = run_gpu_trace(mc, sd, o, d, om, True, steps, 'f16x3w', pm=pm, minsdf_lipschitz=2.0)
+    evalm = run_gpu_trace(mc, sd, o, d, om, False, steps, 'f16x3w', coarse_tau=tau, pm=pm, minsdf_lipschitz=2.0)
+    evalb = run_gpu_trace(mc, sd, o, d, om, False, steps, 'f16x3w', coarse_tau=tau, pm=pm)
+    for k in range(3):
+        assert torch.equal(plain[k], ignored[k]), 'the staged search ran without a coarse pass'
+        assert torch.equal(evalm[k], evalb[k])
+    assert ignored[3][:, 11].sum() == 0 and evalm[3][:, 11].sum() == 0
+    for tier, group in ((0, 0), (1, 0), (0, 500)):
+        st = rows.reshape(-1) if group else steps
+        kw = dict(trace_tier=tier, minsdf_group=group)
+        base = run_gpu_trace(mc, sd, o, d, om, True, st, 'f16x3w', coarse_tau=tau, pm=pm, **kw)
+        cb = base[3].cpu().long()
+        assert cb[:, 11].sum() == 0 and cb[:, 12].max() == 0
+        _, coarse0 = ops.executed_evals(cb, 100)
+        for f in (1.0, 1.5, 4.0):
+            got = run_gpu_trace(mc, sd, o, d, om, True, st, 'f16x3w', coarse_tau=tau, pm=pm, minsdf_lipschitz=f * gmax, **kw)
+            for k, what in enumerate(('points', 'hit mask', 'depths')):
+                assert torch.equal(got[k], base[k]), (case, tier, group, f, what, (got[2] - base[2]).abs().max().item())
+            c = got[3].cpu().long()
+            assert ops.algorithmic_evals(c, 100).sum() == ops.algorithmic_evals(cb, 100).sum()
+            assert c[:, 6].sum() == cb[:, 6].sum()
+            assert c[:, 12].max() == 0, 'the audit of the slope bound fired at %.2f x the largest gradient seen' % f
+            _, coarse = ops.executed_evals(c, 100)
+            searches = cb[:, 6].sum().item()        # (dense searches entered: bracket + min-SDF)
+            if f == 1.5 and not tier:
+                print('[staged min-SDF %s group=%d] |grad| max %.3f, L %.3f: single-pass evaluations %d -> %d (x %.2f), %d '
+                      'second-stage depths over %d searches' % (case, group, gmax, f * gmax, coarse0.sum().item(),
+                                                                coarse.sum().item(), coarse.sum().item() / coarse0.sum().item(),
+                                                                c[:, 11].sum().item(), searches))
+            assert c[:, 11].sum() > 0 and coarse.sum() < (0.8 if f <= 1.5 else 0.9) * coarse0.sum()
+    # a claim far below the real slope: the audit - which also evaluates one of the SKIPPED depths per search - sees depths
+    # below their "lower bound", and says by how much
+    for claim in (0.05, 0.5):
+        bad = run_gpu_trace(mc, sd, o, d, om, True, steps, 'f16x3w', coarse_tau=tau, pm=pm, minsdf_lipschitz=claim)
+        viol = bad[3][:, 12].cpu().contiguous().view(torch.float32).max().item()
+        print('[staged min-SDF %s] claimed L %.2f (largest gradient seen %.2f): largest violation %.3e' % (case, claim, gmax, viol))
+        assert viol > (0.05 if claim < 0.1 else 0.01)
+
+
 def test_pack_mlp_equals_the_per_layer_packers():
     """nefii_pack_mlp (every layer and every fragment form in ONE launch: what PackedMLP.pack runs) against the per-layer
     entry points the header still exports - nefii_pack_linear (f32 fragments, transpose, padded bias), nefii_pack_linear_f16x3

@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     # nefii_layer: 4 x int32 + 4 pointers; nefii_mlp: 8 x int32 + 12 layers
     assert ctypes.sizeof(_lib.Layer) == 16 + 5 * 8
     assert ctypes.sizeof(_lib.Mlp) == 40 + 12 * ctypes.sizeof(_lib.Layer)
-    assert ctypes.sizeof(_lib.TracerParams) == 68         # 3 floats + 7 int32 + coarse_tau + coarse_cap + minsdf_group + small_round + trace_tier + tier_kappa + tier_gate
+    assert ctypes.sizeof(_lib.TracerParams) == 72         # 3 floats + 7 int32 + coarse_tau + coarse_cap + minsdf_group + small_round + trace_tier + tier_kappa + tier_gate + minsdf_lipschitz
     assert ctypes.sizeof(_lib.RowBlock) == 32             # 2 pointers + cols + src_row_stride + fill + reserved
     assert ctypes.sizeof(_lib.PackSource) == 48           # 2 pointers + 6 int32 + scale + skip_f32
 
@@ -52,6 +52,13 @@ def test_host_side_argument_checks_need_no_gpu():
     p.trace_tier = 1             # tiered sphere tracing: every sphere-tracing evaluation may be repeated in split precision
     assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 2 * (1 + 10 * 4) + 1 + 7 + 1 + 2 + 7
     p.trace_tier = 0
+    w1 = lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p))
+    p.minsdf_lipschitz = 1.5     # staged min-SDF search: training mode only; one round more, a list of 48 single depths per ray, the sorted order of the draws
+    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2 + 7
+    p.training = 1
+    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2 + 7 + 1
+    assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) >= w1 + 4096 * 48 * 4 + 100
+    p.training, p.minsdf_lipschitz = 0, 0.0
     p.coarse_tau = 0.0
     p.trace_tier = 1             # ... and is the coarse pass's: nothing without it
     assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2

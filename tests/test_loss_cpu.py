@@ -120,18 +120,27 @@ def test_counter_sums_keep_the_audit_column_a_maximum_and_the_parameter_list_cac
     the version checks watching dead objects."""
     from nefii_amd import ops
     f = lambda x: torch.tensor([x], dtype=torch.float32).view(torch.int32).item()
-    a = torch.zeros(2, 3, 11, dtype=torch.int32)
+    from nefii_amd import _lib
+    C = _lib.TRACE_COUNTERS
+    a = torch.zeros(2, 3, C, dtype=torch.int32)
     a[0, 1, 0], a[1, 1, 0] = 5, 7
     a[0, 1, 8], a[1, 1, 8] = f(2.5e-4), f(6.0e-4)
     a[0, 2, 9], a[1, 2, 9] = 10, 1
+    a[0, 2, 11], a[1, 2, 11] = 3, 4
+    a[0, 2, 12], a[1, 2, 12] = f(2.0e-3), f(1.0e-3)      # (ABI 13: the slope bound's audit, a maximum as well)
     s = ops.sum_counters(a)
-    assert s.shape == (3, 11) and s[1, 0] == 12 and s[2, 9] == 11
+    assert s.shape == (3, C) and s[1, 0] == 12 and s[2, 9] == 11 and s[2, 11] == 7
     assert s[1, 8].to(torch.int32).view(torch.float32).item() == pytest.approx(6.0e-4)
-    b = torch.zeros(3, 11, dtype=torch.int64)
+    assert s[2, 12].to(torch.int32).view(torch.float32).item() == pytest.approx(2.0e-3)
+    b = torch.zeros(3, C, dtype=torch.int64)
     b[1, 0], b[1, 8] = 1, f(9.0e-4)
     t = ops.sum_counters(s, b)
     assert t[1, 0] == 13 and t[1, 8].to(torch.int32).view(torch.float32).item() == pytest.approx(9.0e-4)
     assert ops._audit_of(t.unsqueeze(0).to(torch.int32)) == pytest.approx(9.0e-4)
+    assert ops._lip_audit_of(t.unsqueeze(0).to(torch.int32)) == pytest.approx(2.0e-3)
+    # executed work: the staged search's second-stage depths count as single-pass evaluations and as waiting work
+    _, coarse = ops.executed_evals(t, 100)
+    assert coarse[2] == 11 + 7 and 11 in ops._WORK
     lin = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2))
     p0 = ops.param_list(lin)
     assert ops.param_list(lin) is p0 and len(p0) == 4

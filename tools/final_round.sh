@@ -34,5 +34,11 @@ for tier in 0 1; do
     NEFII_TRACE_TIER=$tier python3 bench.py --workload cfg3 --steps 10 --warmup 3 --no-cpu-baseline --no-side-measurement 2> /dev/null | tail -1 > $O/bench_cfg3_tier$tier.json
     NEFII_TRACE_TIER=$tier python3 bench.py --workload cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-side-measurement 2> /dev/null | tail -1 > $O/bench_cfg4_tier$tier.json
 done
+for st in 0 1; do      # the staged min-SDF search, same box
+    for w in cfg3 cfg4 cfg2; do
+        NEFII_MINSDF_STAGED=$st python3 bench.py --workload $w --steps $([ $w = cfg2 ] && echo 200 || echo 10) --warmup 5 --no-cpu-baseline --no-side-measurement 2> /dev/null | tail -1 > $O/bench_${w}_staged$st.json
+    done
+done
+python3 tools/render_full_frame.py $O/render_cfg5 64 > $O/render_cfg5_full_frame.log 2>&1
 bash tools/power_probe.sh 2>&1 | grep -v "Warn\|amdgpu.ids" | tr ";" "\n" | grep -v "=====" > $O/power_probe.txt
 tail -c 300 $O/bench_default.json

@@ -39,13 +39,13 @@ for it in range(3):
     lib.nefii_trace_profile_enable(0)
 cnt = m.ray_tracer.last_counters.cpu().tolist()
 tot = 0.0
-print('round  singles  dense  tri(consumed)  refined  coarse quarter rows  tier queries(repeated) | split-precision queries  single-pass queries |   ms')
+print('round  singles  dense  tri(consumed)  refined  coarse quarter rows  tier queries(repeated)  staged 2nd stage | split-precision queries  single-pass queries |   ms')
 for r in range(n):
     c = cnt[r]
     split = c[0] + c[1] * 100 + c[7] + c[4]
-    coarse = c[5] * 25 + c[9]
+    coarse = c[5] * 25 + c[9] + c[11]
     tot += buf[r]
     if split or coarse:
-        print('%4d %8d %6d %5d(%6d) %8d %11d %13d(%6d) | %23d %19d | %6.3f' % (r, c[0], c[1], c[2], c[3], c[4], c[5], c[9], c[10], split,
-                                                                              coarse, buf[r]))
+        print('%4d %8d %6d %5d(%6d) %8d %11d %13d(%6d) %16d | %23d %19d | %6.3f' % (r, c[0], c[1], c[2], c[3], c[4], c[5], c[9], c[10],
+                                                                                   c[11], split, coarse, buf[r]))
 print('total eval ms %.3f over %d launches (a launch = the round\'s split-precision dispatches + its coarse dispatch)' % (tot, n))
