@@ -60,7 +60,7 @@ NORTH_STAR_KEYS = ('sg_rgb_values', 'sg_diffuse_albedo_values')
 
 
 def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel=1, ray_hit=None, ref_ray_hit=None,
-                    max_explained_frac=0.0, sdf_outliers=0, tol_aux=None, tol_points=1e-4):
+                    max_explained_frac=0.0, sdf_outliers=0, tol_aux=None, tol_points=1e-4, miss_sdf_max=5e-3):
     """`out` (HIP path) against `ref` (oracle output or reference-generated fixture), per pixel.
 
     ray_hit / ref_ray_hit: the per-ray hit masks of both sides (model.last_ray_hit, oracle '_ray_hit' / fixture
@@ -68,7 +68,10 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel
     from the three MC-shaded colour keys - at most max_explained_frac of the pixels - and every other pixel is compared
     untrimmed.  tol_aux (default tol_rgb): the bound of every key OTHER than the two the north star names (rendered RGB, albedo)
     - the tiered sphere tracing moves hit points by up to ~sdf_threshold / cos, and the random-weight material network of the
-    synthetic workloads (PE10: 2^9 x position) turns that into 2-3e-3 on the roughness channel."""
+    synthetic workloads (PE10: 2^9 x position) turns that into 2-3e-3 on the roughness channel.
+    miss_sdf_max: bound on |sdf_output| differences of rays that MISS on both sides; None = report only.  In eval mode a missing
+    ray's point is wherever its two sphere-tracing fronts passed each other - nothing reads it - and with the tiered sphere
+    tracing the fronts advance by single-pass values: that crossing place moves."""
     tol_aux = tol_rgb if tol_aux is None else tol_aux
     net, rnet = out['network_object_mask'].cpu(), ref['network_object_mask']
     flips = (net != rnet).sum().item()
@@ -102,8 +105,11 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel
                 _check(int(((a[h] - b[h]).abs() >= 2e-4).sum()) <= sdf_outliers, (what, k, (a[h] - b[h]).abs().max().item()))
                 _check((a[h] - b[h]).abs().median().item() < 2e-6, (what, k))
             if k == 'sdf_output' and (~h).any():
-                _check((a[~h] - b[~h]).abs().max().item() < 5e-3, (what, k))
-                _check(((a[~h] - b[~h]).abs() < 2e-5).float().mean().item() > 0.9, (what, k))
+                figures.append('|d sdf| of missing rays max %.2e' % (a[~h] - b[~h]).abs().max().item())
+                figures.append('within 2e-5: %.3f' % ((a[~h] - b[~h]).abs() < 2e-5).float().mean().item())
+                if miss_sdf_max is not None:
+                    _check((a[~h] - b[~h]).abs().max().item() < miss_sdf_max, (what, k))
+                    _check(((a[~h] - b[~h]).abs() < 2e-5).float().mean().item() > 0.9, (what, k))
             continue
         if k == 'sg_specular_rgb_values':
             # A COMPONENT of the rendered colour: GGX's D = 1 / (pi a^2 ((n.h)^2 + (1 - (n.h)^2) / a^2)^2), a = roughness^2,
@@ -122,4 +128,7 @@ def compare_outputs(out, ref, tol_rgb=1e-3, max_flips=1, what='', rays_per_pixel
     # (above: normals, albedo, roughness, idr_rgb over all `agree` pixels), and their colours must stay finite
     for k in MC_KEYS:
         assert torch.isfinite(out[k]).all(), (what, k)
-    return {'flips': flips, 'dir': n_dir, 'vis': n_vis, 'flagged_pixels': int(flagged_px.sum())}
+    keep = agree & ~flagged_px
+    return {'flips': flips, 'dir': n_dir, 'vis': n_vis, 'flagged_pixels': int(flagged_px.sum()),
+            # what the bound was held to: rendered RGB over the pixels whose Monte-Carlo samples are the same on both sides
+            'rgb_rel_l2_same_samples': rel_l2(out['sg_rgb_values'].detach().cpu()[keep], ref['sg_rgb_values'][keep])}

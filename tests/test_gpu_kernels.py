@@ -1028,6 +1028,58 @@ def test_tracer_audits_its_coarse_bound():
     assert c[:, 5].sum() == 0 and c[:, 4].sum() == 0, 'the coarse evaluator still ran'
 
 
+def test_tracer_audits_its_slope_bound():
+    """The staged min-SDF search's Lipschitz constant (ImplicitNetwork.minsdf_lipschitz) is measured, not proven; the tracer
+    checks every second-stage depth - and one skipped depth per search - against the lower bound the constant gave it (counter
+    12).  With the measured constant nothing is reported and the trace equals the one without the staging bit for bit; an
+    UNDER-claimed constant is noticed, switches the staging off for those weights with a warning (the next trace evaluates every
+    depth again and is the unstaged trace), and is left alone while the tau audit of the same trace fails."""
+    import warnings
+    from nefii_amd import conf
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    mc = syn.model_conf('conf')
+    m = IDRNetwork(conf.from_dict(mc))
+    m.load_state_dict(syn.make_state_dict(mc, seed=2, scene='bowl_trained'), strict=True)
+    m = m.to(DEV)
+    m.freeze_geometry()
+    m.train()
+    net, rt = m.implicit_network, m.ray_tracer
+    o, d, om, steps = _trace_batch(6000, 33, spread=0.6)
+    rt.minsdf_steps_override = steps
+    rt.collect_counters = True
+    cam, dirs = o.to(DEV), d.to(DEV).unsqueeze(1)
+
+    def trace():
+        rt.counter_sum = None
+        out = rt.forward(net, cam, om.to(DEV), dirs)
+        torch.cuda.synchronize()
+        return out, rt.counter_sum.cpu()
+
+    rt.minsdf_staged = False
+    ref, c0 = trace()
+    assert c0[:, 11].sum() == 0
+    rt.minsdf_staged = True
+    L = net.minsdf_lipschitz(rt.object_bounding_sphere)
+    got, c = trace()
+    assert 1.0 <= L < 4.0 and c[:, 11].sum() > 0 and c[:, 12].max() == 0 and not net.coarse_audit_events
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    _, coarse0 = ops.executed_evals(c0.long(), 100)
+    _, coarse = ops.executed_evals(c.long(), 100)
+    print('[slope audit] L %.3f: single-pass evaluations %d -> %d' % (L, coarse0.sum().item(), coarse.sum().item()))
+    assert coarse.sum() < 0.7 * coarse0.sum()
+    net._lip = (net._lip[0], net._lip[1], 0.3)              # an under-claimed constant
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        trace()
+    assert any('staged min-SDF search' in str(x.message) for x in w)
+    assert net.coarse_audit_events[-1][0] == 'lipschitz_disabled' and net.minsdf_lipschitz(rt.object_bounding_sphere) == 0.0
+    again, c = trace()
+    assert c[:, 11].sum() == 0 and net.coarse_tau(rt.object_bounding_sphere) > 0
+    for a, b in zip(again, ref):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('case', ['conf512-bowl', 'physg512-bumpy'])
 def test_tracer_leading_samples_first_changes_no_decision(case, monkeypatch):
     """The bracket search's first few samples evaluated in split precision before anything else (NEFII_SAMPLER_CHUNK, default

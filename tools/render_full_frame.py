@@ -95,9 +95,12 @@ def main():
         m.ray_tracer.trace_tier = None
         stats = compare_outputs(out, ref, max_flips=max(4, n_ray // 2000), what='cfg5 frame sample', rays_per_pixel=1,
                                 ray_hit=m.last_ray_hit, ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02,
-                                sdf_outliers=max(1, n_ray // 8000) + (n_ray // 2000 if tier else 0), tol_aux=4e-3 if tier else None)
+                                sdf_outliers=max(1, n_ray // 8000) + (n_ray // 2000 if tier else 0), tol_aux=4e-3 if tier else None,
+                                miss_sdf_max=None if tier else 5e-3)     # (eval mode: a missing ray's point is where its fronts crossed)
         both = (out['network_object_mask'].cpu() == ref['network_object_mask'])
         res['oracle_check'] = {'pixels': int(pick.numel()), 'rays': n_ray, 'hit_ray_fraction': ref['_ray_hit'].float().mean().item(),
+                               # (rgb_rel_l2: over ALL rays that hit both ways, i.e. including the `dir` + `vis` rays that drew
+                               # another Monte-Carlo sample - one ray per "pixel" here; rgb_rel_l2_same_samples: without them)
                                'rgb_rel_l2': rel_l2(out['sg_rgb_values'][both.to(dev)], ref['sg_rgb_values'][both]),
                                'albedo_rel_l2': rel_l2(out['sg_diffuse_albedo_values'][both.to(dev)],
                                                        ref['sg_diffuse_albedo_values'][both]),
