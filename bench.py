@@ -707,8 +707,9 @@ def main():
                                       side=True, sustained=sustained)
         nested['cfg2_near'] = run_workload('cfg2_near', args, short['steps'], short['warmup'], rank, world, dev, backend, lib,
                                            side=False, sustained=sustained)
-        # (config 1's traces are enqueued in groups of three, four groups ahead: a dozen steps until the schedule has settled)
-        nested['cfg1'] = run_workload('cfg1', args, max(short['steps'], 30), max(short['warmup'], 12), rank, world, dev, backend,
+        # (config 1's traces are enqueued in groups of eight, four groups ahead: some forty steps until the schedule has settled;
+        # a step is under a millisecond)
+        nested['cfg1'] = run_workload('cfg1', args, max(short['steps'], 96), max(short['warmup'], 48), rank, world, dev, backend,
                                       lib, side=False, sustained=sustained)
         # BASELINE's 8-GPU training config as it is defined: the global 8192-pixel batch split over the ranks
         nested['cfg4'] = run_workload('cfg4', args, max(1, min(args.steps, 10)), min(args.warmup, 2), rank, world, dev, backend,

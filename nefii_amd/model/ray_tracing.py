@@ -65,6 +65,7 @@ class RayTracing(nn.Module):
         self.coarse = os.environ.get('NEFII_TRACER_COARSE', '1') != '0'
         self.coarse_tau_override = None
         self.coarse_cap = int(os.environ.get('NEFII_TRACER_COARSE_CAP', '0'))
+        self.coarse_min_rays = int(os.environ.get('NEFII_COARSE_MIN_RAYS', '1024'))      # batches of up to this many rays: no coarse pass
         # Tiered sphere tracing (nefii_tracer_params.trace_tier; needs the coarse pass): the sphere-tracing evaluations whose
         # front is still far from the surface run on the single-pass evaluator and their value is taken as it is once it is
         # out of the band where it could decide differently.  Changes VALUES (fronts move by v16 instead of v): depths of
@@ -186,7 +187,8 @@ class RayTracing(nn.Module):
         # ... and geometry that still trains (model/trainable_geometry.py) changes its weights every step: the bound would
         # have to be re-measured per forward (two 65 k-point evaluations and a host sync) - no coarse pass there
         frozen = not any(p.requires_grad for p in ops.param_list(net))
-        if self.coarse and self.precision == 'f16x3w' and n_rays > 1024 and (frozen or self.coarse_tau_override is not None):
+        if self.coarse and self.precision == 'f16x3w' and n_rays > self.coarse_min_rays and \
+                (frozen or self.coarse_tau_override is not None):
             tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
                 net.coarse_tau(self.object_bounding_sphere)
             lip = 0.0

@@ -480,11 +480,12 @@ class TrainStep:
     # CUs that the tracer's latency-bound rounds (fewer tiles than CUs) leave idle.  Same arithmetic, same order of the
     # tracer's random draws; only the schedule changes.
     def trace_group_for(self, model_input):
-        """Batches traced per tracer call when their rays are enqueued ahead (prefetch_group).  Tiny batches (config 1:
-        512 rays) are traced three at a time: a lone trace of a few hundred rays is all launch and tile latency, and one
-        call of three batches costs hardly more than one of one (config 1: 1.95 -> 1.63 ms per step).  From a few thousand
-        rays on it no longer pays - config 2 (4096 rays): 3.10 vs 3.12 ms per step, the three traces in flight already fill
-        each other's gaps - and big batches fill the chip on their own: 1.  NEFII_TRACE_GROUP overrides."""
+        """Batches traced per tracer call when their rays are enqueued ahead (prefetch_group).  Tiny batches are traced
+        several at a time: a lone trace of a few hundred rays is all launch and tile latency, and one call of several
+        batches costs hardly more than one of one.  Config 1 (512 rays), ms per step by group size, round 5: 3: 0.89, 4: 0.72,
+        6: 0.63, 8: 0.61, 12: 0.63 - eight (4096 rays per call; before the coarse pass and the staged min-SDF search reached
+        such calls, three was the optimum: 1.95 -> 1.63).  From a few thousand rays on it no longer pays - config 2 (4096
+        rays): 2.26 / 2.36 / 2.22 for 1 / 2 / 3 - and big batches fill the chip on their own: 1.  NEFII_TRACE_GROUP overrides."""
         env = os.environ.get('NEFII_TRACE_GROUP')
         if env:
             return max(1, int(env))
@@ -492,12 +493,13 @@ class TrainStep:
         if uv.shape[0] != 1:
             return 1
         n_rays = uv.shape[1] * (uv.shape[2] if uv.dim() == 4 else 1)
-        return 3 if n_rays <= 2048 else 1
+        return 8 if n_rays <= 1024 else (3 if n_rays <= 2048 else 1)
 
     def preferred_lookahead(self, model_input):
         """Upcoming batches a caller should hand to __call__ (next_input): three traces in flight for big batches; for
         grouped traces four groups minus one: a group is enqueued while three whole traced groups are in flight or waiting (their
-        rounds are all latency; config 1: 1.25 ms per step with two groups, 1.08 with four)."""
+        rounds are all latency; config 1: 1.25 ms per step with two groups, 1.08 with four) - 31 batches for config 1's groups
+        of eight (frozen geometry: a trace depends on no trained parameter, however far ahead it is made)."""
         g = self.trace_group_for(model_input)
         return 3 if g <= 1 else 4 * g - 1
 

@@ -12,8 +12,8 @@ for w in cfg3 cfg4; do
     NEFII_BENCH_PREFETCH=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/np -- python3 bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-side-measurement > $O/bench_${w}_noprefetch_under_rocprof.json 2> /dev/null
     cp $(find /tmp/np -name "*kernel_stats.csv" | head -1) $O/bench_${w}_noprefetch_kernel_stats.csv
 done
-python3 bench.py --workload cfg1 --steps 60 --warmup 15 --no-cpu-baseline > $O/bench_cfg1.json 2> /dev/null
-rm -rf /tmp/c1; rocprofv3 --kernel-trace --output-format csv -d /tmp/c1 -- python3 bench.py --workload cfg1 --steps 60 --warmup 15 --no-cpu-baseline --no-side-measurement > /dev/null 2>&1
+python3 bench.py --workload cfg1 --steps 240 --warmup 48 --no-cpu-baseline > $O/bench_cfg1.json 2> /dev/null
+rm -rf /tmp/c1; rocprofv3 --kernel-trace --output-format csv -d /tmp/c1 -- python3 bench.py --workload cfg1 --steps 120 --warmup 48 --no-cpu-baseline --no-side-measurement > /dev/null 2>&1
 python3 tools/queue_listing.py $(find /tmp/c1 -name "*kernel_trace.csv" | head -1) 5 > $O/cfg1_tail_listing_after.txt 2>&1
 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
 (python3 tools/mlp_microbench.py 4096 139264; MODEL=neus python3 tools/mlp_microbench.py 139264; echo "== NEFII_MLP_STREAM=0"
