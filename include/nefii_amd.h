@@ -260,7 +260,12 @@ typedef struct nefii_tracer_params {
                                 |grad sdf| seen on a sample of the ball, with a safety factor), not a proof.  Audited online:
                                 every depth of the second stage - plus, per search, ONE of the skipped depths picked by a
                                 hash and evaluated after all - is checked against the lower bound it was given,
-                                counters[r][12].  0: off (all n_steps depths are evaluated). */
+                                counters[r][12].  The BRACKET search (:195-257) is staged the same way for eval-mode traces and
+                                for rays outside the object mask: a quarter row of its n_steps samples spread over the row
+                                first; a sample whose lower bound proves it positive - and, unless the ray lies inside the
+                                mask and surely has a negative sample in front of which only signs matter, above the lowest
+                                value seen + coarse_tau - is never evaluated; the first negative sample, the bracket and the
+                                argmin fallback are the full row's.  0: off (all n_steps depths / samples are evaluated). */
 } nefii_tracer_params;
 #define NEFII_TRACE_COUNTERS 13  /* int32 counters per round, see nefii_trace_rays */
 

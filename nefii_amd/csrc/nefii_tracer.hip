@@ -52,8 +52,8 @@ struct RayState {            // SoA views into the workspace
     unsigned *crefine;       // [n * CREF_CAP]  (ray << 7 | sample): single samples for the COARSE evaluator (staged min-SDF search)
     unsigned char *ord;      // [groups][n_steps]  staged min-SDF search: ord[k] = index of the k-th smallest of the group's draws
 };
-// staged min-SDF search: most second-stage depths of one ray (a ray with more takes its whole row, as without the staging)
-constexpr int CREF_CAP = 48;
+// staged searches: most second-stage samples of one ray (a ray with more takes its whole row, as without the staging)
+constexpr int CREF_CAP = 76;       // (n_steps 100: the 75 depths outside the first stage + the probe - no search falls back)
 
 // flags layout
 constexpr int F_PHASE = 0x7;          // bits 0-2
@@ -63,6 +63,7 @@ constexpr int F_SPH = 1 << 8, F_SAMP = 1 << 9, F_HIT = 1 << 10;
 constexpr int F_IT_SHIFT = 12, F_IT_MASK = 0xFF;     // sphere-tracing iteration / bisection step
 constexpr int F_K_SHIFT = 20, F_K_MASK = 0xF;        // back-off count
 // PH_SAMPLER_C only: 0 = the whole row is with the coarse evaluator; w = 1..4: windowed search, the first w quarter rows are
+// (PH_SAMPLER_C also: 5 / 6 = first / second stage of the staged bracket search (minsdf_lipschitz) is with the coarse evaluator)
 // PH_MINSDF_C: 0 = the row's coarse values are in, 1 = second stage of the two-stage refinement, 2 / 3 = first / second stage
 // of the staged search (minsdf_lipschitz) is with the coarse evaluator
 constexpr int F_WIN_SHIFT = 24, F_WIN_MASK = 0x7;
@@ -96,12 +97,19 @@ struct Params {
     float tier_band;         // tiered sphere tracing: a coarse value v16 decides (v > thr, sign) when |v16| > tier_band; 0: off
     float tier_gate;         //              a step / back-off query goes to the coarse evaluator when the step that led to it is > tier_gate
     float lip;               // staged min-SDF search: Lipschitz bound of the SDF along a ray (0: off)
+    int stage_bracket;       //              ... and the bracket search of eval-mode traces / rays outside the mask staged too
     RayState s;
 };
 
 // first stage of the staged min-SDF search: sorted position of its j-th depth, j < stage1_count (both ends included)
 __host__ __device__ __forceinline__ int stage1_count(int ns) { return coarse_window(ns); }
 __host__ __device__ __forceinline__ int stage1_pos(int ns, int j) { return (j * (ns - 1)) / (stage1_count(ns) - 1); }
+// the staged bracket search takes the rays whose quarter-row windows are long searches: eval-mode traces (the secondary rays
+// of the MC renderer, full-frame renders - most of their searches find their crossing late or not at all) and rays outside
+// the object mask (whole rows, argmin); training-mode rays inside the mask stop in their first window and keep the windows
+__device__ __forceinline__ bool staged_bracket(const Params &P, int64_t r) {
+    return P.lip > 0.f && P.stage_bracket && (!P.p.training || P.obj[r] == 0);
+}
 __device__ __forceinline__ int minsdf_row(const Params &P, int64_t r) {
     const int g = P.p.minsdf_group;
     return g > 0 ? (int)(r / g) : 0;
@@ -401,7 +409,14 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                         qd = !go_coarse;
                         // inside the object mask the search ends at the first negative sample: the quarter rows go out one
                         // at a time (P.window; outside the mask the argmin over the whole row is the result)
-                        if (go_coarse && (P.window & 1) && P.obj[r] != 0) {
+                        if (go_coarse && staged_bracket(P, r)) {
+                            // staged search (minsdf_lipschitz): a quarter row's worth of samples spread over the row first
+                            float *v = P.s.big + (size_t)r * tp.n_steps;
+                            for (int i = 0; i < tp.n_steps; ++i) v[i] = __builtin_inff();
+                            nc = 1;
+                            cwin = CWIN_STAGE1;
+                            fl |= 5 << F_WIN_SHIFT;
+                        } else if (go_coarse && (P.window & 1) && P.obj[r] != 0) {
                             nc = 1;
                             fl |= 1 << F_WIN_SHIFT;
                         } else if (go_coarse) {
@@ -469,7 +484,13 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             ph = PH_SAMPLER;
         } else {
             fl = (fl & ~F_PHASE) | PH_SAMPLER_C;
-            if (P.window & 1) {         // (PH_SAMPLER_X rays lie inside the object mask)
+            if (staged_bracket(P, r)) {
+                // (the leading samples keep their exact values: evaluated samples like any other)
+                for (int i = P.chunk; i < ns; ++i) v[i] = __builtin_inff();
+                nc = 1;
+                cwin = CWIN_STAGE1;
+                fl |= 5 << F_WIN_SHIFT;
+            } else if (P.window & 1) {         // (PH_SAMPLER_X rays lie inside the object mask)
                 nc = 1;
                 fl |= 1 << F_WIN_SHIFT;
             } else {
@@ -478,6 +499,80 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             dense_which = 0;
             P.s.flags[r] = fl;
             ph = -1;
+        }
+    }
+
+    if (valid && ph == PH_SAMPLER_C && ((fl >> F_WIN_SHIFT) & F_WIN_MASK) >= 5) {
+        // Staged bracket search (nefii_tracer_params.minsdf_lipschitz).  What the search decides: the FIRST negative sample
+        // and - unless the ray lies inside the object mask and surely has one - the argmin.  Lower bound of sample s between
+        // evaluated neighbours a < s < b as in the staged min-SDF search below: v_s >= max(c_a - L dt_a, c_b - L dt_b) - tau.
+        //   stage 1 done (5): with a surely negative first-stage sample j1 on a ray inside the mask only the samples in front
+        //     of j1 matter, and only their sign: s is skipped for good when its bound is > 0.  Otherwise s must also not be
+        //     the argmin: skipped when its bound exceeds max(0, best + tau).  The others go to the coarse evaluator one by
+        //     one (with one skipped sample per search as the audit's probe);
+        //   stage 2 done (6): audit, then the row - skipped samples at +inf: positive, never a minimum - is decided as a whole.
+        const int stage = (fl >> F_WIN_SHIFT) & F_WIN_MASK;
+        const int ns = tp.n_steps, n1 = stage1_count(ns);
+        float *v = P.s.big + (size_t)r * ns;
+        const float Llen = fmul(P.lip, fsub(P.s.t_e[r], P.s.t_s[r]));
+        const bool obj = P.obj[r] != 0;
+        float best = __builtin_inff();
+        int j1 = ns;
+        for (int j = 0; j < n1; ++j) {
+            const int i = stage1_pos(ns, j);
+            best = fminf(best, v[i]);
+            if (v[i] < -P.tau && j1 == ns) j1 = i;
+        }
+        const bool sign_only = obj && j1 < ns && !(v[0] < P.tau);       // (sample 0 possibly negative: the row is decided as a whole)
+        const float lim = sign_only ? 0.f : fmaxf(0.f, fadd(best, P.tau));
+        const int last = sign_only ? j1 : ns - 1;
+        int ja = 0, k = 0;
+        float worst = 0.f;
+        int probe = -1;
+        unsigned probe_h = ~0u;
+        for (int kk = 1; kk < ns - 1; ++kk) {
+            if (kk == stage1_pos(ns, ja + 1)) {
+                ++ja;
+                continue;
+            }
+            const int ia = stage1_pos(ns, ja), ib = stage1_pos(ns, ja + 1);
+            const float lb = fsub(fmaxf(fsub(v[ia], fmul(Llen, fsub(P.lin[kk], P.lin[ia]))),
+                                        fsub(v[ib], fmul(Llen, fsub(P.lin[ib], P.lin[kk])))), P.tau);
+            if (stage == 5) {
+                if (kk >= last || v[kk] < __builtin_inff()) continue;      // not needed / one of the leading exact samples
+                if (!(fsub(lb, 1e-6f) > lim)) {
+                    cmask[kk >> 5] |= 1u << (kk & 31);
+                    ++k;
+                } else {
+                    const unsigned h = ((unsigned)r * 2654435761u) ^ ((unsigned)(kk + 1) * 0x9E3779B1u);
+                    const unsigned hh = (h ^ (h >> 15)) * 0x85EBCA6Bu;
+                    if (hh < probe_h) probe_h = hh, probe = kk;
+                }
+            } else if (v[kk] < __builtin_inff()) {
+                worst = fmaxf(worst, fsub(fsub(lb, P.tau), v[kk]));
+            }
+        }
+        fl &= ~(F_WIN_MASK << F_WIN_SHIFT);
+        if (stage == 5 && probe >= 0) {
+            cmask[probe >> 5] |= 1u << (probe & 31);
+            ++k;
+        }
+        if (stage == 5 && k > 0) {
+            if (k <= CREF_CAP) {
+                n_ref = k;
+                ref_coarse = true;
+                fl |= 6 << F_WIN_SHIFT;
+            } else {        // too many to list: the whole row
+                cmask[0] = cmask[1] = cmask[2] = cmask[3] = 0u;
+                nc = 4;
+            }
+            dense_which = 0;
+            P.s.flags[r] = fl;
+            ph = -1;
+        } else {
+            // (the leading exact samples are audited with the rest: an exact value obeys the bound a fortiori)
+            if (worst > 0.f) atomicMax(P.counters + round * NCNT + 12, __float_as_int(worst));
+            cmask[0] = cmask[1] = cmask[2] = cmask[3] = 0u;      // the row's values are in: decided below, this round
         }
     }
 
@@ -940,14 +1035,14 @@ __device__ __forceinline__ void decode_tile_coarse(const Params &P, int round, i
     if (q < n_rows && (e >> 29) == CWIN_STAGE1) {     // first stage of a staged min-SDF search: slot j -> sorted position -> sample
         const int j = (int)(q - di * cw);
         const int64_t r = (e & 0x1FFFFFFFu) >> 1;
-        i = j < stage1_count(ns) ? P.s.ord[(size_t)minsdf_row(P, r) * ns + stage1_pos(ns, j)] : ns;
+        i = j >= stage1_count(ns) ? ns : (e & 1) ? P.s.ord[(size_t)minsdf_row(P, r) * ns + stage1_pos(ns, j)] : stage1_pos(ns, j);
     }
     const int64_t n_cs = P.counters[round * NCNT + 9];
     if (q >= n_rows + n_cs && q < total) {            // second stage: single depths
         const unsigned s = P.s.crefine[q - n_rows - n_cs];
         const int64_t r = s >> 7;
         const int si = (int)(s & 127u);
-        const float t = dense_depth(P, r, si, true);
+        const float t = dense_depth(P, r, si, (P.s.flags[r] & F_PHASE) == PH_MINSDF_C);      // (else: a bracket search's sample)
         dst = &P.s.big[(size_t)r * ns + si];
         px = fadd(P.o[r * 3], fmul(t, P.d[r * 3]));
         py = fadd(P.o[r * 3 + 1], fmul(t, P.d[r * 3 + 1]));
@@ -2236,7 +2331,7 @@ static int coarse_cap(const nefii_tracer_params *p) {
 
 // the staged min-SDF search runs (the coarse pass itself may still be refused for the net: then it is simply not used)
 static bool minsdf_staged(const nefii_tracer_params *p) {
-    return p->training && p->coarse_tau > 0.f && p->minsdf_lipschitz > 0.f && p->n_steps >= 16 && p->n_steps <= 128;
+    return p->coarse_tau > 0.f && p->minsdf_lipschitz > 0.f && p->n_steps >= 16 && p->n_steps <= 128;
 }
 
 extern "C" int nefii_trace_max_rounds(const nefii_tracer_params *p) {
@@ -2353,6 +2448,13 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     if (h_params->minsdf_lipschitz < 0.f || h_params->minsdf_lipschitz > 1e6f) return NEFII_E_ARG;
     const bool staged = J.coarse && minsdf_staged(h_params);
     P.lip = staged ? h_params->minsdf_lipschitz : 0.f;
+    {       // NEFII_BRACKET_STAGED=0: the bracket search keeps its quarter-row windows (A/B switch)
+        static const int v = [] {
+            const char *e = getenv("NEFII_BRACKET_STAGED");
+            return e ? atoi(e) != 0 : 1;
+        }();
+        P.stage_bracket = v;
+    }
     // (the workspace is laid out by the PARAMETERS, as nefii_trace_workspace_bytes sized it, whether or not the net takes the coarse pass)
     const int64_t step_rows = minsdf_staged(h_params) ? minsdf_rows(n_rays, &P.p) : 0;
     size_t off = carve(P.s, (char *)workspace, n_rays, h_params->n_steps, P.cap, step_rows);
@@ -2364,7 +2466,7 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
         if (e != hipSuccess) return (int)e;
         e = hipMemsetAsync(P.s.flags, 0, sizeof(int) * n_rays, J.st);
         if (e != hipSuccess) return (int)e;
-        if (staged) {
+        if (staged && h_params->training) {
             hipLaunchKernelGGL(minsdf_order_kernel, dim3((int)minsdf_rows(n_rays, &P.p)), dim3(128), 0, J.st, P);
             HIP_CHECK_LAUNCH();
         }

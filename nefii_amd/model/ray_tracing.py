@@ -76,10 +76,12 @@ class RayTracing(nn.Module):
         self.trace_tier = None if env is None or env == '' else env != '0'
         self.tier_kappa = float(os.environ.get('NEFII_TIER_KAPPA', '0'))
         self.tier_gate = float(os.environ.get('NEFII_TIER_GATE', '0'))
-        # Staged min-SDF search (nefii_tracer_params.minsdf_lipschitz; needs the coarse pass): a quarter of the search's depths,
+        # Staged searches (nefii_tracer_params.minsdf_lipschitz; need the coarse pass): a quarter of the min-SDF search's depths,
         # spread over their sorted order, first; a depth whose lower bound from its evaluated neighbours and the network's
         # measured slope bound L (ImplicitNetwork.minsdf_lipschitz) already exceeds the lowest value seen is never evaluated.
-        # Same argmin - bit-identical outputs - provided L holds (audited by the tracer).  NEFII_MINSDF_STAGED=0 turns it off;
+        # Likewise the bracket search of eval-mode traces (secondary rays, renders) and of rays outside the object mask: a sample
+        # that the bound proves positive - and not the argmin, where the argmin matters - is never evaluated.
+        # Same decisions - bit-identical outputs - provided L holds (audited by the tracer).  NEFII_MINSDF_STAGED=0 turns both off;
         # minsdf_lipschitz_override pins L (tests).
         self.minsdf_staged = os.environ.get('NEFII_MINSDF_STAGED', '1') != '0'
         self.minsdf_lipschitz_override = None
@@ -192,7 +194,7 @@ class RayTracing(nn.Module):
             tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
                 net.coarse_tau(self.object_bounding_sphere)
             lip = 0.0
-            if tau > 0 and training and self.minsdf_staged:
+            if tau > 0 and self.minsdf_staged:
                 lip = self.minsdf_lipschitz_override if self.minsdf_lipschitz_override is not None else \
                     net.minsdf_lipschitz(self.object_bounding_sphere)
             if tau > 0 and (self.coarse_tau_override is None or (lip > 0 and self.minsdf_lipschitz_override is None)):

@@ -887,12 +887,36 @@ def test_tracer_staged_min_sdf_search(case):
     rows = torch.rand(12, 100, generator=torch.Generator().manual_seed(5))
     plain = run_gpu_trace(mc, sd, o, d, om, True, steps, 'f16x3w', pm=pm)
     ignored = run_gpu_trace(mc, sd, o, d, om, True, steps, 'f16x3w', pm=pm, minsdf_lipschitz=2.0)
-    evalm = run_gpu_trace(mc, sd, o, d, om, False, steps, 'f16x3w', coarse_tau=tau, pm=pm, minsdf_lipschitz=2.0)
-    evalb = run_gpu_trace(mc, sd, o, d, om, False, steps, 'f16x3w', coarse_tau=tau, pm=pm)
     for k in range(3):
         assert torch.equal(plain[k], ignored[k]), 'the staged search ran without a coarse pass'
-        assert torch.equal(evalm[k], evalb[k])
-    assert ignored[3][:, 11].sum() == 0 and evalm[3][:, 11].sum() == 0
+    assert ignored[3][:, 11].sum() == 0
+    # Eval-mode traces (no min-SDF search): the BRACKET search is staged - same first negative sample, same bracket, same
+    # argmin fallback.  Primary rays, and secondary ones as the Monte-Carlo renderer sends them: from the hit points into the
+    # hemisphere about the normal (origins inside the bounding sphere start 0.01 along the ray).
+    hits = plain[1].bool()
+    hp = plain[0][hits][:4000]
+    nrm = torch.nn.functional.normalize(ops.sdf_value_grad(pm32, hp)[2], dim=1)
+    w2 = torch.nn.functional.normalize(torch.randn(hp.shape[0], 3, generator=torch.Generator().manual_seed(9)), dim=1).to(DEV)
+    w2 = torch.where((w2 * nrm).sum(1, keepdim=True) < 0, -w2, w2)
+    ones = torch.ones(hp.shape[0], dtype=torch.bool)
+    for what, (oo, dd, mm) in (('primary', (o, d, om)), ('secondary', (hp.cpu(), w2.cpu(), ones))):
+        for tier in (0, 1):
+            evalb = run_gpu_trace(mc, sd, oo, dd, mm, False, steps, 'f16x3w', coarse_tau=tau, pm=pm, trace_tier=tier)
+            cb = evalb[3].cpu().long()
+            _, coarse0 = ops.executed_evals(cb, 100)
+            for f in (1.0, 1.5, 4.0):
+                evalm = run_gpu_trace(mc, sd, oo, dd, mm, False, steps, 'f16x3w', coarse_tau=tau, pm=pm, trace_tier=tier,
+                                      minsdf_lipschitz=f * gmax)
+                for k, name_k in enumerate(('points', 'hit mask', 'depths')):
+                    assert torch.equal(evalm[k], evalb[k]), (case, what, tier, f, name_k, (evalm[2] - evalb[2]).abs().max().item())
+                c = evalm[3].cpu().long()
+                assert ops.algorithmic_evals(c, 100).sum() == ops.algorithmic_evals(cb, 100).sum()
+                assert c[:, 12].max() == 0, 'the audit of the slope bound fired in the bracket search at %.2f x' % f
+                _, coarse = ops.executed_evals(c, 100)
+                if f == 1.5 and not tier:
+                    print('[staged bracket %s %s] %d searches: single-pass evaluations %d -> %d (x %.2f), %d second-stage samples' % (
+                        case, what, cb[:, 6].sum().item(), coarse0.sum().item(), coarse.sum().item(),
+                        coarse.sum().item() / max(coarse0.sum().item(), 1), c[:, 11].sum().item()))
     for tier, group in ((0, 0), (1, 0), (0, 500)):
         st = rows.reshape(-1) if group else steps
         kw = dict(trace_tier=tier, minsdf_group=group)

@@ -53,12 +53,10 @@ def test_host_side_argument_checks_need_no_gpu():
     assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 2 * (1 + 10 * 4) + 1 + 7 + 1 + 2 + 7
     p.trace_tier = 0
     w1 = lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p))
-    p.minsdf_lipschitz = 1.5     # staged min-SDF search: training mode only; one round more, a list of 48 single depths per ray, the sorted order of the draws
-    assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2 + 7
-    p.training = 1
+    p.minsdf_lipschitz = 1.5     # staged searches: one round more, a list of 76 single samples per ray, the sorted order of the min-SDF draws
     assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2 + 7 + 1
-    assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) >= w1 + 4096 * 48 * 4 + 100
-    p.training, p.minsdf_lipschitz = 0, 0.0
+    assert lib.nefii_trace_workspace_bytes(4096, ctypes.byref(p)) >= w1 + 4096 * 76 * 4 + 100
+    p.minsdf_lipschitz = 0.0
     p.coarse_tau = 0.0
     p.trace_tier = 1             # ... and is the coarse pass's: nothing without it
     assert lib.nefii_trace_max_rounds(ctypes.byref(p)) == 1 + 10 * 4 + 1 + 7 + 1 + 2
