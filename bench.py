@@ -417,10 +417,11 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                 # single-pass evaluator, and how many of them had to be repeated in split precision
                 'trace_tier': bool(model.ray_tracer.tier_for(rays_per_rank)),
                 'tier_queries_single_pass': tier_queries, 'tier_queries_repeated': tier_repeats,
-                # staged min-SDF search (nefii_tracer_params.minsdf_lipschitz): the measured slope bound in use (0: off), the
-                # depths its second stage evaluated one by one (the first stage's are a quarter row per search, counted with
-                # the single-pass evaluations), dense searches entered (bracket + min-SDF; the reference evaluates n_steps depths
-                # for each), and the audit: the largest amount a second-stage depth lay below the bound that kept it (0 = held)
+                # staged searches (nefii_tracer_params.minsdf_lipschitz: the min-SDF search, and the bracket search of eval-mode
+                # traces and of rays outside the mask): the measured slope bound in use (0: off), the samples their second stages
+                # evaluated one by one (the first stage's are a quarter row per search, counted with the single-pass
+                # evaluations), dense searches entered (bracket + min-SDF; the reference evaluates n_steps samples for each), and
+                # the audit: the largest amount an evaluated sample lay below the lower bound it was given (0 = the bound held)
                 'minsdf_lipschitz': float(model.implicit_network.minsdf_lipschitz(model.ray_tracer.object_bounding_sphere))
                 if (model.ray_tracer.minsdf_staged and coarse_tau > 0) else 0.0,
                 'minsdf_second_stage_depths': int(cnt[:, 11].sum().item()), 'dense_searches_entered': int(cnt[:, 6].sum().item()),

@@ -34,7 +34,14 @@ for tier in 0 1; do
     NEFII_TRACE_TIER=$tier python3 bench.py --workload cfg3 --steps 10 --warmup 3 --no-cpu-baseline --no-side-measurement 2> /dev/null | tail -1 > $O/bench_cfg3_tier$tier.json
     NEFII_TRACE_TIER=$tier python3 bench.py --workload cfg4 --steps 10 --warmup 3 --no-cpu-baseline --no-side-measurement 2> /dev/null | tail -1 > $O/bench_cfg4_tier$tier.json
 done
-for st in 0 1; do      # the staged min-SDF search, same box
+python3 tools/trace_rounds_secondary.py cfg3 2> /dev/null | grep -v "Warning\|WeightNorm\|amdgpu" > $O/rounds_cfg3_secondary.txt
+for st in 0 1; do      # the staged bracket search alone (the staged min-SDF search stays on), same box
+    for w in cfg3 cfg4; do
+        NEFII_BRACKET_STAGED=$st python3 bench.py --workload $w --steps 10 --warmup 5 --no-cpu-baseline --no-side-measurement 2> /dev/null | tail -1 > $O/bench_${w}_bracket$st.json
+    done
+    NEFII_BRACKET_STAGED=$st python3 bench.py --workload cfg5 --frame-rows 32 2> /dev/null | tail -1 > $O/bench_cfg5_bracket$st.json
+done
+for st in 0 1; do      # both staged searches (NEFII_MINSDF_STAGED switches the slope bound off altogether), same box
     for w in cfg3 cfg4 cfg2; do
         NEFII_MINSDF_STAGED=$st python3 bench.py --workload $w --steps $([ $w = cfg2 ] && echo 200 || echo 10) --warmup 5 --no-cpu-baseline --no-side-measurement 2> /dev/null | tail -1 > $O/bench_${w}_staged$st.json
     done
