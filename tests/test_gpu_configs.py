@@ -232,6 +232,45 @@ def test_secondary_trace_without_the_miss_search_changes_nothing_that_is_read(wl
     print('[%s] algorithmic SDF evaluations %d -> %d' % (wl, evals[1], evals[0]))
 
 
+@pytest.mark.parametrize('wl', ['cfg3', 'cfg4', 'cfg2'])
+def test_staged_searches_change_no_output_at_full_size(wl):
+    """The staged min-SDF and bracket searches (nefii_tracer_params.minsdf_lipschitz, ABI 13) on the config's FULL batch - what
+    bench.py times, where the tier, the quarter-row windows and the secondary trace of the Monte-Carlo configs are all in play:
+    a forward of the model with RayTracing.minsdf_staged off and on gives BIT-IDENTICAL output dicts (same uniform draws), the
+    audit of the slope bound stays silent, the reference's algorithmic evaluation count is the same and fewer single-pass
+    evaluations are executed."""
+    from nefii_amd import ops
+    w = syn.WORKLOADS[wl]
+    mc, sd = syn.workload_state_dict(wl, seed=0)
+    inp, gt = syn.make_inputs(w['num_pixels'], w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=3)
+    g = torch.Generator().manual_seed(11)
+    steps1, steps2 = torch.rand(100, generator=g), torch.rand(100, generator=g)
+    outs, cnts = [], []
+    for staged in (False, True):
+        m = build_model(mc, sd, True)
+        m.ray_tracer.minsdf_staged = staged
+        m.ray_tracer.minsdf_steps_override = [steps1, steps2]
+        m.ray_tracer.collect_counters = True
+        m.ray_tracer.counter_sum = None
+        torch.manual_seed(5)                      # the Monte-Carlo sampler's draws
+        with torch.no_grad():
+            outs.append(m(to_dev(inp)))
+        torch.cuda.synchronize()
+        cnts.append(m.ray_tracer.counter_sum.cpu().long())
+        assert not m.implicit_network.coarse_audit_events
+    plain, staged = outs
+    for k, v in plain.items():
+        if torch.is_tensor(v):
+            assert torch.equal(staged[k], v), (wl, k)
+    c0, c1 = cnts
+    assert c0[:, 11].sum() == 0 and c1[:, 11].sum() > 0 and c1[:, 12].max() == 0
+    assert ops.algorithmic_evals(c1, 100).sum() == ops.algorithmic_evals(c0, 100).sum()
+    (s0, e0), (s1, e1) = ops.executed_evals(c0, 100), ops.executed_evals(c1, 100)
+    print('[%s full size] single-pass evaluations %d -> %d (x %.2f), split-precision %d -> %d' % (
+        wl, e0.sum().item(), e1.sum().item(), e1.sum().item() / e0.sum().item(), s0.sum().item(), s1.sum().item()))
+    assert e1.sum() < 0.8 * e0.sum() and abs(s1.sum().item() - s0.sum().item()) <= 0.02 * s0.sum().item()
+
+
 @pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg4'])
 def test_config_full_size_properties(wl):
     """One training step (TrainStep: forward, IDRLoss, backward, 2 x Adam, secondary-consistency step where the conf has
