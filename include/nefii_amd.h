@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 13
+#define NEFII_ABI_VERSION 14
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -266,6 +266,13 @@ typedef struct nefii_tracer_params {
                                 mask and surely has a negative sample in front of which only signs matter, above the lowest
                                 value seen + coarse_tau - is never evaluated; the first negative sample, the bracket and the
                                 argmin fallback are the full row's.  0: off (all n_steps depths / samples are evaluated). */
+    int32_t unread_misses;   /* ABI 14 - 1: the caller reads nothing of the rays that end WITHOUT a hit (out_points / out_dists of
+                                such rays are then unspecified, out_hit is exact).  Honoured for eval-mode traces (training == 0):
+                                the bracket search's argmin fallback (:221-231: a ray without a negative sample takes the depth
+                                of its lowest sample) is not computed - no refinement of the samples near the minimum, and the
+                                staged search skips every sample its bound proves positive.  Hit masks, hit points and hit
+                                depths are those of unread_misses == 0 bit for bit.  What the Monte-Carlo renderer's secondary
+                                rays need (path_tracing_render.py: visibility and the radiance at secondary HITS). */
 } nefii_tracer_params;
 #define NEFII_TRACE_COUNTERS 13  /* int32 counters per round, see nefii_trace_rays */
 

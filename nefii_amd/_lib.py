@@ -14,7 +14,7 @@ MAX_LAYERS = 12
 TILE_ROWS = 32
 MAX_WIDTH = 512
 MAX_ENC = 96
-ABI_VERSION = 13
+ABI_VERSION = 14
 TRACE_COUNTERS = 13         # int32 counters per tracer round (NEFII_TRACE_COUNTERS)
 
 ACT_RELU, ACT_ELU, ACT_SOFTPLUS100 = 0, 1, 2
@@ -42,7 +42,8 @@ class TracerParams(ctypes.Structure):
                 ('n_rootfind_steps', ctypes.c_int32), ('training', ctypes.c_int32), ('bisect_levels', ctypes.c_int32),
                 ('precision', ctypes.c_int32), ('coarse_tau', ctypes.c_float), ('coarse_cap', ctypes.c_int32),
                 ('minsdf_group', ctypes.c_int32), ('small_round', ctypes.c_int32), ('trace_tier', ctypes.c_int32),
-                ('tier_kappa', ctypes.c_float), ('tier_gate', ctypes.c_float), ('minsdf_lipschitz', ctypes.c_float)]
+                ('tier_kappa', ctypes.c_float), ('tier_gate', ctypes.c_float), ('minsdf_lipschitz', ctypes.c_float),
+                ('unread_misses', ctypes.c_int32)]
 
 
 class PackSource(ctypes.Structure):

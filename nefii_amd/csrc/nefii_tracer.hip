@@ -98,6 +98,7 @@ struct Params {
     float tier_gate;         //              a step / back-off query goes to the coarse evaluator when the step that led to it is > tier_gate
     float lip;               // staged min-SDF search: Lipschitz bound of the SDF along a ray (0: off)
     int stage_bracket;       //              ... and the bracket search of eval-mode traces / rays outside the mask staged too
+    int miss_argmin;         // eval-mode bracket search: the argmin fallback of rays WITHOUT a negative sample is computed (1; 0: nobody reads it)
     RayState s;
 };
 
@@ -523,9 +524,10 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             best = fminf(best, v[i]);
             if (v[i] < -P.tau && j1 == ns) j1 = i;
         }
-        const bool sign_only = obj && j1 < ns && !(v[0] < P.tau);       // (sample 0 possibly negative: the row is decided as a whole)
+        const bool front_only = obj && j1 < ns && !(v[0] < P.tau);      // (sample 0 possibly negative: the row is decided as a whole)
+        const bool sign_only = front_only || !P.miss_argmin;
         const float lim = sign_only ? 0.f : fmaxf(0.f, fadd(best, P.tau));
-        const int last = sign_only ? j1 : ns - 1;
+        const int last = front_only ? j1 : ns - 1;
         int ja = 0, k = 0;
         float worst = 0.f;
         int probe = -1;
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
             vmin = x < vmin ? x : vmin;
         }
         const bool obj = P.obj[r] != 0;
-        const bool need_argmin = !(obj && i1 >= 0);
+        const bool need_argmin = P.miss_argmin && !(obj && i1 >= 0);
         int n_sign = 0, n_min = 0;
         if (i0 >= 0) {
             const int end = i1 >= 0 ? i1 : ns;
@@ -2455,6 +2457,8 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
         }();
         P.stage_bracket = v;
     }
+    if (h_params->unread_misses < 0 || h_params->unread_misses > 1) return NEFII_E_ARG;
+    P.miss_argmin = !(h_params->unread_misses && !h_params->training);
     // (the workspace is laid out by the PARAMETERS, as nefii_trace_workspace_bytes sized it, whether or not the net takes the coarse pass)
     const int64_t step_rows = minsdf_staged(h_params) ? minsdf_rows(n_rays, &P.p) : 0;
     size_t off = carve(P.s, (char *)workspace, n_rays, h_params->n_steps, P.cap, step_rows);

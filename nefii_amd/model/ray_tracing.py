@@ -49,8 +49,9 @@ class RayTracing(nn.Module):
         self.draw_when_skipped = False
         # False while a caller traces rays whose MISS outputs nothing reads (the secondary rays of pt_render_indirect_mlp:
         # their only consumer masks them with the hit mask, idr_train.py:819): the trace then runs the reference's
-        # eval-mode recurrences (ray_tracing.py:62-96 without the `if self.training` blocks) - no min-SDF search for the
-        # rays that leave without a hit, no argmin fallback in the bracket search - whose hits are the training path's
+        # eval-mode recurrences (ray_tracing.py:62-96 without the `if self.training` blocks: no min-SDF search for the rays
+        # that leave without a hit) with nefii_tracer_params.unread_misses (ABI 14: no argmin fallback in the bracket search
+        # either) - whose hits are the training path's
         self.miss_search = True
         # True while TrainStep traces several batches as ONE call (cam_loc [G,3], ray_directions [G,S,3]): every batch keeps
         # the uniform draw of the min-SDF search the reference makes per call (ray_tracing.py:316), in batch order
@@ -217,7 +218,8 @@ class RayTracing(nn.Module):
                                         coarse_cap=self.coarse_cap, minsdf_group=group,
                                         small_round=self.small_round_for(n_rays, self.concurrent),
                                         trace_tier=self.tier_for(n_rays), tier_kappa=self.tier_kappa,
-                                        tier_gate=self.tier_gate, minsdf_lipschitz=lip)
+                                        tier_gate=self.tier_gate, minsdf_lipschitz=lip,
+                                        unread_misses=0 if self.miss_search else 1)
         state = None
         if self.adaptive_rounds:      # one guess per (mode, batch size): primary and secondary traces differ
             import math

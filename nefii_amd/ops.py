@@ -525,8 +525,9 @@ PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}
 
 
 def make_tracer_params(cfg, training, precision='f32', bisect_levels=3, coarse_tau=0.0, coarse_cap=0, minsdf_group=0,
-                       small_round=0, trace_tier=0, tier_kappa=0.0, tier_gate=0.0, minsdf_lipschitz=0.0):
+                       small_round=0, trace_tier=0, tier_kappa=0.0, tier_gate=0.0, minsdf_lipschitz=0.0, unread_misses=0):
     p = TracerParams()
+    p.unread_misses = 1 if unread_misses else 0
     p.minsdf_lipschitz = float(minsdf_lipschitz) if coarse_tau > 0.0 else 0.0
     p.trace_tier = 1 if (trace_tier and coarse_tau > 0.0) else 0
     p.tier_kappa = float(tier_kappa)

@@ -917,6 +917,23 @@ def test_tracer_staged_min_sdf_search(case):
                     print('[staged bracket %s %s] %d searches: single-pass evaluations %d -> %d (x %.2f), %d second-stage samples' % (
                         case, what, cb[:, 6].sum().item(), coarse0.sum().item(), coarse.sum().item(),
                         coarse.sum().item() / max(coarse0.sum().item(), 1), c[:, 11].sum().item()))
+            # nefii_tracer_params.unread_misses (ABI 14): nothing of the rays that end without a hit is read - no argmin fallback,
+            # with and without the staging; hit mask, hit points and hit depths stay bit-identical
+            split0, _ = ops.executed_evals(cb, 100)
+            for lip in (0.0, 1.5 * gmax):
+                um = run_gpu_trace(mc, sd, oo, dd, mm, False, steps, 'f16x3w', coarse_tau=tau, pm=pm, trace_tier=tier,
+                                   minsdf_lipschitz=lip, unread_misses=1)
+                h = evalb[1].bool()
+                assert torch.equal(um[1], evalb[1]), (case, what, tier, lip, 'hit mask')
+                assert torch.equal(um[0][h], evalb[0][h]) and torch.equal(um[2][h], evalb[2][h]), (case, what, tier, lip)
+                assert torch.isfinite(um[0]).all() and torch.isfinite(um[2]).all()
+                cu = um[3].cpu().long()
+                assert cu[:, 12].max() == 0
+                splitu, coarseu = ops.executed_evals(cu, 100)
+                assert splitu.sum() <= split0.sum() and coarseu.sum() <= coarse0.sum() + cb[:, 6].sum() * 2
+                if not tier and lip > 0:
+                    print('[unread misses %s %s] split-precision evaluations %d -> %d, single-pass %d -> %d' % (
+                        case, what, split0.sum().item(), splitu.sum().item(), coarse0.sum().item(), coarseu.sum().item()))
     for tier, group in ((0, 0), (1, 0), (0, 500)):
         st = rows.reshape(-1) if group else steps
         kw = dict(trace_tier=tier, minsdf_group=group)

@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     # nefii_layer: 4 x int32 + 4 pointers; nefii_mlp: 8 x int32 + 12 layers
     assert ctypes.sizeof(_lib.Layer) == 16 + 5 * 8
     assert ctypes.sizeof(_lib.Mlp) == 40 + 12 * ctypes.sizeof(_lib.Layer)
-    assert ctypes.sizeof(_lib.TracerParams) == 72         # 3 floats + 7 int32 + coarse_tau + coarse_cap + minsdf_group + small_round + trace_tier + tier_kappa + tier_gate + minsdf_lipschitz
+    assert ctypes.sizeof(_lib.TracerParams) == 76         # 3 floats + 7 int32 + coarse_tau + coarse_cap + minsdf_group + small_round + trace_tier + tier_kappa + tier_gate + minsdf_lipschitz + unread_misses
     assert ctypes.sizeof(_lib.RowBlock) == 32             # 2 pointers + cols + src_row_stride + fill + reserved
     assert ctypes.sizeof(_lib.PackSource) == 48           # 2 pointers + 6 int32 + scale + skip_f32
 
