@@ -91,8 +91,8 @@ class ImplicitNetwork(nn.Module):
 
     def minsdf_lipschitz(self, radius=1.0):
         """Bound on the SDF's slope along a ray for the current weights (ops.calibrate_lipschitz: 1.5 x the largest |grad sdf|
-        over 65 536 points of the bounding sphere), measured once per packed version; 0.0 after the tracer's audit has seen it
-        fail (note_coarse_audit)."""
+        found in the bounding sphere by a random sample and a local search around its steepest points), measured once per
+        packed version; 0.0 after the tracer's audit has seen it fail (note_lipschitz_audit)."""
         self.packed(f16x3=True)
         if self._lip is None or self._lip[0] != self._pm_version or self._lip[1] != radius:
             with torch.no_grad():
