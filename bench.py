@@ -704,10 +704,11 @@ def main():
     nested = {}
     if args.workload is None and not args.no_nested:
         short = dict(steps=max(1, min(args.steps, 20)), warmup=min(args.warmup, 3))
-        nested['cfg2'] = run_workload('cfg2', args, short['steps'], short['warmup'], rank, world, dev, backend, lib,
+        # (config 2's traces are enqueued in groups of four, four groups ahead: some twenty steps until the schedule has settled)
+        nested['cfg2'] = run_workload('cfg2', args, max(short['steps'], 24), max(short['warmup'], 24), rank, world, dev, backend, lib,
                                       side=True, sustained=sustained)
-        nested['cfg2_near'] = run_workload('cfg2_near', args, short['steps'], short['warmup'], rank, world, dev, backend, lib,
-                                           side=False, sustained=sustained)
+        nested['cfg2_near'] = run_workload('cfg2_near', args, max(short['steps'], 24), max(short['warmup'], 24), rank, world, dev,
+                                           backend, lib, side=False, sustained=sustained)
         # (config 1's traces are enqueued in groups of eight, four groups ahead: some forty steps until the schedule has settled;
         # a step is under a millisecond)
         nested['cfg1'] = run_workload('cfg1', args, max(short['steps'], 96), max(short['warmup'], 48), rank, world, dev, backend,

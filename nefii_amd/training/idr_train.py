@@ -261,7 +261,7 @@ class IDRTrainRunner:
             self.train_sampler_generator.manual_seed(epoch)
             resample = getattr(self.loss, 'sample_each_iter', False)
 
-            def batches():       # batches of lookahead (3; 11 or 31 when small batches are traced in groups): TrainStep traces
+            def batches():       # batches of lookahead (3; 15 or 31 when small batches are traced in groups): TrainStep traces
                                  # them beside the tail of the current one
                 window = []
                 for item in self.train_dataloader:

@@ -484,8 +484,9 @@ class TrainStep:
         several at a time: a lone trace of a few hundred rays is all launch and tile latency, and one call of several
         batches costs hardly more than one of one.  Config 1 (512 rays), ms per step by group size, round 5: 3: 0.89, 4: 0.72,
         6: 0.63, 8: 0.61, 12: 0.63 - eight (4096 rays per call; before the coarse pass and the staged min-SDF search reached
-        such calls, three was the optimum: 1.95 -> 1.63).  From a few thousand rays on it no longer pays - config 2 (4096
-        rays): 2.26 / 2.36 / 2.22 for 1 / 2 / 3 - and big batches fill the chip on their own: 1.  NEFII_TRACE_GROUP overrides."""
+        such calls, three was the optimum: 1.95 -> 1.63).  Config 2 (4096 rays), on the round's final tree: 1: 2.27, 3: 2.18, 4:
+        2.04, 6: 2.01 - four (16 384 rays per call: a call stays below RayTracing.TIER_MIN_RAYS, so grouping never changes which
+        arithmetic a batch is traced with).  Bigger batches fill the chip on their own: 1.  NEFII_TRACE_GROUP overrides."""
         env = os.environ.get('NEFII_TRACE_GROUP')
         if env:
             return max(1, int(env))
@@ -493,7 +494,7 @@ class TrainStep:
         if uv.shape[0] != 1:
             return 1
         n_rays = uv.shape[1] * (uv.shape[2] if uv.dim() == 4 else 1)
-        return 8 if n_rays <= 1024 else (3 if n_rays <= 2048 else 1)
+        return 8 if n_rays <= 1024 else (4 if n_rays <= 4096 else 1)
 
     def preferred_lookahead(self, model_input):
         """Upcoming batches a caller should hand to __call__ (next_input): three traces in flight for big batches; for

@@ -754,7 +754,7 @@ def test_steps_on_traces_enqueued_ahead_do_not_synchronise_the_callers_stream(mo
     """A graph step whose trace was enqueued ahead must not call torch.nonzero, Tensor.cpu or Tensor.item on the way (they
     would wait for the previous step's tail on the caller's stream and keep the host from running ahead: round 3's config 1
     spent half of its step there): hit lists, hit counts and the tracer's round counters arrive through pinned memory from
-    the trace stream.  Checked for config 1's shape (traces grouped eight at a time) and config 2's (one at a time)."""
+    the trace stream.  Checked for config 1's shape (traces grouped eight at a time) and config 2's (four at a time)."""
     from nefii_amd.training.step import TrainStep
     for name, pixels in (('cfg1', 512), ('cfg2', 4096)):
         w = syn.WORKLOADS[name]
@@ -764,7 +764,7 @@ def test_steps_on_traces_enqueued_ahead_do_not_synchronise_the_callers_stream(mo
         inp, gt = to_dev(inp), {'rgb': gt.to(DEV)}
         st = TrainStep(m, syn.loss_conf(w['model']), graph=True)
         nxt = [inp] * st.preferred_lookahead(inp)
-        for _ in range(12 if name == 'cfg2' else 40):     # eager steps, the capture, the tracer's round guess settle (per tracer call)
+        for _ in range(24 if name == 'cfg2' else 40):     # eager steps, the capture, the tracer's round guess settle (per tracer call)
             st(inp, gt, nxt)
         torch.cuda.synchronize()
         calls = []
@@ -772,7 +772,7 @@ def test_steps_on_traces_enqueued_ahead_do_not_synchronise_the_callers_stream(mo
         monkeypatch.setattr(torch, 'nonzero', lambda t, *a, **k: (calls.append('nonzero') if t.is_cuda else None, real_nonzero(t, *a, **k))[1])
         monkeypatch.setattr(torch.Tensor, 'cpu', lambda t, *a, **k: (calls.append('cpu') if t.is_cuda else None, real_cpu(t, *a, **k))[1])
         monkeypatch.setattr(torch.Tensor, 'item', lambda t: (calls.append('item') if t.is_cuda else None, real_item(t))[1])
-        for _ in range(9 if name == 'cfg2' else 17):     # (config 1: at least two tracer calls of eight batches)
+        for _ in range(9 if name == 'cfg2' else 17):     # (at least two tracer calls: of four batches for config 2, of eight for config 1)
             out, lo = st(inp, gt, nxt)
         monkeypatch.undo()
         torch.cuda.synchronize()
