@@ -151,3 +151,32 @@ def test_counter_sums_keep_the_audit_column_a_maximum_and_the_parameter_list_cac
     for _ in range(300):
         p2 = ops.param_list(lin)
     assert p2[3] is lin[1].bias
+
+
+def test_slope_bound_audit_bookkeeping():
+    """Host side of the staged searches' audit (ImplicitNetwork.note_lipschitz_audit): nothing happens without a violation or
+    without a claim; a violation warns, records the event TrainStep re-traces on and turns the claim off for these weights; and
+    the tracer's callback does not blame the slope bound for a trace whose coarse bound failed (its premise |coarse - exact| <
+    tau is then void)."""
+    import warnings
+    from nefii_amd import conf, synthetic as syn
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    mc = syn.model_conf('physg', hidden=64)
+    net = IDRNetwork(conf.from_dict(mc)).implicit_network
+    net._pm_version = 7
+    net.note_lipschitz_audit(1e-2, 2.0)                 # no claim on record: ignored
+    assert not net.coarse_audit_events
+    net._lip = (7, 1.0, 2.0)
+    net.note_lipschitz_audit(0.0, 2.0)                  # the bound held
+    net.note_lipschitz_audit(1e-2, 0.0)                 # a trace that did not use it
+    assert not net.coarse_audit_events and net._lip[2] == 2.0
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        net.note_lipschitz_audit(3e-3, 2.0)
+    assert any('staged min-SDF search' in str(x.message) for x in w)
+    assert net.coarse_audit_events == [('lipschitz_disabled', pytest.approx(3e-3), 2.0)] and net._lip == (7, 1.0, 0.0)
+    net.note_lipschitz_audit(3e-3, 2.0)                 # already off: no second event
+    assert len(net.coarse_audit_events) == 1
+    net._lip = (6, 1.0, 2.0)                            # a claim about OTHER weights (stale version): ignored
+    net.note_lipschitz_audit(3e-3, 2.0)
+    assert len(net.coarse_audit_events) == 1
