@@ -58,6 +58,9 @@ def gpu_forward_with_per_ray_draws(m, inp, uniforms):
 
 
 SHRUNK = {'cfg2': 256, 'cfg3': 48, 'cfg4': 48}
+# 'cfg2-coarse': 2048 rays - above RayTracing.coarse_min_rays, so that config 2's model-level path is ALSO compared with the oracle
+# with the coarse pass and the staged min-SDF search in it (the 256-ray case runs every sample in split precision)
+SHRUNK_CASE = {'cfg2-coarse': 2048, 'cfg2-coarse-tier': 2048}
 # measured on these exact workloads (round 4): every count of discrete differences between the HIP path and the oracle
 # (a sampled lobe that differs = a uniform draw within rounding of a CDF boundary: 3 rays of config 3's 3072 with the
 # replicated embedding of the stand-in geometry, whose feature vector - and with it the lobe weights - differs from the
@@ -65,11 +68,12 @@ SHRUNK = {'cfg2': 256, 'cfg3': 48, 'cfg4': 48}
 PINNED_DISCRETE = {'cfg2': {'flips': 0}, 'cfg3': {'flips': 0, 'dir': 2, 'vis': 0}, 'cfg3-bowl': {'flips': 0, 'dir': 2, 'vis': 0},
                    'cfg3-dense': {'flips': 0, 'dir': 5, 'vis': 0}, 'cfg4': {'flips': 0}, 'cfg4-dense': {'flips': 0},
                    'cfg3-tier': {'flips': 0, 'dir': 20, 'vis': 0}, 'cfg4-tier': {'flips': 0},
-                   'cfg3-dense-tier': {'flips': 0, 'dir': 30, 'vis': 0}, 'cfg3-frame': {'flips': 2, 'dir': 8, 'vis': 2}}
+                   'cfg3-dense-tier': {'flips': 0, 'dir': 30, 'vis': 0}, 'cfg3-frame': {'flips': 2, 'dir': 8, 'vis': 2},
+                   'cfg2-coarse': {'flips': 0}, 'cfg2-coarse-tier': {'flips': 0}}
 
 
 @pytest.mark.parametrize('wl', ['cfg2', 'cfg3', 'cfg3-bowl', 'cfg3-dense', 'cfg4', 'cfg4-dense', 'cfg3-tier', 'cfg4-tier',
-                                'cfg3-dense-tier', 'cfg3-frame'])
+                                'cfg3-dense-tier', 'cfg3-frame', 'cfg2-coarse', 'cfg2-coarse-tier'])
 def test_config_shrunk_in_pixels_vs_oracle(wl):
     """The config's model at full network width, its geometry stand-in, camera and rays per pixel (64 for configs 3-4);
     only the number of pixels is reduced.  Forward + IDRLoss + backward against the CPU oracle with injected draws:
@@ -96,7 +100,7 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
     mc, sd = syn.workload_state_dict(wl, seed=0, scene=scene)
     lc = syn.loss_conf(w['model'])
     # (the 12 patches of seed 1 all miss the thin frame; seed 4's see bars, plate and ball: hit fraction 0.24)
-    inp, gt = syn.make_inputs(SHRUNK[wl], w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'],
+    inp, gt = syn.make_inputs(SHRUNK_CASE.get(bound_key, SHRUNK[wl]), w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'],
                               seed=4 if scene == 'frame_trained' else 1)
     flat, gt_flat, R = per_ray_layout(inp, gt)
     n_ray = flat['uv'].shape[1]
@@ -128,6 +132,9 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
     stats = compare_outputs(out, ref, max_flips=max(2, n_ray // 1000), what=bound_key + ' shrunk', rays_per_pixel=1,
                             ray_hit=m.last_ray_hit, ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02,
                             tol_aux=4e-3 if tier else None)
+    if 'coarse' in bound_key:
+        c = m.ray_tracer.counter_sum
+        assert c[:, 5].sum() > 0 and c[:, 11].sum() > 0 and c[:, 12].max() == 0, 'the coarse pass / the staged search did not run'
     if tier:
         c9 = m.ray_tracer.counter_sum[:, 9].sum().item()
         assert c9 > 0.3 * (c9 + m.ray_tracer.counter_sum[:, 0].sum().item()), 'the tier did not run'
@@ -169,7 +176,7 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
             # cancellation, on which the fp32 oracle itself is 2.4e-3 from an fp64 one - follow: 8.2e-3 measured)
             assert rel_l2(p.grad, gref) < {'cfg2': 1.5e-3, 'cfg3': 3e-3, 'cfg3-bowl': 3e-3, 'cfg3-dense': 6e-3, 'cfg4': 6e-3,
                                            'cfg4-dense': 6e-3, 'cfg3-tier': 1.5e-2, 'cfg4-tier': 1.2e-2, 'cfg3-dense-tier': 1.5e-2,
-                                           'cfg3-frame': 6e-3}[bound_key], (name, rel_l2(p.grad, gref))
+                                           'cfg3-frame': 6e-3, 'cfg2-coarse': 1.5e-3, 'cfg2-coarse-tier': 3e-3}[bound_key], (name, rel_l2(p.grad, gref))
     print('[%s] worst parameter-gradient rel-L2 %.2e' % (wl, worst))
     # ---- algorithmic SDF evaluations: tracer counters (primary + secondary traces) = the oracle's evaluation counts
     cnt = m.ray_tracer.counter_sum.cpu().long()
