@@ -13,17 +13,25 @@ patch split) and gradients are averaged by one RCCL all-reduce per step: weak sc
 max-over-ranks time.  `python bench.py --gpus N` without a launcher starts its own N ranks (torch.distributed.run, as child
 processes, before anything touches a GPU).
 
-Prints ONE JSON line (rank 0).  Beside the headline it carries shorter measurements of the other BASELINE configs under
-"cfg1", "cfg2" (with its own CPU baseline and parity), "cfg2_camera_at_1.6", "cfg4" (N > 1: --scaling strong, its global
-8192 pixels split over the ranks as the dataset does) and "cfg5" (a band of rows of the 800 x 800 frame at 256 rays per
-pixel, chunks dealt round-robin over the ranks); --workload X measures X alone.
+Prints ONE JSON line (rank 0), the LAST line of stdout: a flat record of < 4 KB (compact_line) - metric, value, ms_per_step,
+config, roofline, cpu_baseline, parity.  The FULL record (every definition, the nested shorter measurements of the other
+BASELINE configs: "cfg1", "cfg2" with its own CPU baseline and parity, "cfg2_camera_at_1.6", "cfg4", a band of "cfg5", the
+earlier stand-ins of config 3) goes to --full-out (default bench_full.json beside this file; round 5's 25.8 KB single line
+was more than the driver parses); --workload X measures X alone.
+
+The timed steps cycle over --cycle-batches distinct pixel batches (default 4: hit counts differ from step to step, as in
+the runner - the padded-hit-count graphs and the trace prefetch see what they see in training).  The tiered sphere
+tracing is a per-run switch: this benchmark turns it ON for every workload (config.trace_tier; NEFII_TRACE_TIER=0
+for the untiered run, whose ms_per_step the line also carries as ms_per_step_untiered).
 
 `roofline` (recomputable from the numbers in the line): the tracer's SDF-evaluation kernels (eval_kernel16q: split
 precision, 3 fp16 MFMAs per product; eval_kernel16s: the single-pass coarse evaluator) against the dense fp16 MFMA peak
 (2.5 PFLOP/s, MI355X_MICROARCH.md) in ALGORITHMIC flops:
-  frac = frac_kernel = sdf_evals_per_step x flops_per_sdf_eval / kernel_ms_per_step / peak, the evaluations being what
-         the reference's recurrences execute (the min-SDF search included: it is executed, on these kernels), the time
-         measured live with HIP events on the launch stream over one extra un-timed step;
+  frac = the SDF evaluations the kernels EXECUTED (split precision + single pass, one F_sdf each whatever the arithmetic) x
+         flops_per_sdf_eval / kernel_ms_per_step / peak, the time measured live with HIP events on the launch stream over one
+         extra un-timed step (rounds 2-5 called this frac_executed);
+  frac_credited = the same time against the evaluations the REFERENCE's recurrences would execute (rounds 2-5's "frac"): it
+         rises when the staged searches skip work - an algorithm-level figure, not a roofline fraction;
   frac_step = SURVEY.md section 8(d)'s A x rays/s / peak: A excludes the min-SDF search (dead work under frozen
          geometry), the speculative bisection nodes and the reference's repeated SDF passes, and includes the MLP and
          shading work behind the tracer; its terms are listed under roofline.step_model.
@@ -145,9 +153,7 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None, parity_p
             m.ray_tracer.minsdf_steps_override = over
         if ref['uniforms'] is not None:
             m.uniforms_override = ref['uniforms']
-        # the parity sample is smaller than the batch the headline times: it takes the tracer's tier exactly when THAT batch does
-        if m.ray_tracer.trace_tier is None:
-            m.ray_tracer.trace_tier = bool(m.ray_tracer.tier_for(w['num_pixels'] * R_))
+        m.ray_tracer.trace_tier = bench_tier()      # the arithmetic the timed steps run (a per-run switch)
         with torch.no_grad():
             out = m({k: v.to(device) for k, v in inp.items()})
         mask = ref['network_object_mask'] & out['network_object_mask'].cpu()
@@ -187,8 +193,14 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None, parity_p
     return res, parity
 
 
+def bench_tier():
+    """The tiered sphere tracing (RayTracing.trace_tier) is a per-run switch, off by default in the library; the
+    benchmark runs every workload WITH it unless NEFII_TRACE_TIER=0."""
+    return os.environ.get('NEFII_TRACE_TIER', '1') != '0'
+
+
 def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side=True, scaling=None, sustained=None,
-                 power=False):
+                 power=False, tier=None):
     """Time `steps` training steps of WORKLOADS[name] (every rank), then measure the roofline terms in un-timed extra
     steps.  Returns the result dict on rank 0, None elsewhere."""
     import ctypes
@@ -212,13 +224,19 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     model = model.to(dev)
     model.freeze_geometry()
     model.train()
+    model.ray_tracer.trace_tier = bench_tier() if tier is None else bool(tier)
     # weak scaling (default): global batch = num_pixels * world; --scaling strong: the config's own global batch (config 4:
     # 8192 pixels) - either way the contiguous per-rank slice of the global patch list (scene_dataset.py:268-279)
     strong = (scaling or getattr(args, 'scaling', 'weak')) == 'strong'
-    inp, gt = syn.make_inputs(w['num_pixels'] * (1 if strong else world), w['image_hw'], w['focal'], w['cam_pos'],
-                              w['num_rays'], seed=1, rank=rank, world_size=world)
-    inp = {k: v.to(dev) for k, v in inp.items()}
-    gt = {'rgb': gt.to(dev)}
+    # --cycle-batches C: the steps cycle over C distinct pixel batches (seeds 1 .. C), as tools/long_train.py and the runner
+    # do: another hit count every step, so the per-padded-hit-count graphs and the trace lookahead meet what training gives them
+    n_cycle = max(1, int(getattr(args, 'cycle_batches', 1)))
+    batches = []
+    for b in range(n_cycle):
+        bi, bg = syn.make_inputs(w['num_pixels'] * (1 if strong else world), w['image_hw'], w['focal'], w['cam_pos'],
+                                 w['num_rays'], seed=1 + b, rank=rank, world_size=world)
+        batches.append(({k: v.to(dev) for k, v in bi.items()}, {'rgb': bg.to(dev)}))
+    inp, gt = batches[0]
     rays_per_rank = inp['uv'].shape[1] * (w['num_rays'] if w['num_rays'] > 0 else 1)
     rays_all_ranks = rays_per_rank * world
     if strong and world > 1:        # the last rank takes the remainder of the patch list
@@ -233,16 +251,26 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                      secondary_batch_size=1024, num_rays=w['num_rays'], graph=use_graph)
 
     # NEFII_BENCH_PREFETCH=1 (default): every step also enqueues the trace of the next batch (TrainStep.prefetch_trace)
-    nxt = inp if os.environ.get('NEFII_BENCH_PREFETCH', '1') != '0' else None
-    if nxt is not None:         # batches known ahead of time (a dataloader's prefetch queue): 3, or 5 when traced in groups of 3
-        nxt = [inp] * max(1, int(os.environ.get('NEFII_BENCH_LOOKAHEAD', str(step.preferred_lookahead(inp)))))
+    prefetch = os.environ.get('NEFII_BENCH_PREFETCH', '1') != '0'
+    look = max(1, int(os.environ.get('NEFII_BENCH_LOOKAHEAD', str(step.preferred_lookahead(inp))))) if prefetch else 0
+    it_no = [0]
+
+    def run_step():
+        """the next step of the cycle, with the batches known ahead of it (a dataloader's prefetch queue) as next_input"""
+        i = it_no[0]
+        it_no[0] = i + 1
+        bi, bg = batches[i % n_cycle]
+        ahead = [batches[(i + 1 + j) % n_cycle][0] for j in range(look)] if look else None
+        return step(bi, bg, ahead)
+
+    nxt = [inp] * look if look else None        # (the un-timed roofline passes below run ONE batch)
     for _ in range(warmup):
-        step(inp, gt, nxt)
+        run_step()
     # the graph of the step's tail is captured once per padded hit count, after 3 eager steps: with fewer warm-up steps
     # than that, run the missing ones (still untimed) so that no capture lands in the timed region
     priming = max(0, step.graph_after + 1 - warmup) if use_graph else 0     # the same count on every rank
     for _ in range(priming):
-        step(inp, gt, nxt)
+        run_step()
     # the timed region - exactly `steps` steps between barrier + synchronize on both sides, max over ranks - is measured
     # `repeats` times back to back (63 ms of a 20-step config-2 region is a thin basis for a headline: boxes and moments
     # differ by a few percent); the line reports the MEDIAN repetition and lists them all
@@ -256,7 +284,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(steps):
-                out, lo = step(inp, gt, nxt)
+                out, lo = run_step()
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -278,12 +306,13 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     ms_skip = None
     model.ray_tracer.skip_min_sdf_search = True
     if side:
+        step._prefetch = []         # traces enqueued WITH the search: dropped, the loop below starts its own queue
         for _ in range(3):
-            step(inp, gt, nxt)
+            run_step()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         for _ in range(max(steps // 2, 1)):
-            step(inp, gt, nxt)
+            run_step()
         torch.cuda.synchronize()
         ms_skip = (time.perf_counter() - t2) / max(steps // 2, 1) * 1e3
     torch.cuda.synchronize()
@@ -376,7 +405,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     # committed under profiles/ (tools/profile_round.sh; separate FETCH_SIZE / WRITE_SIZE runs, gfx950 correction applied
     # by tools/pmc_traffic.py), and only quoted for the workload / kernels it was measured on
     traffic, traffic_source = None, None
-    for rnd in ('r05', 'r04', 'r03', 'r02', 'r01'):
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02', 'r01'):
         tpath = os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic_%s.json' % name)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -386,17 +415,33 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                                   '(2*FETCH_SIZE + WRITE_SIZE per tracer round, all dispatches of the round\'s evaluation '
                                   'kernels, averaged over all rounds incl. empty ones); not measured by this run' % (rnd, name))
                 break
+    # algorithmic HBM bytes of one tracer round on the same basis as `traffic` (all rounds of the step, empty ones included):
+    # every fragment stream a round's evaluators read, once (split: hi + lo pairs; single pass: hi only), plus ~45 B per query
+    # (ray state in, value out)
+    traffic_alg = None
+    if pm is not None and getattr(pm, 'w_stream', None) is not None and n_eval.value > 0:
+        split_bytes = sum(2 * 2 * s_.k_in * s_.n_out for s_ in model.implicit_network.specs)
+        rounds_split = int((cnt[:, [0, 1, 4, 7]].sum(dim=1) > 0).sum().item())
+        rounds_single = int((cnt[:, [5, 9, 11]].sum(dim=1) > 0).sum().item())
+        traffic_alg = (split_bytes * rounds_split + split_bytes // 2 * rounds_single + 45.0 * (executed + executed_coarse)) \
+            / n_eval.value
+    achieved_executed = frac_executed * peak
     roofline = {'bound': 'mfma',
                 'kernel': kname + ' (fused SDF MLP over the tracer work list)',
-                'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak,
-                'frac_kernel': achieved / peak, 'frac_step': frac_step, 'frac_chip': frac_chip, 'frac_8d': frac_8d,
+                # frac = what the kernels EXECUTED (one F_sdf per evaluation whatever its arithmetic) / their launch time / peak
+                'achieved': achieved_executed, 'peak': peak, 'unit': 'TFLOP/s', 'frac': frac_executed,
                 'frac_executed': frac_executed,
+                # the evaluations the REFERENCE's recurrences execute against the same time (rounds 2-5 called this `frac`): rises
+                # when a staged search skips work - an algorithm-level figure
+                'achieved_credited': achieved, 'frac_credited': achieved / peak,
+                'frac_kernel': achieved / peak, 'frac_step': frac_step, 'frac_chip': frac_chip, 'frac_8d': frac_8d,
+                'traffic_algorithmic': traffic_alg,
                 'issued_tflops': issued,
                 'sustained_peak': sustained,
                 'board_power': meter.summary() if meter is not None else None,
                 'frac_of_sustained': (achieved / sustained['value']) if sustained else None,
                 'issued_frac_of_sustained': (issued / sustained['value']) if sustained else None,
-                'frac_definitions': 'frac_kernel: evaluator flops / evaluator launch time of ONE trace run serially (HIP '
+                'frac_definitions': 'frac = frac_executed; frac_credited = frac_kernel: the REFERENCE\'s evaluator flops / evaluator launch time of ONE trace run serially (HIP '
                                     'events, an extra un-timed step); frac_chip: the same flops / ms_per_step of the timed '
                                     'steps (traces overlapped); frac_step: SURVEY 8(d) A x rays/s / peak (whole step, dead '
                                     'min-SDF search excluded); frac_8d: evaluations WITHOUT the min-SDF search / the same '
@@ -415,7 +460,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                 'coarse_tau': coarse_tau,
                 # tiered sphere tracing (nefii_tracer_params.trace_tier): sphere-tracing queries of this step that ran on the
                 # single-pass evaluator, and how many of them had to be repeated in split precision
-                'trace_tier': bool(model.ray_tracer.tier_for(rays_per_rank)),
+                'trace_tier': bool(model.ray_tracer.tier_for()),
                 'tier_queries_single_pass': tier_queries, 'tier_queries_repeated': tier_repeats,
                 # staged searches (nefii_tracer_params.minsdf_lipschitz: the min-SDF search, and the bracket search of eval-mode
                 # traces and of rays outside the mask): the measured slope bound in use (0: off), the samples their second stages
@@ -466,14 +511,16 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                                   w['num_pixels'], (' x %d rays/pixel' % w['num_rays']) if w['num_rays'] > 0 else '',
                                   'indirect OFF (closed-form SG)' if not indirect else 'MC direct + near-field indirect ON'),
                    'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
-                   'step_graph': bool(use_graph),
+                   'step_graph': bool(use_graph), 'cycle_batches': n_cycle,
+                   'trace_tier': bool(model.ray_tracer.tier_for()),
+                   'synchronous_retraces': int(model.ray_tracer.retraced_calls), 'retraced_steps': int(step.retraced_steps),
                    'num_pixels_override': px_override or None,
                    'rank_param_spread': param_spread,
                    # steps cancelled by TrainStep's NaN guard: in warm-up + timed repetitions / in the whole run.  Any
                    # cancelled step makes the line INVALID (main() flags it and exits non-zero)
                    'nonfinite_steps_timed': nonfinite_timed,
                    'nonfinite_steps': int(step.nonfinite_steps.item()),
-                   'trace_prefetch': len(nxt) if nxt is not None else 0,   # batches traced ahead, beside the tail of batch i
+                   'trace_prefetch': look,   # batches traced ahead, beside the tail of batch i
                    # MC workloads: does the secondary trace also fill the outputs of rays that MISS (min-SDF search,
                    # argmin fallback)?  Nothing reads them (idr_train.py:819 masks secondary_points with the hit mask);
                    # the default skips them - every consumed output bit-identical
@@ -505,6 +552,7 @@ def run_render(name, args, frames, rank, world, dev, backend):
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     model.freeze_geometry()
+    model.ray_tracer.trace_tier = bench_tier()
     H, W = w['image_hw']
     rows = min(H, args.frame_rows) if args.frame_rows > 0 else H
     row0 = (H - rows) // 2              # a band through the middle of the frame (through the object)
@@ -540,7 +588,7 @@ def run_render(name, args, frames, rank, world, dev, backend):
             'config': {'workload': '%s: conf.conf model at full width on the non-convex stand-in, %d x %d pixels x %d rays per '
                                    'pixel, chunks of %d pixels dealt round-robin over %d rank(s) and gathered on rank 0'
                                    % (name, rows, W, w['num_rays'], (1 << level) // w['num_rays'], world),
-                       'primary_rays_per_frame': rays,
+                       'primary_rays_per_frame': rays, 'trace_tier': bool(model.ray_tracer.tier_for()),
                        # (a band through the object is dearer per pixel than the frame's average: no extrapolation from it)
                        'seconds_per_800x800_frame': elapsed / frames if rows == H else None,
                        'hit_pixel_fraction': out['network_object_mask'].float().mean().item(),
@@ -637,6 +685,111 @@ def measure_sustained(lib):
     return out
 
 
+def _r(x, nd=4):
+    """a float at nd significant digits (the compact line is a result line, not a log)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if not math.isfinite(x):
+            return None if x != x else (1e308 if x > 0 else -1e308)
+        return float('%.*g' % (nd, x))
+    return x
+
+
+def compact_line(full):
+    """The LAST line of stdout: a flat JSON object of < 4 KB holding what the driver parses - the contract's keys, `roofline`
+    (frac = what the kernels EXECUTED), `cpu_baseline`, `parity` - no prose, no nested configs.  Everything else is in the full
+    record (--full-out).  Pure function of the full record: tests/test_bench_line_cpu.py runs it on a canned one."""
+    cfg, rf = full.get('config') or {}, full.get('roofline') or {}
+    wl = str(cfg.get('workload', ''))
+    out = {'metric': full.get('metric'), 'value': _r(full.get('value'), 6), 'unit': full.get('unit'),
+           'n_gpus': full.get('n_gpus'), 'steps': full.get('steps'), 'warmup': full.get('warmup'),
+           'ms_per_step': _r(full.get('ms_per_step'), 5), 'higher_is_better': full.get('higher_is_better', True),
+           'scaling': full.get('scaling'), 'vs_baseline': full.get('vs_baseline'), 'dtype': full.get('dtype'),
+           'data': full.get('data', 'synthetic')}
+    c = {'workload': wl.split(':')[0] if wl else None}
+    for k in ('primary_rays_per_step_per_gpu', 'primary_rays_per_frame', 'parallelism', 'trace_tier', 'secondary_miss_search',
+              'step_graph', 'cycle_batches', 'trace_prefetch', 'nonfinite_steps', 'num_pixels_override', 'seconds_per_800x800_frame',
+              'hit_pixel_fraction'):
+        if cfg.get(k) is not None:
+            c[k] = _r(cfg[k])
+    out['config'] = c
+    if rf:
+        sus = rf.get('sustained_peak') or {}
+        r = {'bound': rf.get('bound'), 'kernel': str(rf.get('kernel', '')).split(' (')[0], 'unit': rf.get('unit'),
+             'achieved': _r(rf.get('achieved')), 'peak': rf.get('peak'), 'frac': _r(rf.get('frac')),
+             'frac_step': _r(rf.get('frac_step')), 'frac_credited': _r(rf.get('frac_credited', rf.get('frac_kernel'))),
+             'issued_tflops': _r(rf.get('issued_tflops')), 'issued_frac_of_sustained': _r(rf.get('issued_frac_of_sustained')),
+             'sustained_peak_tflops': _r(sus.get('value')) if isinstance(sus, dict) else None,
+             'traffic': _r(rf.get('traffic')), 'traffic_algorithmic': _r(rf.get('traffic_algorithmic')),
+             'traffic_measured_by': ('this run' if rf.get('traffic_live') else 'profiles/') if rf.get('traffic') is not None else None,
+             'kernel_ms_per_step': _r(rf.get('kernel_ms_per_step')), 'launches_per_step': rf.get('launches_per_step'),
+             'sdf_evals_executed_split_precision': rf.get('sdf_evals_executed_split_precision'),
+             'sdf_evals_executed_single_pass': rf.get('sdf_evals_executed_single_pass'),
+             'sdf_evals_reference': rf.get('sdf_evals_per_step'), 'flops_per_sdf_eval': rf.get('flops_per_sdf_eval'),
+             'coarse_tau': _r(rf.get('coarse_tau')), 'coarse_audit_max': _r(rf.get('coarse_audit_max')),
+             'minsdf_lipschitz': _r(rf.get('minsdf_lipschitz')),
+             'minsdf_lipschitz_violation': _r(rf.get('minsdf_lipschitz_violation')),
+             'lipschitz_audited_samples': rf.get('lipschitz_audited_samples'),
+             'audit_events': len(rf.get('coarse_audit_events') or []),
+             'hit_fraction': _r(rf.get('hit_fraction')), 'secondary_hit_fraction': _r(rf.get('secondary_hit_fraction'))}
+        bp = rf.get('board_power')
+        if isinstance(bp, dict):
+            r['board_power_w'], r['board_power_cap_w'] = _r(bp.get('avg_w')), _r(bp.get('cap_w'))
+        out['roofline'] = r
+    cb = full.get('cpu_baseline')
+    if cb:
+        out['cpu_baseline'] = {'value': _r(cb.get('value')), 'unit': cb.get('unit'), 'cores': cb.get('cores'), 'kind': cb.get('kind'),
+                               'value_1_thread': _r(cb.get('value_1_thread')), 'host_cpu': cb.get('host_cpu'),
+                               'host_cores': cb.get('host_cores'), 'sample': str(cb.get('sample', ''))[:96]}
+    pa = full.get('parity_vs_cpu_oracle')
+    if pa:
+        out['parity'] = {'rgb_rel_l2': _r(pa.get('rgb_rel_l2')), 'albedo_rel_l2': _r(pa.get('albedo_rel_l2')),
+                         'rgb_rel_l2_same_samples': _r(pa.get('rgb_rel_l2_same_samples')), 'tolerance_rel_l2': pa.get('tolerance_rel_l2'),
+                         'hit_pixels': pa.get('hit_pixels'), 'pixels': pa.get('pixels'), 'flips': pa.get('hit_mask_mismatches'),
+                         'rays_with_another_sampled_direction': pa.get('rays_with_another_sampled_direction'),
+                         'trace_tier': pa.get('trace_tier')}
+    out['ms_per_step_without_dead_min_sdf_search'] = _r(full.get('ms_per_step_without_dead_min_sdf_search'), 5)
+    if full.get('untiered'):
+        out['ms_per_step_untiered'] = _r(full['untiered'].get('ms_per_step'), 5)
+    others = {}
+    for k in ('cfg1', 'cfg2', 'cfg4'):
+        if isinstance(full.get(k), dict) and full[k].get('ms_per_step') is not None:
+            others[k + '_ms_per_step'] = _r(full[k]['ms_per_step'], 4)
+            others[k + '_frac'] = _r((full[k].get('roofline') or {}).get('frac'), 3)
+    if isinstance(full.get('cfg5'), dict):
+        others['cfg5_band_s'] = _r(full['cfg5'].get('ms_per_step', 0.0) / 1e3, 4)
+    if isinstance(full.get('cfg3_replicated_stand_in'), dict):
+        others['cfg3_replicated_stand_in_ms_per_step'] = _r(full['cfg3_replicated_stand_in'].get('ms_per_step'), 4)
+    if others:
+        out['others'] = others
+    out['invalid'] = bool(full.get('invalid', False))
+    if full.get('invalid_reason'):
+        out['invalid_reason'] = str(full['invalid_reason'])[:120]
+    out['full_record'] = full.get('full_record')
+    line = json.dumps(out, separators=(',', ':'))
+    if len(line) >= 4096:       # never again a line the driver cannot hold: shed the optional blocks, keep the contract
+        for k in ('others', 'parity', 'full_record'):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(',', ':'))
+            if len(line) < 4096:
+                break
+    return line
+
+
+def write_full(full, path):
+    """The full record as indented JSON at `path` (best effort: a read-only tree only loses the side file), also copied under
+    gpurun_out/ when that scratch directory exists (it is what travels back from a GPU box)."""
+    full['full_record'] = os.path.basename(path) if path else None
+    for pth in ([path] if path else []) + ([os.path.join(ROOT, 'gpurun_out', os.path.basename(path))]
+                                             if path and os.path.isdir(os.path.join(ROOT, 'gpurun_out')) else []):
+        try:
+            with open(pth, 'w') as f:
+                json.dump(full, f, indent=1)
+        except OSError:
+            full['full_record'] = None
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (torch.distributed.run on
     127.0.0.1), before this process has touched a GPU, forward their output and exit with their code."""
@@ -667,6 +820,10 @@ def main():
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
                     help='N > 1: weak = every rank its own num_pixels (default); strong = the workload\'s global batch split '
                          'over the ranks as the dataset does (config 4: 8192 pixels); cfg5 (one frame) is always strong')
+    ap.add_argument('--cycle-batches', type=int, default=4,
+                    help='distinct pixel batches the steps cycle over (hit counts then differ from step to step, as in training)')
+    ap.add_argument('--full-out', default=os.path.join(ROOT, 'bench_full.json'),
+                    help='where the FULL record goes (every definition and nested measurement); stdout ends with the compact line')
     ap.add_argument('--frame-rows', type=int, default=0, help='cfg5: render only a band of R rows of the frame (0: all 800)')
     args = ap.parse_args()
 
@@ -696,7 +853,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps(result), flush=True)
+            write_full(result, args.full_out)
+            print(compact_line(result), flush=True)
         return
     sustained = measure_sustained(lib)          # every rank (its own device); rank 0's goes into the line
     result = run_workload(headline, args, args.steps, args.warmup, rank, world, dev, backend, lib,
@@ -716,6 +874,10 @@ def main():
         # BASELINE's 8-GPU training config as it is defined: the global 8192-pixel batch split over the ranks
         nested['cfg4'] = run_workload('cfg4', args, max(1, min(args.steps, 10)), min(args.warmup, 2), rank, world, dev, backend,
                                       lib, side=False, scaling='strong' if world > 1 else 'weak', sustained=sustained)
+        if world == 1 and headline == 'cfg3' and bench_tier():
+            # the same workload on the library's default arithmetic (no tier), for the like-for-like figure
+            nested['cfg3_untiered'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
+                                                   dev, backend, lib, side=False, sustained=sustained, tier=False)
         if world == 1 and headline == 'cfg3':
             # the same step on the earlier stand-ins of the same scene: the ZERO-PADDED embedding of an 8 x 64 fit (rounds 2-4:
             # 98 % zero weights - what a power-limited part makes of cheap operands) and its REPLICATED embedding (round 4's
@@ -799,9 +961,18 @@ def main():
         cancelled = result['config']['nonfinite_steps'] + sum(
             x['config']['nonfinite_steps'] for k, x in nested.items() if x and k != 'cfg5')
         result['invalid'] = cancelled > 0
+        unt = nested.get('cfg3_untiered')
+        if unt is not None:
+            result['untiered'] = {'ms_per_step': unt['ms_per_step'], 'ms_per_step_repeats': unt['ms_per_step_repeats'],
+                                  'value': unt['value'], 'frac': unt['roofline']['frac'],
+                                  'kernel_ms_per_step': unt['roofline']['kernel_ms_per_step'],
+                                  'nonfinite_steps': unt['config']['nonfinite_steps'],
+                                  'note': 'the same workload with RayTracing.trace_tier off (the library default): every sphere-'
+                                          'tracing value is the split evaluator\'s'}
         if cancelled:
             result['invalid_reason'] = '%d training step(s) produced a non-finite loss or gradient and were cancelled' % cancelled
-        print(json.dumps(result), flush=True)
+        write_full(result, args.full_out)
+        print(compact_line(result), flush=True)
         if cancelled:
             sys.exit(3)
 

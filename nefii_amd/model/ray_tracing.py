@@ -10,7 +10,9 @@ from .. import ops
 
 class RayTracing(nn.Module):
     def __init__(self, object_bounding_sphere=1.0, sdf_threshold=5.0e-5, line_search_step=0.5, line_step_iters=1,
-                 sphere_tracing_iters=10, n_steps=100, n_rootfind_steps=8):
+                 sphere_tracing_iters=10, n_steps=100, n_rootfind_steps=8, trace_tier=None):
+        """trace_tier (not a reference kwarg; conf key model.ray_tracer.trace_tier): the tiered sphere tracing of DESIGN 4f,
+        a PER-MODEL switch - see tier_for."""
         super().__init__()
         self.object_bounding_sphere = object_bounding_sphere
         self.sdf_threshold = sdf_threshold
@@ -70,11 +72,14 @@ class RayTracing(nn.Module):
         # Tiered sphere tracing (nefii_tracer_params.trace_tier; needs the coarse pass): the sphere-tracing evaluations whose
         # front is still far from the surface run on the single-pass evaluator and their value is taken as it is once it is
         # out of the band where it could decide differently.  Changes VALUES (fronts move by v16 instead of v): depths of
-        # converged rays differ by up to ~sdf_threshold / cos, a handful of knife-edge rays change path (DESIGN.md,
-        # "tiered sphere tracing").  None: automatic - on for batches the tier pays for (>= 32768 rays, where evaluations and
-        # not round latency make the trace) unless NEFII_TRACE_TIER=0; True / False (or NEFII_TRACE_TIER=1 / 0) force it.
+        # converged rays differ by up to ~sdf_threshold / cos, a handful of knife-edge rays change path (DESIGN.md 4f and the
+        # error budget of section 2).  A property of the MODEL / the run, never of a call: the constructor kwarg (conf key
+        # model.ray_tracer.trace_tier), overridden by NEFII_TRACE_TIER=1 / 0; default off.  Rounds 4-5 switched it by the
+        # number of rays in the tracer call, which made a ray's result depend on how many other rays were traced with it
+        # (world size, per-rank shard, TrainStep's trace grouping) - withdrawn.
         env = os.environ.get('NEFII_TRACE_TIER')
-        self.trace_tier = None if env is None or env == '' else env != '0'
+        self.trace_tier = (bool(trace_tier) if trace_tier is not None else self.TIER_DEFAULT) if env is None or env == '' \
+            else env != '0'
         self.tier_kappa = float(os.environ.get('NEFII_TIER_KAPPA', '0'))
         self.tier_gate = float(os.environ.get('NEFII_TIER_GATE', '0'))
         # Staged searches (nefii_tracer_params.minsdf_lipschitz; need the coarse pass): a quarter of the min-SDF search's depths,
@@ -86,6 +91,7 @@ class RayTracing(nn.Module):
         # minsdf_lipschitz_override pins L (tests).
         self.minsdf_staged = os.environ.get('NEFII_MINSDF_STAGED', '1') != '0'
         self.minsdf_lipschitz_override = None
+        self.retraced_calls = 0       # synchronous traces repeated because their online audit found a bound violated (forward)
 
     @staticmethod
     def auto_levels(n_rays, concurrent=False):
@@ -111,18 +117,16 @@ class RayTracing(nn.Module):
             return int(env)
         return 4096 if concurrent and n_rays > 1024 else 0
 
-    # The automatic choice (tier_for): on from 32768 rays per tracer call - where evaluations, not round latency, make the
-    # trace (config 3: 226 -> 203 ms per step, config 4: 166 -> 154; config 2's 4096 rays: 2.85 -> 2.74 for up to twice the
-    # rounds of a lone trace) - after the parity protocol of DESIGN.md section 4f: 0 hit-mask flips, depths within 7e-5,
-    # RGB / albedo 5e-5 .. 2.5e-4 of the oracle on the shrunk configs (north-star bound 1e-3).  Results of a batch therefore
-    # depend, at that level, on whether it is big enough to take the tier.
-    TIER_DEFAULT = True
-    TIER_MIN_RAYS = 32768
+    # Off unless the model / the run asks for it (the runner's --trace_tier, conf model.ray_tracer.trace_tier, bench.py,
+    # NEFII_TRACE_TIER=1): the untiered trace is the one whose every decision and value is the split evaluator's.  What the
+    # tier buys where evaluations, not round latency, make the trace: config 3 169 -> 143 ms per step, config 4 126 -> 115,
+    # config 2 2.05 -> 1.92 (round 5) - after the parity protocol of DESIGN.md section 4f.
+    TIER_DEFAULT = False
 
-    def tier_for(self, n_rays):
-        if self.trace_tier is not None:
-            return bool(self.trace_tier)
-        return self.TIER_DEFAULT and n_rays >= self.TIER_MIN_RAYS
+    def tier_for(self, n_rays=None):
+        """Whether traces of this model take the tier.  n_rays is ignored (kept for callers of the rounds-4/5 rule, which
+        switched at 32768 rays per call): a ray's result does not depend on the size of the call it is traced in."""
+        return bool(self.trace_tier)
 
     def bind(self, implicit_network):
         """The kernels evaluate the SDF MLP themselves, so the tracer needs the network, not a closure."""
@@ -133,6 +137,38 @@ class RayTracing(nn.Module):
                     line_search_step=self.line_search_step, line_step_iters=self.line_step_iters,
                     sphere_tracing_iters=self.sphere_tracing_iters, n_steps=self.n_steps,
                     n_rootfind_steps=self.n_rootfind_steps)
+
+    def _bounds(self, net, n_rays, frozen):
+        """(coarse_tau, minsdf_lipschitz, audit callable or None) for a call of n_rays rays with the network's CURRENT bounds."""
+        tau, lip, audit = 0.0, 0.0, None
+        # (batches of up to 1024 rays are latency-bound - a handful of tiles per round: the coarse pass's extra round per
+        # dense search costs them more than its cheaper samples save; config 1: 2.39 vs 2.2 ms per step)
+        # ... and geometry that still trains (model/trainable_geometry.py) changes its weights every step: the bound would
+        # have to be re-measured per forward (two 65 k-point evaluations and a host sync) - no coarse pass there
+        # (the tier needs the coarse pass's bound and evaluator: a model that takes the tier runs the pass whatever the size of
+        # the call, so that its arithmetic does not change with the batch)
+        if self.coarse and self.precision == 'f16x3w' and (n_rays > self.coarse_min_rays or self.tier_for()) and \
+                (frozen or self.coarse_tau_override is not None):
+            tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
+                net.coarse_tau(self.object_bounding_sphere)
+            if tau > 0 and self.minsdf_staged:
+                lip = self.minsdf_lipschitz_override if self.minsdf_lipschitz_override is not None else \
+                    net.minsdf_lipschitz(self.object_bounding_sphere)
+            if tau > 0 and (self.coarse_tau_override is None or (lip > 0 and self.minsdf_lipschitz_override is None)):
+                # every refined sample is evaluated both ways: the tracer reports the largest difference it saw and the
+                # network compares it with the bound it claimed (ImplicitNetwork.note_coarse_audit); likewise for the
+                # slope bound of the staged min-SDF search (note_lipschitz_audit)
+                radius, used, lip_used = self.object_bounding_sphere, tau, lip
+                check_tau, check_lip = self.coarse_tau_override is None, self.minsdf_lipschitz_override is None
+
+                def audit(v, lip_violation=0.0):
+                    if check_tau:
+                        net.note_coarse_audit(v, used, radius)
+                    # (the slope check presumes |coarse - exact| < tau: a trace whose tau audit failed says nothing about L -
+                    # and without the coarse pass there is no staged search to switch off)
+                    if check_lip and not v > used:
+                        net.note_lipschitz_audit(lip_violation, lip_used)
+        return tau, lip, audit
 
     def forward(self, sdf, cam_loc, object_mask, ray_directions):
         """cam_loc [B,3], ray_directions [B,S,3], object_mask [B*S] -> (points [B*S,3], hit [B*S], dists [B*S]).
@@ -184,52 +220,36 @@ class RayTracing(nn.Module):
             group = S if rows > 1 else 0
         n_rays = dirs.shape[0]
         levels = self.bisect_levels or self.auto_levels(n_rays, self.concurrent)
-        tau, audit = 0.0, None
-        # (batches of up to 1024 rays are latency-bound - a handful of tiles per round: the coarse pass's extra round per
-        # dense search costs them more than its cheaper samples save; config 1: 2.39 vs 2.2 ms per step)
-        # ... and geometry that still trains (model/trainable_geometry.py) changes its weights every step: the bound would
-        # have to be re-measured per forward (two 65 k-point evaluations and a host sync) - no coarse pass there
         frozen = not any(p.requires_grad for p in ops.param_list(net))
-        if self.coarse and self.precision == 'f16x3w' and n_rays > self.coarse_min_rays and \
-                (frozen or self.coarse_tau_override is not None):
-            tau = self.coarse_tau_override if self.coarse_tau_override is not None else \
-                net.coarse_tau(self.object_bounding_sphere)
-            lip = 0.0
-            if tau > 0 and self.minsdf_staged:
-                lip = self.minsdf_lipschitz_override if self.minsdf_lipschitz_override is not None else \
-                    net.minsdf_lipschitz(self.object_bounding_sphere)
-            if tau > 0 and (self.coarse_tau_override is None or (lip > 0 and self.minsdf_lipschitz_override is None)):
-                # every refined sample is evaluated both ways: the tracer reports the largest difference it saw and the
-                # network compares it with the bound it claimed (ImplicitNetwork.note_coarse_audit); likewise for the
-                # slope bound of the staged min-SDF search (note_lipschitz_audit)
-                radius, used, lip_used = self.object_bounding_sphere, tau, lip
-                check_tau, check_lip = self.coarse_tau_override is None, self.minsdf_lipschitz_override is None
-
-                def audit(v, lip_violation=0.0):
-                    if check_tau:
-                        net.note_coarse_audit(v, used, radius)
-                    # (the slope check presumes |coarse - exact| < tau: a trace whose tau audit failed says nothing about L -
-                    # and without the coarse pass there is no staged search to switch off)
-                    if check_lip and not v > used:
-                        net.note_lipschitz_audit(lip_violation, lip_used)
-        else:
-            lip = 0.0
-        params = ops.make_tracer_params(self._cfg(), training, self.precision, levels, coarse_tau=tau,
-                                        coarse_cap=self.coarse_cap, minsdf_group=group,
-                                        small_round=self.small_round_for(n_rays, self.concurrent),
-                                        trace_tier=self.tier_for(n_rays), tier_kappa=self.tier_kappa,
-                                        tier_gate=self.tier_gate, minsdf_lipschitz=lip,
-                                        unread_misses=0 if self.miss_search else 1)
         state = None
         if self.adaptive_rounds:      # one guess per (mode, batch size): primary and secondary traces differ
             import math
             state = self._rounds_state.setdefault((training, int(math.log2(n_rays + 1))), ops.TraceRounds())
-        res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs,
-                             object_mask.reshape(-1), self._lin, steps, want_counters=self.collect_counters,
-                             rounds_state=state,
-                             groups=1 if group else (self.stream_groups or 1),
-                             deferred=self.deferred_checks if state is not None else None,
-                             audit=audit)
+        deferred = self.deferred_checks
+        # A trace whose online audit finds its coarse bound tau or its slope bound L violated has made decisions on the strength of
+        # a bound that does not hold (a skipped sample may have been the crossing / the argmin): note_*_audit switches the
+        # pass off for these weights, and THIS trace is repeated without it - same rays, same min-SDF draws - before anything
+        # reads its result.  Synchronous callers (a step's own trace, model(input), eval renders, the secondary trace) get that
+        # here; traces enqueued ahead report through their deferred checks and TrainStep._take_prefetched re-traces them.
+        for attempt in range(3):
+            seen = len(net.coarse_audit_events)
+            tau, lip, audit = self._bounds(net, n_rays, frozen)
+            params = ops.make_tracer_params(self._cfg(), training, self.precision, levels, coarse_tau=tau,
+                                            coarse_cap=self.coarse_cap, minsdf_group=group,
+                                            small_round=self.small_round_for(n_rays, self.concurrent),
+                                            trace_tier=self.tier_for(), tier_kappa=self.tier_kappa,
+                                            tier_gate=self.tier_gate, minsdf_lipschitz=lip,
+                                            unread_misses=0 if self.miss_search else 1)
+            res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs,
+                                 object_mask.reshape(-1), self._lin, steps, want_counters=self.collect_counters,
+                                 rounds_state=state,
+                                 groups=1 if group else (self.stream_groups or 1),
+                                 deferred=deferred,
+                                 audit=audit)
+            if deferred is not None or audit is None or not any(
+                    kind in ('disabled', 'lipschitz_disabled') for kind, _, _ in net.coarse_audit_events[seen:]):
+                break
+            self.retraced_calls += 1
         if self.collect_counters:
             self.last_counters = res[3]
             cur = res[3]

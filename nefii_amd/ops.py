@@ -508,8 +508,9 @@ def calibrate_lipschitz(grad_fn, device, radius=1.0, n=65536, safety=LIPSCHITZ_S
 
 
 def algorithmic_evals(counters, n_steps):
-    """SDF evaluations the reference's recurrences need for the rounds in `counters` [..., rounds, 9] (what the
-    roofline credits): singles + n_steps per dense search entered + bisection steps consumed."""
+    """SDF evaluations the reference's recurrences need for the rounds in `counters` [..., rounds, 13] (_lib.TRACE_COUNTERS
+    columns; what frac_credited credits): singles (0) + tiered singles taken (9 - 10) + n_steps per dense search entered (6)
+    + bisection steps consumed (3)."""
     c = counters.long()
     return c[..., 0] + c[..., 9] - c[..., 10] + c[..., 6] * n_steps + c[..., 3]
 
@@ -642,6 +643,10 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
     hit = torch.empty(n, device=dev, dtype=torch.uint8)
     dist = torch.empty(n, device=dev, dtype=torch.float32)
     rounds = lib.nefii_trace_max_rounds(ctypes.byref(params))
+    # (inside a stream capture nothing may be read back: a capture of the non-adaptive path runs without the audit - its counters
+    # would need a host copy - and the caller audits an eager trace of the same weights instead)
+    if audit is not None and rounds_state is None and torch.cuda.is_current_stream_capturing():
+        audit = None
     need_cnt = want_counters or rounds_state is not None or audit is not None
     groups = max(1, min(int(groups), n // 64)) if n > 0 else 1
     counters = torch.zeros(groups, rounds, _lib.TRACE_COUNTERS, device=dev, dtype=torch.int32) if need_cnt else None
@@ -697,8 +702,15 @@ def trace_rays(pm_sdf, params, origins, dirs, object_mask, lin_steps, minsdf_ste
         if rounds_state is None:
             run(everyone, 0, 0)
             join()
-            if audit is not None:           # (the non-adaptive path has no counter read-back of its own: one host sync)
-                (lambda h: audit(_audit_of(h), _lip_audit_of(h)))(counters.cpu())
+            if audit is not None:
+                # the non-adaptive path has no counter read-back of its own.  A caller that hands in a `deferred` list gets the
+                # audit there (pinned asynchronous copy, run once the work has completed); otherwise one host sync
+                if deferred is not None:
+                    ahead = torch.empty(counters.shape, dtype=counters.dtype, pin_memory=True)
+                    ahead.copy_(counters, non_blocking=True)
+                    deferred.append(lambda: audit(_audit_of(ahead), _lip_audit_of(ahead)))
+                else:
+                    (lambda h: audit(_audit_of(h), _lip_audit_of(h)))(counters.cpu())
         else:
             guess = rounds if rounds_state.guess is None else max(2, min(rounds, rounds_state.guess))
             run(everyone, 0, guess)

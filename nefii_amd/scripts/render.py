@@ -73,6 +73,15 @@ class RenderRunner:
             self.model.envmap_material_network.load_light(kwargs['light_sg_path'])
         self.model.freeze_geometry()
         self.model.eval()
+        # tiered sphere tracing: per run (--trace_tier / trace_tier=...), else what the checkpoint was trained with, else the
+        # model block / NEFII_TRACE_TIER (off by default)
+        tt = kwargs.get('trace_tier')
+        if tt is None:
+            tt = saved.get('trace_tier')
+        rt = getattr(self.model, 'ray_tracer', None)
+        if tt is not None and rt is not None and os.environ.get('NEFII_TRACE_TIER', '') == '':
+            rt.trace_tier = bool(tt)
+        self.trace_tier = bool(rt.tier_for()) if rt is not None and hasattr(rt, 'tier_for') else False
 
     def run(self):                                                                  # render.py:262-442
         ds = self.test_dataset
@@ -116,9 +125,11 @@ def main(argv=None):
     p.add_argument('--local_rank', type=int, default=-1)
     p.add_argument('--model_class', type=str, default='nefii_amd.model.implicit_differentiable_renderer.IDRNetwork')
     p.add_argument('--dataset_class', type=str, default='')
+    p.add_argument('--trace_tier', default=None, action='store_true',
+                   help='tiered sphere tracing for this render (DESIGN.md 4f; default: what the checkpoint records, else off)')
     opt, _ignored = p.parse_known_args(argv)
     local_rank = opt.local_rank if opt.local_rank > -1 else (int(os.environ['LOCAL_RANK']) if 'RANK' in os.environ else -1)
-    RenderRunner(conf=opt.conf, data_split_dir_test=opt.data_split_dir_test or opt.data_split_dir, gamma=opt.gamma,
+    RenderRunner(trace_tier=opt.trace_tier, conf=opt.conf, data_split_dir_test=opt.data_split_dir_test or opt.data_split_dir, gamma=opt.gamma,
                  subsample=opt.subsample, vis_subsample=opt.vis_subsample, expname=opt.expname or 'default',
                  exps_folder_name=opt.exps_folder, old_expdir=opt.old_expdir, timestamp=opt.timestamp,
                  checkpoint=opt.checkpoint, memory_capacity_level=opt.memory_capacity_level,

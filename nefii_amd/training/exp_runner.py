@@ -47,6 +47,9 @@ def main(argv=None):
                         "SyntheticSceneDataset needs no data on disk")
     p.add_argument('--coordinate_type', type=str, default='mitsuba')     # exp_runner.py: axes of the logged envmap image
     p.add_argument('--no_graph', default=False, action='store_true')
+    p.add_argument('--trace_tier', default=None, action='store_true',
+                   help="tiered sphere tracing for every trace of this run (DESIGN.md 4f; default: the conf's train.trace_tier, "
+                        "else off)")
     p.add_argument('--plots', default=False, action='store_true',
                    help="every train.plot_freq iterations render one training view and write its buffers under plots/")
     opt, _ignored = p.parse_known_args(argv)
@@ -64,7 +67,7 @@ def main(argv=None):
         pretrain_geometry_path=opt.pretrain_geometry_path, pretrain_idr_rendering_path=opt.pretrain_idr_rendering_path,
         pretrain_diffuse_path=opt.pretrain_diffuse_path, light_sg_path=opt.light_sg, geometry=opt.geometry, geometry_neus=opt.geometry_neus,
         local_rank=local_rank, model_class=opt.model_class, dataset_class=opt.dataset_class or None,
-        graph=not opt.no_graph, plots=opt.plots, coordinate_type=opt.coordinate_type)
+        graph=not opt.no_graph, plots=opt.plots, coordinate_type=opt.coordinate_type, trace_tier=opt.trace_tier)
     runner.run()
 
 

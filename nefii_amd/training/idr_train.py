@@ -144,6 +144,17 @@ class IDRTrainRunner:
         if self.freeze_diffuse:
             self.model.envmap_material_network.freeze_diffuse()
         self.model.train()
+        # Tiered sphere tracing (model/ray_tracing.py): a property of the RUN - the `trace_tier` keyword
+        # (exp_runner's --trace_tier), else the conf's train.trace_tier, else what the model block / NEFII_TRACE_TIER set (off
+        # by default).  Every trace of the run then uses the same arithmetic whatever its batch size or world size; the choice
+        # is printed with the first log line and saved with the model checkpoint ("trace_tier").
+        tt = kwargs.get('trace_tier')
+        if tt is None and self.conf.get('train.trace_tier', None) is not None:
+            tt = self.conf.get_bool('train.trace_tier')
+        rt = getattr(self.model, 'ray_tracer', None)
+        if tt is not None and rt is not None and os.environ.get('NEFII_TRACE_TIER', '') == '':
+            rt.trace_tier = bool(tt)
+        self.trace_tier = bool(rt.tier_for()) if rt is not None and hasattr(rt, 'tier_for') else False
 
         t = self.conf.get_config('train')
         self.step = TrainStep(
@@ -193,7 +204,7 @@ class IDRTrainRunner:
         bad = [k for k, v in self.model.state_dict().items() if v.dtype.is_floating_point and not torch.isfinite(v).all()]
         if bad:
             raise FloatingPointError('refusing to checkpoint non-finite parameters: %s' % ', '.join(bad[:4]))
-        payload = {'model': {'epoch': epoch, 'model_state_dict': self.model.state_dict()},
+        payload = {'model': {'epoch': epoch, 'model_state_dict': self.model.state_dict(), 'trace_tier': self.trace_tier},
                    'idr_opt': {'epoch': epoch, 'optimizer_state_dict': st.portable_state_dict(st.idr_optimizer)},
                    'idr_sched': {'epoch': epoch, 'scheduler_state_dict': st.idr_scheduler.state_dict()},
                    'sg_opt': {'epoch': epoch, 'optimizer_state_dict': st.portable_state_dict(st.sg_optimizer)},
@@ -294,7 +305,7 @@ class IDRTrainRunner:
                     rec = {'iter': it, 'epoch': epoch, 'loss': loss, 'sg_rgb_loss': lo['sg_rgb_loss'].item(),
                            'sg_psnr': float(mse2psnr(lo['sg_rgb_loss'].item())),
                            'idr_lr': float(self.step.idr_optimizer.param_groups[0]['lr']),
-                           'sg_lr': float(self.step.sg_optimizer.param_groups[0]['lr'])}
+                           'sg_lr': float(self.step.sg_optimizer.param_groups[0]['lr']), 'trace_tier': self.trace_tier}
                     # what the online audit of the tracer's coarse bound did since the last line (TrainStep.coarse_events: a
                     # bound raised, or the coarse pass switched off and the step's batch traced again) goes into the record
                     if len(self.step.coarse_events) > self._coarse_events_logged:

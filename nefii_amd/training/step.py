@@ -650,6 +650,7 @@ class TrainStep:
         tail, see prefetch_trace."""
         self._pre_iteration()
         ctx = None
+        self._audit_seen = len(getattr(getattr(self.model, 'implicit_network', None), 'coarse_audit_events', ()))
         if next_input is not None:
             m = self.model
             upcoming = list(next_input) if isinstance(next_input, (list, tuple)) else [next_input]
@@ -690,6 +691,7 @@ class TrainStep:
             if res is not None:
                 if self.secondary_train_interval > 0 and self.cur_iter % self.secondary_train_interval == 0:
                     self.train_with_secondary(res[0])
+                self._note_sync_audit()
                 self._post_iteration()
                 return res
         self._eager_steps += 1
@@ -705,8 +707,27 @@ class TrainStep:
         self._update(lo['loss'])
         if self.secondary_train_interval > 0 and self.cur_iter % self.secondary_train_interval == 0:
             self.train_with_secondary(out)
+        self._note_sync_audit()
         self._post_iteration()
         return _detached(out), _detached(lo)
+
+    def _note_sync_audit(self):
+        """Audit events raised by this step's SYNCHRONOUS traces (its own primary trace when nothing was enqueued ahead, the
+        secondary trace inside the tail): RayTracing.forward has already repeated those traces without the failed bound; what
+        is left to do here is to record the event for the runner's log and to drop the traces enqueued AHEAD under the bound
+        that no longer holds (they are traced again when their batch comes up)."""
+        net = getattr(self.model, 'implicit_network', None)
+        if net is None or not hasattr(net, 'coarse_audit_events'):
+            return
+        fresh = net.coarse_audit_events[self._audit_seen:]
+        self._audit_seen = len(net.coarse_audit_events)
+        known = {(k, o, b) for _, k, o, b in self.coarse_events[-len(fresh) - 8:]} if fresh else set()
+        for kind, observed, bound in fresh:
+            if (kind, observed, bound) not in known:
+                self.coarse_events.append((self.cur_iter, kind, observed, bound))
+        if any(kind in ('disabled', 'lipschitz_disabled') for kind, _, _ in fresh) and self._prefetch:
+            self._prefetch = []
+            self.retraced_steps += 1
 
     def train_with_secondary(self, model_outputs):
         """L1(sg_rgb, idr_rgb) at secondary hit points, seen from the direction they were hit from

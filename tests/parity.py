@@ -10,10 +10,11 @@ import os
 
 import torch
 
-# NEFII_PARITY_SOFT=1 (tools/tier_round.sh: the parity protocol of an arithmetic that is NOT expected to meet every bound):
-# a tolerance that does not hold is printed ("EXCEEDS") instead of raised, so that one run lists every figure; the printed
-# line of figures below is always there
-SOFT = os.environ.get('NEFII_PARITY_SOFT', '0') == '1'
+# Soft mode (the parity PROTOCOL of an arithmetic that is not expected to meet every bound, tools/tier_round.sh): a tolerance that
+# does not hold is printed ("EXCEEDS") instead of raised, so that one run lists every figure.  It is switched on by the explicit
+# pytest option `--parity-soft` only (tests/conftest.py sets this flag and prints a banner); no environment variable reaches it -
+# a leaked NEFII_PARITY_SOFT fails the session at collection instead of making the suite pass vacuously.
+SOFT = False
 
 
 def _check(ok, info):

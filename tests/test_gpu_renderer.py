@@ -541,6 +541,29 @@ model { %s }
     assert os.path.exists(os.path.join(str(tmp_path), 'cli', runs[0], 'runconf.conf'))
 
 
+def _bench_records(stdout, full_path):
+    """bench.py's output: the LAST stdout line is the compact record the driver parses (< 4 KB, flat, carrying the headline's
+    own numbers), the full record - returned - is the file named by --full-out."""
+    import json
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert lines[-1].startswith('{') and len(lines[-1]) < 4096, len(lines[-1])
+    compact = json.loads(lines[-1])
+    full = json.load(open(full_path))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'scaling', 'dtype', 'invalid'):
+        assert k in compact, k
+        if isinstance(full[k], float):
+            assert compact[k] == pytest.approx(full[k], rel=1e-4), k
+        else:
+            assert compact[k] == full[k], k
+    assert compact['config']['workload'] == full['config']['workload'].split(':')[0]
+    if 'roofline' in full:
+        # frac is what the kernels executed - never more than what the reference's recurrences would have executed
+        assert compact['roofline']['frac'] == pytest.approx(full['roofline']['frac_executed'], rel=1e-3)
+        assert compact['roofline']['frac'] <= compact['roofline']['frac_credited'] * 1.001
+        assert compact['config']['trace_tier'] == full['config']['trace_tier']
+    return full
+
+
 def test_bench_two_processes_share_one_gpu():
     """bench.py's multi-process path end to end, started the way the driver starts the one-GPU bench - `python bench.py --gpus
     2`, NO launcher: the script spawns its own two ranks (torch.distributed.run as a child process, before it touches a GPU).
@@ -552,16 +575,17 @@ def test_bench_two_processes_share_one_gpu():
     import os
     import subprocess
     import sys
+    import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NEFII_BENCH_BACKEND='gloo')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
         env.pop(k, None)
+    full_path = os.path.join(tempfile.mkdtemp(), 'bench_full.json')
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '4', '--repeats', '1',
-           '--no-cpu-baseline', '--frame-rows', '4']
+           '--no-cpu-baseline', '--frame-rows', '4', '--full-out', full_path]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
-    d = json.loads(line)
+    d = _bench_records(r.stdout, full_path)
     assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'dp2' and d['value'] > 0 and d['scaling'] == 'weak'
     assert d['config']['workload'].startswith('cfg3') and d['config']['primary_rays_per_step_per_gpu'] == 4096 * 64
     assert d['config']['rank_param_spread'] < 1e-9       # both ranks hold the same parameters after 8+ synchronised steps
@@ -586,15 +610,17 @@ def test_bench_eight_processes_share_one_gpu():
     import os
     import subprocess
     import sys
+    import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NEFII_BENCH_BACKEND='gloo', NEFII_BENCH_PIXELS='200')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE'):
         env.pop(k, None)
+    full_path = os.path.join(tempfile.mkdtemp(), 'bench_full.json')
     cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '4', '--repeats', '1',
-           '--no-cpu-baseline', '--frame-rows', '1']
+           '--no-cpu-baseline', '--frame-rows', '1', '--full-out', full_path]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    d = _bench_records(r.stdout, full_path)
     assert d['n_gpus'] == 8 and d['config']['parallelism'] == 'dp8' and d['value'] > 0 and d['scaling'] == 'weak'
     assert d['config']['num_pixels_override'] == 200 and d['config']['primary_rays_per_step_per_gpu'] == 200 * 64
     assert d['config']['trace_prefetch'] == 3            # three traces in flight beside every step's all-reduce
@@ -614,8 +640,11 @@ def _run_bench(args, nproc, port, timeout=600):
     import os
     import subprocess
     import sys
+    import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NEFII_BENCH_BACKEND='gloo')
+    full_path = os.path.join(tempfile.mkdtemp(), 'bench_full.json')
+    args = list(args) + ['--full-out', full_path]
     if nproc > 1:
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr',
                '127.0.0.1', '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', str(nproc)] + args
@@ -623,7 +652,7 @@ def _run_bench(args, nproc, port, timeout=600):
         cmd = [sys.executable, os.path.join(root, 'bench.py')] + args
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    return json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    return _bench_records(r.stdout, full_path)
 
 
 def test_bench_strong_scaling_modes():

@@ -19,6 +19,7 @@ m = IDRNetwork(conf.from_dict(mc))
 m.load_state_dict(sd)
 m = m.to(dev)
 m.freeze_geometry()
+m.ray_tracer.trace_tier = os.environ.get('NEFII_TRACE_TIER', '1') != '0'      # the per-run switch, as bench.py sets it
 m.train(True)
 rays = []
 for g in range(G):

@@ -32,6 +32,7 @@ def main():
     m.load_state_dict(syn.make_state_dict(mc, seed=0, scene=w.get('scene')), strict=True)
     m = m.to(dev)
     m.freeze_geometry()
+    m.ray_tracer.trace_tier = os.environ.get('NEFII_TRACE_TIER', '1') != '0'      # the per-run switch, as bench.py sets it
     m.train()
     batches = []
     for b in range(nb):

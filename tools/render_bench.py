@@ -21,6 +21,7 @@ m = IDRNetwork(conf.from_dict(mc))
 m.load_state_dict(sd)
 m = m.cuda().eval()
 m.freeze_geometry()
+m.ray_tracer.trace_tier = os.environ.get('NEFII_TRACE_TIER', '1') != '0'      # the per-run switch, as bench.py sets it
 inp, _ = syn.make_inputs(pixels, (800, 800), 1111.0, (0., 0., 2.4), num_rays, seed=3)
 inp = {k: v.cuda() for k, v in inp.items()}
 S = inp['uv'].shape[1]

@@ -35,6 +35,7 @@ def main():
     m.load_state_dict(sd, strict=True)
     m = m.to(dev).eval()
     m.freeze_geometry()
+    m.ray_tracer.trace_tier = os.environ.get('NEFII_TRACE_TIER', '1') != '0'      # as bench.py renders the frame
     H, W = w['image_hw']
     full = syn.frame_inputs(w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'])
     inp = {k: v.to(dev) for k, v in full.items()}
@@ -85,14 +86,11 @@ def main():
         with torch.no_grad():
             ref = Ro.forward(flat, None, uniforms, None)
         res['oracle_seconds'] = time.perf_counter() - t2
-        # the frame's chunks (2^level rays per tracer call) take the tracer's tier; the sample below (n_check x R rays) would
-        # not on its own: it is traced with the same arithmetic as the frame it is compared with
-        tier = bool(m.ray_tracer.tier_for(1 << w['memory_capacity_level']))
-        m.ray_tracer.trace_tier = tier
+        # the tier is a per-model switch (set where the model is built, above): frame and sample share one arithmetic
+        tier = bool(m.ray_tracer.tier_for())
         res['trace_tier'] = tier
         with torch.no_grad():
             out = gpu_forward_with_per_ray_draws(m, {k: v.to(dev) for k, v in flat.items()}, uniforms)
-        m.ray_tracer.trace_tier = None
         stats = compare_outputs(out, ref, max_flips=max(4, n_ray // 2000), what='cfg5 frame sample', rays_per_pixel=1,
                                 ray_hit=m.last_ray_hit, ref_ray_hit=ref['_ray_hit'], max_explained_frac=0.02,
                                 sdf_outliers=max(1, n_ray // 8000) + (n_ray // 2000 if tier else 0), tol_aux=4e-3 if tier else None,

@@ -8,9 +8,9 @@ export TMPDIR=/tmp
 T=${1:-r05}; O=gpurun_out/$T
 mkdir -p $O
 python3 tools/tier_parity.py 32768 2>&1 | grep -v "Warning\|WeightNorm\|amdgpu\|warn" > $O/tier_parity_tracer.txt
-# (NEFII_PARITY_SOFT=1: tests/parity.py prints a bound that does not hold instead of raising - the run lists every figure)
+# (--parity-soft: tests/parity.py prints a bound that does not hold instead of raising - the run lists every figure)
 for tier in 0 1; do
-    NEFII_PARITY_SOFT=1 NEFII_TRACE_TIER=$tier timeout 1500 python3 -m pytest tests/test_gpu_configs.py tests/test_gpu_longrun.py \
+    NEFII_TRACE_TIER=$tier timeout 1500 python3 -m pytest --parity-soft tests/test_gpu_configs.py tests/test_gpu_longrun.py \
         tests/test_gpu_renderer.py -m gpu -q -s -k "config or longrun or long or golden or full_size or indirect" \
         2>&1 | grep -v "Warning\|WeightNorm\|amdgpu\|warnings.warn" > $O/tier_parity_suite_tier$tier.txt
 done

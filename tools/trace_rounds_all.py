@@ -15,6 +15,7 @@ m = IDRNetwork(conf.from_dict(mc))
 m.load_state_dict(syn.make_state_dict(mc, seed=0, scene=w.get('scene')))
 m = m.to('cuda:0')
 m.freeze_geometry()
+m.ray_tracer.trace_tier = os.environ.get('NEFII_TRACE_TIER', '1') != '0'      # the per-run switch, as bench.py sets it
 m.train()
 inp, gt = syn.make_inputs(w['num_pixels'], w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
 inp = {k: v.to('cuda:0') for k, v in inp.items()}
