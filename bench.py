@@ -132,65 +132,88 @@ def cpu_baseline(workload, sample_rays, steps=5, warmup=2, device=None, parity_p
                      % (sample_pixels, n_rays, steps, warmup, threads)}
     parity = None
     if device is not None:
-        from nefii_amd import conf
-        from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
         torch.set_num_threads(threads)
         pp = max(sample_pixels, parity_pixels) // 4 * 4
-        inp, _ = syn.make_inputs(pp, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
-        torch.manual_seed(0)        # the oracle draws the sampler's uniforms and the min-SDF steps here: the same sample every run
-        with torch.no_grad():
-            out = orr.Renderer(syn.make_state_dict(mc, seed=0, scene=w.get('scene')), mc, training=True).forward(inp)
-        ref = {k: out[k].detach().clone() for k in ('sg_rgb_values', 'sg_diffuse_albedo_values', 'network_object_mask')}
-        ref['ray_hit'], ref['secondary_dir'], ref['secondary_mask'] = out.get('_ray_hit'), out.get('secondary_dir'), out.get('secondary_mask')
-        ref['uniforms'], ref['steps'], ref['steps2'] = out.get('_uniforms'), out.get('_minsdf_steps'), out.get('_minsdf_steps2')
-        m = IDRNetwork(conf.from_dict(mc))
-        m.load_state_dict(syn.make_state_dict(mc, seed=0, scene=w.get('scene')), strict=True)
-        m = m.to(device)
-        m.freeze_geometry()
-        m.train()
-        over = [x for x in (ref['steps'], ref['steps2']) if x is not None]
-        if over:
-            m.ray_tracer.minsdf_steps_override = over
-        if ref['uniforms'] is not None:
-            m.uniforms_override = ref['uniforms']
-        m.ray_tracer.trace_tier = bench_tier()      # the arithmetic the timed steps run (a per-run switch)
-        with torch.no_grad():
-            out = m({k: v.to(device) for k, v in inp.items()})
-        mask = ref['network_object_mask'] & out['network_object_mask'].cpu()
-        parity = {'pixels': int(mask.numel()), 'hit_pixels': int(mask.sum()),
-                  'hit_mask_mismatches': int((ref['network_object_mask'] != out['network_object_mask'].cpu()).sum())}
-        for k, name in (('sg_rgb_values', 'rgb'), ('sg_diffuse_albedo_values', 'albedo')):
-            a, b = out[k].cpu()[mask], ref[k][mask]
-            mse = ((a - b) ** 2).mean().item()
-            parity[name + '_rel_l2'] = ((a - b).norm() / (b.norm() + 1e-12)).item()
-            parity[name + '_psnr_db'] = float('inf') if mse == 0 else 20.0 * math.log10(1.0 / mse ** 0.5)
-        # Monte-Carlo workloads: a primary ray whose sampled direction differs (the SG-mixture sampler picks its lobe by a CDF
-        # comparison: a uniform within rounding of a boundary picks the neighbour) or one of whose secondary rays hits on one
-        # side only is ANOTHER sample of the integrand, not an error of it: counted, and the colour also given without the
-        # pixels that hold such a ray (what the GPU suite asserts the north-star bound on: tests/parity.py)
-        if ref.get('secondary_dir') is not None and out.get('secondary_dir') is not None and ref.get('ray_hit') is not None:
-            hit, rhit = m.last_ray_hit.cpu().bool(), ref['ray_hit'].bool()
-
-            def spread(x, h):
-                full = torch.zeros(3, h.shape[0], x.shape[-1])
-                full[:, h] = x.detach().cpu().float()
-                return full
-            both = hit & rhit
-            dflag = ((spread(out['secondary_dir'], hit) - spread(ref['secondary_dir'], rhit)).abs().amax(-1) > 1e-3).any(0) & both
-            mflag = (spread(out['secondary_mask'].float(), hit)[..., 0] != spread(ref['secondary_mask'].float(), rhit)[..., 0]).any(0) & both & ~dflag
-            flagged_px = (dflag | mflag).reshape(-1, R_).any(1)
-            parity['rays_with_another_sampled_direction'] = int(dflag.sum())
-            parity['rays_with_another_secondary_hit_flag'] = int(mflag.sum())
-            parity['pixels_holding_such_a_ray'] = int((flagged_px & mask).sum())
-            keep = mask & ~flagged_px
-            if keep.any():
-                a, b = out['sg_rgb_values'].cpu()[keep], ref['sg_rgb_values'][keep]
-                parity['rgb_rel_l2_same_samples'] = ((a - b).norm() / (b.norm() + 1e-12)).item()
-        parity['tolerance_rel_l2'] = 1e-3
-        parity['sample'] = 'the first %d pixels of the workload (%d primary rays), forward only, the oracle\'s draws replayed' % (
-            pp, pp * R_)
-        parity['trace_tier'] = bool(m.ray_tracer.trace_tier)
+        parity = parity_of(workload, oracle_reference(workload, pp), device, bench_tier())
     return res, parity
+
+
+def oracle_reference(workload, pp):
+    """The oracle's forward (training mode, seeded draws) on the first pp pixels of the workload's batch: what parity_of compares with."""
+    from nefii_amd import synthetic as syn
+    from oracle import renderer as orr
+    w = dict(syn.WORKLOADS[workload])
+    mc = syn.model_conf(w['model'])
+    inp, _ = syn.make_inputs(pp, w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
+    torch.manual_seed(0)        # the oracle draws the sampler's uniforms and the min-SDF steps here: the same sample every run
+    with torch.no_grad():
+        out = orr.Renderer(syn.make_state_dict(mc, seed=0, scene=w.get('scene')), mc, training=not w.get('eval')).forward(inp)
+    ref = {k: out[k].detach().clone() for k in ('sg_rgb_values', 'sg_diffuse_albedo_values', 'network_object_mask')}
+    ref['ray_hit'], ref['secondary_dir'], ref['secondary_mask'] = out.get('_ray_hit'), out.get('secondary_dir'), out.get('secondary_mask')
+    ref['uniforms'], ref['steps'], ref['steps2'] = out.get('_uniforms'), out.get('_minsdf_steps'), out.get('_minsdf_steps2')
+    ref['inp'], ref['pp'] = inp, pp
+    return ref
+
+
+def parity_of(workload, ref, device, tier, tweak=None):
+    """Relative L2 / PSNR of the HIP path's rendered RGB and albedo against `ref` (oracle_reference) on identical rays, weights and
+    draws, forward only.  tier: RayTracing.trace_tier for this run; tweak(model): further switches (tools/error_budget.py)."""
+    from nefii_amd import conf, synthetic as syn
+    from nefii_amd.model.implicit_differentiable_renderer import IDRNetwork
+    w = dict(syn.WORKLOADS[workload])
+    mc = syn.model_conf(w['model'])
+    R_ = w['num_rays'] if w['num_rays'] > 0 else 1
+    inp, pp = ref['inp'], ref['pp']
+    m = IDRNetwork(conf.from_dict(mc))
+    m.load_state_dict(syn.make_state_dict(mc, seed=0, scene=w.get('scene')), strict=True)
+    m = m.to(device)
+    m.freeze_geometry()
+    m.train(not w.get('eval'))
+    over = [x for x in (ref['steps'], ref['steps2']) if x is not None]
+    if over:
+        m.ray_tracer.minsdf_steps_override = over
+    if ref['uniforms'] is not None:
+        m.uniforms_override = ref['uniforms']
+    m.ray_tracer.trace_tier = bool(tier)      # the arithmetic the timed steps run (a per-run switch)
+    if tweak is not None:
+        tweak(m)
+    with torch.no_grad():
+        out = m({k: v.to(device) for k, v in inp.items()})
+    mask = ref['network_object_mask'] & out['network_object_mask'].cpu()
+    parity = {'pixels': int(mask.numel()), 'hit_pixels': int(mask.sum()),
+              'hit_mask_mismatches': int((ref['network_object_mask'] != out['network_object_mask'].cpu()).sum())}
+    for k, name in (('sg_rgb_values', 'rgb'), ('sg_diffuse_albedo_values', 'albedo')):
+        a, b = out[k].cpu()[mask], ref[k][mask]
+        mse = ((a - b) ** 2).mean().item()
+        parity[name + '_rel_l2'] = ((a - b).norm() / (b.norm() + 1e-12)).item()
+        parity[name + '_psnr_db'] = float('inf') if mse == 0 else 20.0 * math.log10(1.0 / mse ** 0.5)
+    # Monte-Carlo workloads: a primary ray whose sampled direction differs (the SG-mixture sampler picks its lobe by a CDF
+    # comparison: a uniform within rounding of a boundary picks the neighbour) or one of whose secondary rays hits on one
+    # side only is ANOTHER sample of the integrand, not an error of it: counted, and the colour also given without the
+    # pixels that hold such a ray (what the GPU suite asserts the north-star bound on: tests/parity.py)
+    if ref.get('secondary_dir') is not None and out.get('secondary_dir') is not None and ref.get('ray_hit') is not None:
+        hit, rhit = m.last_ray_hit.cpu().bool(), ref['ray_hit'].bool()
+
+        def spread(x, h):
+            full = torch.zeros(3, h.shape[0], x.shape[-1])
+            full[:, h] = x.detach().cpu().float()
+            return full
+        both = hit & rhit
+        dflag = ((spread(out['secondary_dir'], hit) - spread(ref['secondary_dir'], rhit)).abs().amax(-1) > 1e-3).any(0) & both
+        mflag = (spread(out['secondary_mask'].float(), hit)[..., 0] != spread(ref['secondary_mask'].float(), rhit)[..., 0]).any(0) & both & ~dflag
+        flagged_px = (dflag | mflag).reshape(-1, R_).any(1)
+        parity['rays_with_another_sampled_direction'] = int(dflag.sum())
+        parity['rays_with_another_secondary_hit_flag'] = int(mflag.sum())
+        parity['pixels_holding_such_a_ray'] = int((flagged_px & mask).sum())
+        keep = mask & ~flagged_px
+        if keep.any():
+            a, b = out['sg_rgb_values'].cpu()[keep], ref['sg_rgb_values'][keep]
+            parity['rgb_rel_l2_same_samples'] = ((a - b).norm() / (b.norm() + 1e-12)).item()
+    parity['tolerance_rel_l2'] = 1e-3
+    parity['sample'] = 'the first %d pixels of the workload (%d primary rays), forward only, the oracle\'s draws replayed' % (
+        pp, pp * R_)
+    parity['trace_tier'] = bool(m.ray_tracer.trace_tier)
+    return parity
 
 
 def bench_tier():
@@ -470,6 +493,11 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                 'minsdf_lipschitz': float(model.implicit_network.minsdf_lipschitz(model.ray_tracer.object_bounding_sphere))
                 if (model.ray_tracer.minsdf_staged and coarse_tau > 0) else 0.0,
                 'minsdf_second_stage_depths': int(cnt[:, 11].sum().item()), 'dense_searches_entered': int(cnt[:, 6].sum().item()),
+                # the slope bound's online audit: every second-stage sample is held against the bound it was given; among them the
+                # PROBES - samples the search had skipped, evaluated after all (one per search by hash + those whose bound cleared
+                # the limit by < 2 tau; counter 13, ABI 15)
+                'lipschitz_audited_samples': int(cnt[:, 11].sum().item()),
+                'lipschitz_probe_samples': int(cnt[:, 13].sum().item()) if cnt.shape[1] > 13 else None,
                 'minsdf_lipschitz_violation': float(cnt[:, 12].contiguous().int().view(torch.float32).max().item()) if cnt.numel() else 0.0,
                 # the online audit of that bound (every refined sample is evaluated both ways): the largest |single pass -
                 # split| the tracer saw in this run, and what ImplicitNetwork.note_coarse_audit did about it (nothing, if empty)
@@ -731,6 +759,7 @@ def compact_line(full):
              'minsdf_lipschitz': _r(rf.get('minsdf_lipschitz')),
              'minsdf_lipschitz_violation': _r(rf.get('minsdf_lipschitz_violation')),
              'lipschitz_audited_samples': rf.get('lipschitz_audited_samples'),
+             'lipschitz_probe_samples': rf.get('lipschitz_probe_samples'),
              'audit_events': len(rf.get('coarse_audit_events') or []),
              'hit_fraction': _r(rf.get('hit_fraction')), 'secondary_hit_fraction': _r(rf.get('secondary_hit_fraction'))}
         bp = rf.get('board_power')

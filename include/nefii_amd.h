@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define NEFII_ABI_VERSION 14
+#define NEFII_ABI_VERSION 15
 #define NEFII_MAX_LAYERS 12
 #define NEFII_TILE_ROWS 32          /* points per workgroup tile */
 #define NEFII_MAX_WIDTH 512         /* widest hidden layer / feature vector */
@@ -274,7 +274,7 @@ typedef struct nefii_tracer_params {
                                 depths are those of unread_misses == 0 bit for bit.  What the Monte-Carlo renderer's secondary
                                 rays need (path_tracing_render.py: visibility and the radiance at secondary HITS). */
 } nefii_tracer_params;
-#define NEFII_TRACE_COUNTERS 13  /* int32 counters per round, see nefii_trace_rays */
+#define NEFII_TRACE_COUNTERS 14  /* int32 counters per round, see nefii_trace_rays */
 
 /* The pipelined evaluator behind nefii_trace_rays (precision 2) and nefii_sdf_eval reads the hidden layers' fragments as
  * ONE stream per wave, 4 KiB per 16-deep unit of the layer sequence: [8 waves][units][4 fragments][64 lanes][8 halves];
@@ -333,7 +333,9 @@ int nefii_trace_max_rounds(const nefii_tracer_params *h_params);
  * repeat such a query in split precision (they take part in the audit of [r][8]);
  * [r][11] (ABI 13, minsdf_lipschitz) depths of staged min-SDF searches evaluated one by one in the single-pass evaluator (the
  * first stage's depths are a quarter row of [r][5]); [r][12] (the bits of a float >= 0) the largest amount by which such a
- * depth's value fell below the lower bound that minsdf_lipschitz gave it: above 0 the bound does not hold for this net.
+ * depth's value fell below the lower bound that minsdf_lipschitz gave it: above 0 the bound does not hold for this net;
+ * [r][13] (ABI 15) samples the staged searches had SKIPPED and evaluated after all as probes of that audit: one per search picked
+ * by a hash of (ray, position), plus up to 6 whose bound cleared the limit by less than 2 coarse_tau (they are among [r][11]).
  * Algorithmic evaluations (what the reference's recurrences need) = [0] + [9] - [10] + n_steps*[6] + [3]; executed in split
  * precision = [0] + n_steps*[1] + [7] + [4]; executed in the coarse evaluator = ceil(n_steps / 4)*[5] + [9] + [11]. */
 int nefii_trace_rays(const nefii_mlp *h_sdf, const nefii_tracer_params *h_params,

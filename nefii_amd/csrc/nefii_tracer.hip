@@ -36,6 +36,7 @@ enum Phase : int { PH_DONE = 0, PH_TRACE = 1, PH_SAMPLER = 2, PH_BISECT = 3, PH_
                    PH_SAMPLER_X = 7 };
 constexpr int PH_POST = 100;      // local to advance_kernel: the stage behind tracing / sampler / bisection
 constexpr int NCNT = NEFII_TRACE_COUNTERS;
+constexpr int NEAR_PROBES = 6;     // skipped samples per staged search that the audit evaluates because their bound cleared the limit by < 2 tau
 enum Kind : int { Q_START = 0, Q_END = 1, Q_MID = 2 };
 
 struct RayState {            // SoA views into the workspace
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         const bool sign_only = front_only || !P.miss_argmin;
         const float lim = sign_only ? 0.f : fmaxf(0.f, fadd(best, P.tau));
         const int last = front_only ? j1 : ns - 1;
-        int ja = 0, k = 0;
+        int ja = 0, k = 0, n_near = 0;
         float worst = 0.f;
         int probe = -1;
         unsigned probe_h = ~0u;
@@ -545,6 +546,12 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                 if (!(fsub(lb, 1e-6f) > lim)) {
                     cmask[kk >> 5] |= 1u << (kk & 31);
                     ++k;
+                } else if (n_near < NEAR_PROBES && !(fsub(lb, 1e-6f) > fadd(lim, fmul(2.f, P.tau)))) {
+                    // skipped, but its bound clears the limit by less than 2 tau: the skipped samples closest to mattering are
+                    // evaluated after all - as PROBES of the audit (stage 6 holds every evaluated sample against its bound); a
+                    // probe's value decides nothing the bound had not decided (ABI 15, counter 13)
+                    cmask[kk >> 5] |= 1u << (kk & 31);
+                    ++k, ++n_near;
                 } else {
                     const unsigned h = ((unsigned)r * 2654435761u) ^ ((unsigned)(kk + 1) * 0x9E3779B1u);
                     const unsigned hh = (h ^ (h >> 15)) * 0x85EBCA6Bu;
@@ -557,8 +564,9 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         fl &= ~(F_WIN_MASK << F_WIN_SHIFT);
         if (stage == 5 && probe >= 0) {
             cmask[probe >> 5] |= 1u << (probe & 31);
-            ++k;
+            ++k, ++n_near;
         }
+        if (stage == 5 && n_near > 0) atomicAdd(P.counters + round * NCNT + 13, n_near);
         if (stage == 5 && k > 0) {
             if (k <= CREF_CAP) {
                 n_ref = k;
@@ -799,7 +807,7 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         float best = __builtin_inff();
         for (int j = 0; j < n1; ++j) best = fminf(best, v[ord[stage1_pos(ns, j)]]);
         const float lim = fadd(best, P.tau);
-        int ja = 0, k = 0;
+        int ja = 0, k = 0, n_near = 0;
         float worst = 0.f;
         int probe = -1;             // one of the SKIPPED depths, picked by a hash of (ray, position): evaluated after all, so that
         unsigned probe_h = ~0u;     // the audit also sees the bound where it was relied upon (a ray costs one evaluation more)
@@ -815,6 +823,9 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
                 if (!(fsub(lb, 1e-6f) > lim)) {
                     cmask[is >> 5] |= 1u << (is & 31);
                     ++k;
+                } else if (n_near < NEAR_PROBES && !(fsub(lb, 1e-6f) > fadd(lim, fmul(2.f, P.tau)))) {
+                    cmask[is >> 5] |= 1u << (is & 31);      // a probe of the audit: skipped by less than 2 tau (see the bracket search)
+                    ++k, ++n_near;
                 } else {
                     const unsigned h = ((unsigned)r * 2654435761u) ^ ((unsigned)(kk + 1) * 0x9E3779B1u);
                     const unsigned hh = (h ^ (h >> 15)) * 0x85EBCA6Bu;
@@ -827,8 +838,9 @@ __global__ __launch_bounds__(256) void advance_kernel(Params P, int round) {
         fl &= ~(F_WIN_MASK << F_WIN_SHIFT);
         if (stage == 2 && probe >= 0) {
             cmask[probe >> 5] |= 1u << (probe & 31);
-            ++k;
+            ++k, ++n_near;
         }
+        if (stage == 2 && n_near > 0) atomicAdd(P.counters + round * NCNT + 13, n_near);
         if (stage == 2 && k > 0) {
             if (k <= CREF_CAP) {
                 n_ref = k;

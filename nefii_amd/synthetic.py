@@ -288,6 +288,73 @@ def make_state_dict(model, seed=0, radius=None, bumpy=0.0, scene=None):
     return sd
 
 
+def add_sdf_dent(model, sd, center, width=0.01, depth=0.02, sharp=40.0, value_scale=1.0, row0=None):
+    """ADVERSARIAL geometry for the tracer's slope bound (tests only): a small, steep, non-eikonal dent added to an SDF network
+    whose wide layers have SPARE hidden units (the zero-padded 'bowl' embedding of the 8 x 64 stand-in: rows 64.. of every layer
+    are dead) - in place, the same state-dict keys.
+
+        sdf'(x) = value_scale * sdf(x)  -  depth * max(0, hat(x0) + hat(x1) + hat(x2) - 2),      hat(u) = max(0, 1 - |u - c| / width)
+
+    i.e. a pocket on the octahedron sum_i |x_i - c_i| < width (volume 4/3 width^3: 1.3e-6 for width 0.01 - a random sample of the
+    bounding sphere does not find it), `depth` deep at its centre, slope depth / width per axis (|grad| up to sqrt(3) depth /
+    width = 3.5 for the defaults) - built from Softplus(beta 100) units: layer 0 holds nine ramps sp(sharp (x_i - c_i - {-w, 0,
+    w})) (knee 0.01 / sharp), layer 1 one unit sp(kappa (sum of hats - 2)), layers 2.. carry it (a unit with a +1 offset is in
+    Softplus's exactly linear range), the last layer subtracts it.  value_scale < 1 turns the base into an UNDER-estimated
+    distance (|grad| = value_scale): sphere tracing then does not converge in its ten iterations and the rays go to the bracket
+    search - the path the staged search of eval-mode traces takes.  Returns sd."""
+    ic = model['implicit_network']
+    shapes = sdf_layer_dims(ic, int(model['feature_vector_size']))
+    nl = len(shapes)
+    skip = tuple(ic.get('skip_in', ()))
+    d0 = shapes[0][1]
+    key = 'implicit_network.lin%d.%s'
+    # spare rows: weight_g == 0 (embed_scene_sdf's padding)
+    spare = [torch.nonzero(sd[key % (l, 'weight_g')].reshape(-1) == 0).flatten().tolist() for l in range(nl - 1)]
+    assert len(spare[0]) >= 9 and all(len(sp) >= 1 for sp in spare[1:]), 'add_sdf_dent needs spare hidden units (scene "bowl")'
+    c = [float(v) for v in center]
+    w = float(width)
+    kappa = 1.0             # the layer-1 unit's peak value (exactly linear carry needs value + 1 > 0.2: any kappa >= 0 does)
+
+    def put(l, row, cols_vals, bias):
+        v = torch.zeros(shapes[l][1])
+        for col, val in cols_vals:
+            v[col] = val
+        sd[key % (l, 'weight_v')][row] = v
+        sd[key % (l, 'weight_g')][row] = v.norm()
+        sd[key % (l, 'bias')][row] = bias
+
+    # layer 0: ramps r[i][k] = sp(sharp (x_i - c_i - delta_k)), delta = (-w, 0, +w)
+    ramp = []
+    rows0 = spare[0][:9]
+    for i in range(3):
+        for k, dl in enumerate((-w, 0.0, w)):
+            put(0, rows0[3 * i + k], [(i, sharp)], -sharp * (c[i] + dl))
+            ramp.append(rows0[3 * i + k])
+    # layer 1: d = sp(kappa (sum_i hat_i - 2)), hat_i = (r[i][0] - 2 r[i][1] + r[i][2]) / (sharp w)
+    r1 = spare[1][0]
+    cv = []
+    for i in range(3):
+        for k, coef in enumerate((1.0, -2.0, 1.0)):
+            cv.append((ramp[3 * i + k], kappa * coef / (sharp * w)))
+    put(1, r1, cv, -2.0 * kappa)
+    # layers 2 .. nl-2: carry (value + 1 per layer; the skip layer's input is divided by sqrt(2))
+    prev, carried = r1, 0
+    for l in range(2, nl - 1):
+        r = spare[l][0]
+        put(l, r, [(prev, math.sqrt(2.0) if l in skip else 1.0)], 1.0)
+        prev, carried = r, carried + 1
+    # last layer: sdf' = value_scale * sdf - (depth / kappa) (carry - carried)
+    L = nl - 1
+    v, g = sd[key % (L, 'weight_v')], sd[key % (L, 'weight_g')]
+    eff = v[0] * (g[0] / v[0].norm())
+    eff = eff * value_scale
+    eff[prev] = -depth / kappa * (math.sqrt(2.0) if L in skip else 1.0)
+    sd[key % (L, 'weight_v')][0] = eff
+    sd[key % (L, 'weight_g')][0] = eff.norm()
+    sd[key % (L, 'bias')][0] = sd[key % (L, 'bias')][0] * value_scale + depth / kappa * carried
+    return sd
+
+
 def look_at_origin_pose(cam_pos):
     """OpenCV-style cam-to-world (x right, y down, z forward) looking at the origin."""
     c = np.asarray(cam_pos, dtype=np.float64)

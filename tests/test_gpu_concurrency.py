@@ -186,3 +186,74 @@ def test_config3_prefetch_trajectory_equals_the_serial_schedule():
         if p0[k].dtype.is_floating_point and p0[k].numel() > 0:
             d = (p1[k] - p0[k]).norm().item() / (p0[k].norm().item() + 1e-12)
             assert d < 5e-3, (k, d)
+
+
+def test_a_foreign_reduction_kernel_completes_beside_three_traces():
+    """RCCL readiness without RCCL peers.  While TrainStep keeps three traces in flight their evaluators
+    claim whole SIMDs (mlp_tile.h NEFII_CLAIM_SIMD_2): a foreign kernel - RCCL's reduction kernels on a real node - only gets
+    CUs that host no evaluator workgroup at that moment.  Stand-in for the all-reduce of the 12.95-MB gradient buffer: torch's
+    own elementwise add over a buffer of that size (a foreign kernel of a few hundred workgroups, like RCCL's) on a side stream,
+    enqueued once the traces are running.  Measured: its latency beside three config-3-sized traces against its latency alone and
+    against the traces' own duration.  Asserted: it completes while the traces are still in flight (it is not parked behind them),
+    within a bounded multiple of its stand-alone time - i.e. no 'leave N CUs free' mode is needed for world_size > 1; the figures are
+    printed for DESIGN.md section 6."""
+    import time
+    from nefii_amd import ops
+    _, m = _model('conf', scene='bowl_trained')
+    rt = m.ray_tracer
+    w = syn.WORKLOADS['cfg3']
+    inp, _ = syn.make_inputs(w['num_pixels'], w['image_hw'], w['focal'], w['cam_pos'], w['num_rays'], seed=1)
+    inp = {k: v.to(DEV) for k, v in inp.items()}
+    with torch.no_grad():
+        m.trace_points(inp)                      # warm-up: packing, calibration of tau / L, allocator
+    torch.cuda.synchronize()
+    n = 12_950_000 // 4
+    buf, other = torch.zeros(n, device=DEV), torch.ones(n, device=DEV)
+    side = torch.cuda.Stream()
+
+    def reduction(reps=8):
+        with torch.cuda.stream(side):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):                # a ring all-reduce of W ranks runs 2 (W - 1) such passes over 1/W of the buffer each
+                buf.add_(other)
+            e1.record()
+        return e0, e1
+
+    e0, e1 = reduction()
+    torch.cuda.synchronize()
+    alone_ms = e0.elapsed_time(e1)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    ends = []
+    t_all0 = torch.cuda.Event(enable_timing=True)
+    t_all0.record()
+    rt.concurrent = True
+    try:
+        for st in streams:
+            checks = []
+            rt.deferred_checks = checks
+            with torch.cuda.stream(st):
+                st.wait_event(t_all0)
+                with torch.no_grad():
+                    m.trace_points(inp)
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record()
+                ends.append(ev)
+    finally:
+        rt.deferred_checks = None
+        rt.concurrent = False
+    time.sleep(0.02)                              # the traces are running (each takes ~60-150 ms of evaluator time)
+    assert not any(ev.query() for ev in ends), 'the traces finished before the reduction was enqueued: nothing measured'
+    e0, e1 = reduction()
+    e1.synchronize()
+    still_running = sum(0 if ev.query() else 1 for ev in ends)
+    beside_ms = e0.elapsed_time(e1)
+    torch.cuda.synchronize()
+    traces_ms = max(t_all0.elapsed_time(ev) for ev in ends)
+    print('[foreign reduction beside three traces] 8 passes over a 12.95-MB buffer: alone %.3f ms, beside three config-3 traces '
+          '%.3f ms (x %.1f); the traces took %.1f ms, %d of 3 still in flight when the reduction completed' % (
+              alone_ms, beside_ms, beside_ms / alone_ms, traces_ms, still_running))
+    assert still_running >= 1, 'the foreign kernel was parked until the traces had finished'
+    assert beside_ms < 0.25 * traces_ms, (beside_ms, traces_ms)
+    assert float(buf[0].item()) == 16.0 and float(buf[-1].item()) == 16.0

@@ -7,6 +7,9 @@ path consumes, before anyone writes a kernel for them?
   2prod_w    x_h w_h + x_h w_l  (weights split, activations rounded)
   fp8corr    x_h w_h + x_h q(w_l) + q(x_l) w_h, q = e4m3 with one power-of-two scale per 32 consecutive K (the block-scaled
              v_mfma_scale_f32_16x16x128_f8f6f4: 3 x the fp16 form's sustained rate on this part, profiles/r05/fp8_probe.txt)
+  fp8corr_fix the same with ONE constant power-of-two scale per operand kind instead of block scales (what "16f" does)
+  fp8corr_hw x_h w_h + q(x_h) q(w_l) + q(x_l) q(w_h): the same with BOTH operands of each correction product in e4m3 - the
+             instruction has no fp16 x fp8 form, so this is what a kernel can actually compute (round 6)
 
 (1) the SDF value on points of the bounding sphere and within 0.02 of the surface: max / rms error against fp64 - to be read
     against the tracer's decision threshold 5e-5, the coarse bound tau ~ 2e-3 and the split evaluator's 5e-7;
@@ -26,7 +29,7 @@ import torch
 from nefii_amd import synthetic as syn
 from oracle import nets, renderer as orr
 
-MODES = ['split', 'single', '2prod_x', '2prod_w', 'fp8corr']
+MODES = ['split', 'single', '2prod_x', '2prod_w', 'fp8corr', 'fp8corr_hw', 'fp8corr_fix']
 
 
 def e4m3(v):
@@ -35,6 +38,11 @@ def e4m3(v):
     e = torch.floor(torch.log2(a.clamp_min(2.0 ** -20))).clamp_min(-6.0)        # normal exponents -6..8; below: subnormal step
     step = torch.pow(2.0, e - 3.0)
     return torch.sign(v) * torch.round(a / step) * step
+
+
+def q8(v, e):
+    """e4m3 image of v x 2^e with saturation at +-448 (one CONSTANT scale for the whole tensor), back in v's units"""
+    return e4m3((v * 2.0 ** e).clamp(-448.0, 448.0)) * 2.0 ** -e
 
 
 def mx8(v):
@@ -68,6 +76,14 @@ def emu_matmul(x, w, mode):
         acc = acc + xh @ wl.t()
     elif mode == 'fp8corr':
         acc = acc + xh @ mx8(wl).t() + mx8(xl) @ wh.t()
+    elif mode == 'fp8corr_hw':
+        # what the hardware can do (round 6): v_mfma_scale_f32_16x16x128_f8f6f4 takes BOTH operands in an f8f6f4 format - the
+        # partner of each low part is the e4m3 image of the high part, not the high part itself
+        acc = acc + mx8(xh) @ mx8(wl).t() + mx8(xl) @ mx8(wh).t()
+    elif mode == 'fp8corr_fix':
+        # the evaluator as built in round 6 ("16f"): no data-dependent block scales - constants (x_h 2^-3, w_l 2^10, x_l 2^8,
+        # w_h 2^-1 on the 16- / 64-scaled operands), restored by the instruction's scale operand
+        acc = acc + q8(xh, -3) @ q8(wl, 10).t() + q8(xl, 8) @ q8(wh, -1).t()
     return (acc / 1024.0).float()
 
 
@@ -119,6 +135,8 @@ def main():
             e = (v - ref).abs()
             print('  %-8s max %.2e  rms %.2e | near the surface: max %.2e  rms %.2e' % (
                 mode, e.max(), e.pow(2).mean().sqrt(), e[near].max(), e[near].pow(2).mean().sqrt()))
+    if len(sys.argv) > 1 and sys.argv[1] == 'values':
+        return
     # ---- (2) features / normals at hit points in the candidate arithmetic -> rendered RGB / albedo (oracle, config 3 sample)
     inp, gt = syn.make_inputs(64, w['image_hw'], w['focal'], w['cam_pos'], 16, seed=1)
     B, S, R, _ = inp['uv'].shape

@@ -28,7 +28,7 @@ __device__ __forceinline__ unsigned rnd_e4m3x4(unsigned &h, int zero) {
     return w;
 }
 
-enum { K_F16 = 0, K_FP8 = 1, K_MX8 = 2, K_MX4 = 3 };
+enum { K_F16 = 0, K_FP8 = 1, K_MX8 = 2, K_MX4 = 3, K_SPLIT = 4, K_MIX = 5 };
 
 template <int KIND, int CH, int ZERO>
 __global__ __launch_bounds__(256, 1) void k(float *out, unsigned long long *cyc, int groups) {
@@ -63,6 +63,21 @@ __global__ __launch_bounds__(256, 1) void k(float *out, unsigned long long *cyc,
                     asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[q]) : "v"(a16[i]), "v"(b16[q]));
                 } else if (KIND == K_FP8) {
                     asm volatile("v_mfma_f32_16x16x32_fp8_fp8 %0, %1, %2, %0" : "+v"(acc[q]) : "v"(a64[i]), "v"(b64[q]));
+                } else if (KIND == K_SPLIT) {    // one 128-deep chunk of a SPLIT product: 4 k-steps x (hh, hl, lh) on the fp16 form
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[q]) : "v"(a16[i]), "v"(b16[q]));
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[q]) : "v"(a16[i ^ 1]), "v"(b16[q]));
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[q]) : "v"(a16[i]), "v"(b16[(q + 1) % CH]));
+                    }
+                } else if (KIND == K_MIX) {      // the same chunk with the two correction products on ONE block-scaled fp8 MFMA each
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4)
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[q]) : "v"(a16[i]), "v"(b16[q]));
+                    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                                 : "+v"(acc[q]) : "v"(a8[i]), "v"(b8[q]), "v"(unit));
+                    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                                 : "+v"(acc[q]) : "v"(a8[i ^ 1]), "v"(b8[(q + 1) % CH]), "v"(unit));
                 } else if (KIND == K_MX8) {      // both operands fp8 (e4m3): 8 registers each
                     asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
                                  : "+v"(acc[q]) : "v"(a8[i]), "v"(b8[q]), "v"(unit));
@@ -100,6 +115,13 @@ void run(const char *name, float *out, unsigned long long *cyc, int groups) {
     m /= 1024.0;
     const double kdepth = KIND == K_F16 || KIND == K_FP8 ? 32.0 : 128.0;
     const double n_inst = 2.0 * CH * groups;
+    if (KIND == K_SPLIT || KIND == K_MIX) {
+        // n_inst = 128-deep chunks of one 16 x 16 split product; ALGORITHMIC flops: one product per chunk
+        const double pf = 256.0 * 4 * n_inst * 2.0 * 16 * 16 * 128.0 / (ms * 1e-3) / 1e15;
+        printf("%-64s %6.1f cycles per 128-deep chunk, %8.3f ms, clock %.2f GHz, %.3f PFLOP/s ALGORITHMIC chip-wide\n", name,
+               m / n_inst, ms, m / (ms * 1e6), pf);
+        return;
+    }
     const double pf = 256.0 * 4 * n_inst * 2.0 * 16 * 16 * kdepth / (ms * 1e-3) / 1e15;
     printf("%-64s %6.1f cycles per instruction, %8.3f ms, clock %.2f GHz, %.2f PFLOP/s chip-wide\n", name, m / n_inst, ms,
            m / (ms * 1e6), pf);
@@ -124,5 +146,10 @@ int main() {
     run<K_F16, 8, 0>("f16 16x16x32, 8 chains, random operands, long", out, cyc, GL / 2);
     run<K_MX8, 4, 0>("mx fp8 16x16x128 (scaled), 4 chains, random operands, long", out, cyc, GL / 2);
     run<K_MX8, 8, 0>("mx fp8 16x16x128 (scaled), 8 chains, random operands, long", out, cyc, GL / 4);
+    printf("-- one 128-deep chunk of a split-precision product: 12 fp16 MFMAs (today) vs 4 fp16 + 2 block-scaled fp8 (round 6)\n");
+    run<K_SPLIT, 4, 0>("split, 12 x f16 16x16x32 per chunk, 4 chains, random, long", out, cyc, GL / 12);
+    run<K_MIX, 4, 0>("mix, 4 x f16 + 2 x mx fp8 per chunk, 4 chains, random, long", out, cyc, GL / 12);
+    run<K_SPLIT, 8, 0>("split, 12 x f16 16x16x32 per chunk, 8 chains, random, long", out, cyc, GL / 24);
+    run<K_MIX, 8, 0>("mix, 4 x f16 + 2 x mx fp8 per chunk, 8 chains, random, long", out, cyc, GL / 24);
     return 0;
 }
