@@ -182,6 +182,9 @@ def parity_of(workload, ref, device, tier, tweak=None):
     mask = ref['network_object_mask'] & out['network_object_mask'].cpu()
     parity = {'pixels': int(mask.numel()), 'hit_pixels': int(mask.sum()),
               'hit_mask_mismatches': int((ref['network_object_mask'] != out['network_object_mask'].cpu()).sum())}
+    if ref.get('ray_hit') is not None and getattr(m, 'last_ray_hit', None) is not None:
+        # per RAY (a multi-ray pixel counts as hit only when all its rays hit: one ray's flip moves the pixel's mean, not its mask)
+        parity['ray_hit_mismatches'] = int((m.last_ray_hit.cpu().bool() != ref['ray_hit'].bool()).sum())
     for k, name in (('sg_rgb_values', 'rgb'), ('sg_diffuse_albedo_values', 'albedo')):
         a, b = out[k].cpu()[mask], ref[k][mask]
         mse = ((a - b) ** 2).mean().item()
@@ -541,6 +544,9 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                    'primary_rays_per_step_per_gpu': rays_per_rank, 'parallelism': 'dp%d' % world,
                    'step_graph': bool(use_graph), 'cycle_batches': n_cycle,
                    'trace_tier': bool(model.ray_tracer.tier_for()),
+                   # staged bracket search of eval-mode traces (the MC renderer's secondary rays; renders): opt-in since round 6,
+                   # NEFII_BRACKET_STAGED_EVAL=1 - bit-identical while the measured slope bound holds, DESIGN section 4
+                   'bracket_staged_eval': bool(model.ray_tracer.bracket_staged_eval),
                    'synchronous_retraces': int(model.ray_tracer.retraced_calls), 'retraced_steps': int(step.retraced_steps),
                    'num_pixels_override': px_override or None,
                    'rank_param_spread': param_spread,
@@ -617,6 +623,7 @@ def run_render(name, args, frames, rank, world, dev, backend):
                                    'pixel, chunks of %d pixels dealt round-robin over %d rank(s) and gathered on rank 0'
                                    % (name, rows, W, w['num_rays'], (1 << level) // w['num_rays'], world),
                        'primary_rays_per_frame': rays, 'trace_tier': bool(model.ray_tracer.tier_for()),
+                       'bracket_staged_eval': bool(model.ray_tracer.bracket_staged_eval),
                        # (a band through the object is dearer per pixel than the frame's average: no extrapolation from it)
                        'seconds_per_800x800_frame': elapsed / frames if rows == H else None,
                        'hit_pixel_fraction': out['network_object_mask'].float().mean().item(),
@@ -736,7 +743,7 @@ def compact_line(full):
            'scaling': full.get('scaling'), 'vs_baseline': full.get('vs_baseline'), 'dtype': full.get('dtype'),
            'data': full.get('data', 'synthetic')}
     c = {'workload': wl.split(':')[0] if wl else None}
-    for k in ('primary_rays_per_step_per_gpu', 'primary_rays_per_frame', 'parallelism', 'trace_tier', 'secondary_miss_search',
+    for k in ('primary_rays_per_step_per_gpu', 'primary_rays_per_frame', 'parallelism', 'trace_tier', 'bracket_staged_eval', 'secondary_miss_search',
               'step_graph', 'cycle_batches', 'trace_prefetch', 'nonfinite_steps', 'num_pixels_override', 'seconds_per_800x800_frame',
               'hit_pixel_fraction'):
         if cfg.get(k) is not None:
@@ -781,6 +788,8 @@ def compact_line(full):
     out['ms_per_step_without_dead_min_sdf_search'] = _r(full.get('ms_per_step_without_dead_min_sdf_search'), 5)
     if full.get('untiered'):
         out['ms_per_step_untiered'] = _r(full['untiered'].get('ms_per_step'), 5)
+    if full.get('staged_eval_bracket'):
+        out['ms_per_step_staged_eval_bracket'] = _r(full['staged_eval_bracket'].get('ms_per_step'), 5)
     others = {}
     for k in ('cfg1', 'cfg2', 'cfg4'):
         if isinstance(full.get(k), dict) and full[k].get('ms_per_step') is not None:
@@ -907,6 +916,14 @@ def main():
             # the same workload on the library's default arithmetic (no tier), for the like-for-like figure
             nested['cfg3_untiered'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
                                                    dev, backend, lib, side=False, sustained=sustained, tier=False)
+        if world == 1 and headline == 'cfg3' and os.environ.get('NEFII_BRACKET_STAGED_EVAL', '0') != '1':
+            # ... and with the opt-in staging of the secondary traces' bracket search (NEFII_BRACKET_STAGED_EVAL=1)
+            os.environ['NEFII_BRACKET_STAGED_EVAL'] = '1'
+            try:
+                nested['cfg3_staged_eval'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
+                                                          dev, backend, lib, side=False, sustained=sustained)
+            finally:
+                os.environ.pop('NEFII_BRACKET_STAGED_EVAL', None)
         if world == 1 and headline == 'cfg3':
             # the same step on the earlier stand-ins of the same scene: the ZERO-PADDED embedding of an 8 x 64 fit (rounds 2-4:
             # 98 % zero weights - what a power-limited part makes of cheap operands) and its REPLICATED embedding (round 4's
@@ -990,6 +1007,14 @@ def main():
         cancelled = result['config']['nonfinite_steps'] + sum(
             x['config']['nonfinite_steps'] for k, x in nested.items() if x and k != 'cfg5')
         result['invalid'] = cancelled > 0
+        se = nested.get('cfg3_staged_eval')
+        if se is not None:
+            result['staged_eval_bracket'] = {'ms_per_step': se['ms_per_step'], 'ms_per_step_repeats': se['ms_per_step_repeats'],
+                                             'value': se['value'], 'frac': se['roofline']['frac'],
+                                             'minsdf_lipschitz_violation': se['roofline']['minsdf_lipschitz_violation'],
+                                             'nonfinite_steps': se['config']['nonfinite_steps'],
+                                             'note': 'the same workload with RayTracing.bracket_staged_eval on (opt-in: the secondary '
+                                                     'traces\' bracket search staged behind the measured slope bound)'}
         unt = nested.get('cfg3_untiered')
         if unt is not None:
             result['untiered'] = {'ms_per_step': unt['ms_per_step'], 'ms_per_step_repeats': unt['ms_per_step_repeats'],

@@ -82,6 +82,8 @@ class RenderRunner:
         if tt is not None and rt is not None and os.environ.get('NEFII_TRACE_TIER', '') == '':
             rt.trace_tier = bool(tt)
         self.trace_tier = bool(rt.tier_for()) if rt is not None and hasattr(rt, 'tier_for') else False
+        if kwargs.get('bracket_staged_eval') is not None and rt is not None and os.environ.get('NEFII_BRACKET_STAGED_EVAL', '') == '':
+            rt.bracket_staged_eval = bool(kwargs['bracket_staged_eval'])
 
     def run(self):                                                                  # render.py:262-442
         ds = self.test_dataset
@@ -127,9 +129,11 @@ def main(argv=None):
     p.add_argument('--dataset_class', type=str, default='')
     p.add_argument('--trace_tier', default=None, action='store_true',
                    help='tiered sphere tracing for this render (DESIGN.md 4f; default: what the checkpoint records, else off)')
+    p.add_argument('--bracket_staged_eval', default=None, action='store_true',
+                   help='stage the bracket search behind the measured slope bound (DESIGN.md section 4; default off)')
     opt, _ignored = p.parse_known_args(argv)
     local_rank = opt.local_rank if opt.local_rank > -1 else (int(os.environ['LOCAL_RANK']) if 'RANK' in os.environ else -1)
-    RenderRunner(trace_tier=opt.trace_tier, conf=opt.conf, data_split_dir_test=opt.data_split_dir_test or opt.data_split_dir, gamma=opt.gamma,
+    RenderRunner(trace_tier=opt.trace_tier, bracket_staged_eval=opt.bracket_staged_eval, conf=opt.conf, data_split_dir_test=opt.data_split_dir_test or opt.data_split_dir, gamma=opt.gamma,
                  subsample=opt.subsample, vis_subsample=opt.vis_subsample, expname=opt.expname or 'default',
                  exps_folder_name=opt.exps_folder, old_expdir=opt.old_expdir, timestamp=opt.timestamp,
                  checkpoint=opt.checkpoint, memory_capacity_level=opt.memory_capacity_level,

@@ -50,6 +50,9 @@ def main(argv=None):
     p.add_argument('--trace_tier', default=None, action='store_true',
                    help="tiered sphere tracing for every trace of this run (DESIGN.md 4f; default: the conf's train.trace_tier, "
                         "else off)")
+    p.add_argument('--bracket_staged_eval', default=None, action='store_true',
+                   help="stage the bracket search of the secondary traces behind the measured slope bound (DESIGN.md section 4; "
+                        "bit-identical while the bound holds; default off)")
     p.add_argument('--plots', default=False, action='store_true',
                    help="every train.plot_freq iterations render one training view and write its buffers under plots/")
     opt, _ignored = p.parse_known_args(argv)
@@ -67,7 +70,7 @@ def main(argv=None):
         pretrain_geometry_path=opt.pretrain_geometry_path, pretrain_idr_rendering_path=opt.pretrain_idr_rendering_path,
         pretrain_diffuse_path=opt.pretrain_diffuse_path, light_sg_path=opt.light_sg, geometry=opt.geometry, geometry_neus=opt.geometry_neus,
         local_rank=local_rank, model_class=opt.model_class, dataset_class=opt.dataset_class or None,
-        graph=not opt.no_graph, plots=opt.plots, coordinate_type=opt.coordinate_type, trace_tier=opt.trace_tier)
+        graph=not opt.no_graph, plots=opt.plots, coordinate_type=opt.coordinate_type, trace_tier=opt.trace_tier, bracket_staged_eval=opt.bracket_staged_eval)
     runner.run()
 
 

@@ -155,6 +155,13 @@ class IDRTrainRunner:
         if tt is not None and rt is not None and os.environ.get('NEFII_TRACE_TIER', '') == '':
             rt.trace_tier = bool(tt)
         self.trace_tier = bool(rt.tier_for()) if rt is not None and hasattr(rt, 'tier_for') else False
+        # likewise the staged bracket search of eval-mode traces (the MC renderer's secondary rays): opt-in per run
+        # (`bracket_staged_eval` keyword / --bracket_staged_eval, conf train.bracket_staged_eval, NEFII_BRACKET_STAGED_EVAL=1)
+        be = kwargs.get('bracket_staged_eval')
+        if be is None and self.conf.get('train.bracket_staged_eval', None) is not None:
+            be = self.conf.get_bool('train.bracket_staged_eval')
+        if be is not None and rt is not None and os.environ.get('NEFII_BRACKET_STAGED_EVAL', '') == '':
+            rt.bracket_staged_eval = bool(be)
 
         t = self.conf.get_config('train')
         self.step = TrainStep(

@@ -256,6 +256,7 @@ def test_staged_searches_change_no_output_at_full_size(wl):
     for staged in (False, True):
         m = build_model(mc, sd, True)
         m.ray_tracer.trace_tier = True            # as bench.py runs the config (a per-run switch since round 6)
+        m.ray_tracer.bracket_staged_eval = True   # ... and the opt-in staging of the secondary traces' bracket search with it
         m.ray_tracer.minsdf_staged = staged
         m.ray_tracer.minsdf_steps_override = [steps1, steps2]
         m.ray_tracer.collect_counters = True

@@ -1056,16 +1056,30 @@ def test_tracer_staged_bracket_search_adversarial_dent():
     m.eval()
     o, d = _bundle_through(c, 4096, 7)
     rt = m.ray_tracer
+    assert rt.bracket_staged_eval is False          # the default since this test exists: eval-mode traces do not stage their bracket search
+    rt.bracket_staged_eval = True                   # the opt-in
     with warnings_caught() as seen:
         with torch.no_grad():
             pts, hit, dist = rt(sdf=m.implicit_network, cam_loc=o.to(DEV), object_mask=torch.ones(4096, dtype=torch.bool, device=DEV),
                                 ray_directions=d.to(DEV).reshape(4096, 1, 3))
-    base = run_gpu_trace(mc, sd, o, d, torch.ones(4096, dtype=torch.bool), False, steps, 'f16x3w', coarse_tau=tau, pm=pm)
     kinds = [e[0] for e in m.implicit_network.coarse_audit_events]
     print('[adversarial dent] model-level trace: audit events %s, synchronous re-traces %d' % (kinds, rt.retraced_calls))
     assert 'lipschitz_disabled' in kinds and rt.retraced_calls >= 1
     assert m.implicit_network.minsdf_lipschitz(rt.object_bounding_sphere) == 0.0        # off for these weights from now on
-    assert torch.equal(hit, base[1].bool()) and torch.equal(dist, base[2]) and torch.equal(pts, base[0])
+    # ... and what it returned is the trace of a model that never staged its searches (same path, same parameters otherwise)
+    m2 = IDRNetwork(conf.from_dict(mc))
+    m2.load_state_dict(sd, strict=True)
+    m2 = m2.to(DEV)
+    m2.freeze_geometry()
+    m2.eval()
+    m2.ray_tracer.minsdf_staged = False
+    with torch.no_grad():
+        pts2, hit2, dist2 = m2.ray_tracer(sdf=m2.implicit_network, cam_loc=o.to(DEV), object_mask=torch.ones(4096, dtype=torch.bool, device=DEV),
+                                          ray_directions=d.to(DEV).reshape(4096, 1, 3))
+    nd = int((dist != dist2).sum())
+    print('[adversarial dent] re-traced result vs a never-staged model: %d rays differ (max |d depth| %.2e)' % (
+        nd, (dist - dist2).abs().max().item()))
+    assert torch.equal(hit, hit2) and torch.equal(dist, dist2) and torch.equal(pts, pts2)
 
 
 def test_tracer_staged_bracket_search_adversarial_bumps():
@@ -1087,6 +1101,7 @@ def test_tracer_staged_bracket_search_adversarial_bumps():
     w2 = torch.nn.functional.normalize(torch.randn(hp.shape[0], 3, generator=torch.Generator().manual_seed(9)), dim=1).to(DEV)
     nrm = torch.nn.functional.normalize(ops.sdf_value_grad(pm32, hp)[2], dim=1)
     w2 = torch.where((w2 * nrm).sum(1, keepdim=True) < 0, -w2, w2)
+    audited = probes = 0
     for what, (oo, dd, mm) in (('primary', (o, d, om)), ('secondary', (hp.cpu(), w2.cpu(), torch.ones(hp.shape[0], dtype=torch.bool)))):
         for training in (False, True):
             base = run_gpu_trace(mc, sd, oo, dd, mm, training, steps, 'f16x3w', coarse_tau=tau, pm=pm)
@@ -1094,9 +1109,12 @@ def test_tracer_staged_bracket_search_adversarial_bumps():
             for k in range(3):
                 assert torch.equal(got[k], base[k]), (what, training, k)
             c = got[3].cpu().long()
-            assert c[:, 12].max() == 0 and c[:, 11].sum() > 0 and c[:, 13].sum() > 0
-            print('[adversarial bumps %s %s] %d second-stage samples audited, %d of them probes of skipped samples' % (
-                what, 'train' if training else 'eval', c[:, 11].sum().item(), c[:, 13].sum().item()))
+            assert c[:, 12].max() == 0, (what, training)
+            audited += c[:, 11].sum().item()
+            probes += c[:, 13].sum().item()
+            print('[adversarial bumps %s %s] %d dense searches, %d second-stage samples audited, %d of them probes of skipped samples' % (
+                what, 'train' if training else 'eval', c[:, 6].sum().item(), c[:, 11].sum().item(), c[:, 13].sum().item()))
+    assert audited > 0 and probes > 0, (audited, probes)
 
 
 def test_pack_mlp_equals_the_per_layer_packers():

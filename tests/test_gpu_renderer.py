@@ -466,7 +466,7 @@ def test_runner_checkpoint_layout_and_resume(tmp_path, graph):
         assert sorted(os.listdir(os.path.join(ck, sub))) == ['0.pth', '1.pth', 'latest.pth'], sub
     d = torch.load(os.path.join(ck, 'ModelParameters', 'latest.pth'))
     # the reference's payload keys (idr_train.py:334-337: what its loader reads) plus this build's record of the run's tracer arithmetic
-        assert set(d) == {'epoch', 'model_state_dict', 'trace_tier'} and d['epoch'] == 1 and d['trace_tier'] is False
+    assert set(d) == {'epoch', 'model_state_dict', 'trace_tier'} and d['epoch'] == 1 and d['trace_tier'] is False
     assert set(d['model_state_dict']) == set(sd)
     o = torch.load(os.path.join(ck, 'IDROptimizerParameters', 'latest.pth'))
     assert set(o) == {'epoch', 'optimizer_state_dict'} and isinstance(o['optimizer_state_dict']['param_groups'][0]['lr'], float)

@@ -33,7 +33,7 @@ def main():
                 ('+fp16mlp', dict(mlp='f16x3', tracer='f16x3w', tier=False)), ('+tier', dict(mlp='f16x3', tracer='f16x3w', tier=True))]
     if fp8:
         variants.append(('+fp8corr', dict(mlp='f16x3', tracer='f16x3w', tier=True, fp8=True)))
-    for wl, pp in (('cfg3', 128), ('cfg4', 128), ('cfg5', 32)):
+    for wl, pp in (('cfg3', 128), ('cfg4', 128), ('cfg5', 64)):
         ref = bench.oracle_reference(wl, pp)
         for name, v in variants:
             os.environ['NEFII_MLP_PRECISION'] = v['mlp']
@@ -47,13 +47,13 @@ def main():
                 os.environ.pop('NEFII_MLP_PRECISION', None)
                 os.environ.pop('NEFII_SPLIT_FP8', None)
             row = {'workload': wl, 'arithmetic': name, 'pixels': p['pixels'], 'hit_pixels': p['hit_pixels'],
-                   'flips': p['hit_mask_mismatches'], 'rgb_rel_l2': p['rgb_rel_l2'], 'albedo_rel_l2': p['albedo_rel_l2'],
+                   'flips': p['hit_mask_mismatches'], 'ray_flips': p.get('ray_hit_mismatches'), 'rgb_rel_l2': p['rgb_rel_l2'], 'albedo_rel_l2': p['albedo_rel_l2'],
                    'rgb_rel_l2_same_samples': p.get('rgb_rel_l2_same_samples'),
                    'rays_with_another_sampled_direction': p.get('rays_with_another_sampled_direction'),
                    'rays_with_another_secondary_hit_flag': p.get('rays_with_another_secondary_hit_flag')}
             rows.append(row)
-            print('%-5s %-9s hit pixels %3d/%3d flips %d | RGB %.2e (same samples %s) albedo %.2e | rays with another lobe %s, another '
-                  'secondary hit flag %s' % (wl, name, row['hit_pixels'], row['pixels'], row['flips'], row['rgb_rel_l2'],
+            print('%-5s %-9s hit pixels %3d/%3d flips %d (rays: %s) | RGB %.2e (same samples %s) albedo %.2e | rays with another lobe %s, another '
+                  'secondary hit flag %s' % (wl, name, row['hit_pixels'], row['pixels'], row['flips'], row['ray_flips'], row['rgb_rel_l2'],
                                              '%.2e' % row['rgb_rel_l2_same_samples'] if row['rgb_rel_l2_same_samples'] is not None else '-',
                                              row['albedo_rel_l2'], row['rays_with_another_sampled_direction'],
                                              row['rays_with_another_secondary_hit_flag']), flush=True)
