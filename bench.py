@@ -423,6 +423,8 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     frac_chip = queries * f_eval / (ms_per_step * 1e-3) / (peak * 1e12)
     # SURVEY 8(d)-strict on the same kernel time: only the evaluations 8(d) counts (no min-SDF search)
     frac_8d = evals_live * f_eval / (eval_ms.value * 1e-3) / (peak * 1e12) if eval_ms.value > 0 else 0.0
+    # (with RayTracing.split_fp8 the two correction products of a split evaluation are fp8 MFMAs: counted here at their flops, which
+    # the fp16 sustained_peak does not price - issued_frac_of_sustained is then an upper bound of the fp16 share)
     issued = (executed * (3 if split else 1) + executed_coarse) * f_eval / (eval_ms.value * 1e-3) / 1e12 if eval_ms.value > 0 else 0.0
     # what the kernels EXECUTED, one F_sdf per evaluation whatever its arithmetic (frac credits the reference's count: samples
     # the windowed searches never evaluated are an algorithmic saving, not kernel efficiency)
@@ -547,6 +549,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
                    # staged bracket search of eval-mode traces (the MC renderer's secondary rays; renders): opt-in since round 6,
                    # NEFII_BRACKET_STAGED_EVAL=1 - bit-identical while the measured slope bound holds, DESIGN section 4
                    'bracket_staged_eval': bool(model.ray_tracer.bracket_staged_eval),
+                   'split_fp8': bool(model.ray_tracer.split_fp8),
                    'synchronous_retraces': int(model.ray_tracer.retraced_calls), 'retraced_steps': int(step.retraced_steps),
                    'num_pixels_override': px_override or None,
                    'rank_param_spread': param_spread,
@@ -743,7 +746,7 @@ def compact_line(full):
            'scaling': full.get('scaling'), 'vs_baseline': full.get('vs_baseline'), 'dtype': full.get('dtype'),
            'data': full.get('data', 'synthetic')}
     c = {'workload': wl.split(':')[0] if wl else None}
-    for k in ('primary_rays_per_step_per_gpu', 'primary_rays_per_frame', 'parallelism', 'trace_tier', 'bracket_staged_eval', 'secondary_miss_search',
+    for k in ('primary_rays_per_step_per_gpu', 'primary_rays_per_frame', 'parallelism', 'trace_tier', 'bracket_staged_eval', 'split_fp8', 'secondary_miss_search',
               'step_graph', 'cycle_batches', 'trace_prefetch', 'nonfinite_steps', 'num_pixels_override', 'seconds_per_800x800_frame',
               'hit_pixel_fraction'):
         if cfg.get(k) is not None:
@@ -788,6 +791,8 @@ def compact_line(full):
     out['ms_per_step_without_dead_min_sdf_search'] = _r(full.get('ms_per_step_without_dead_min_sdf_search'), 5)
     if full.get('untiered'):
         out['ms_per_step_untiered'] = _r(full['untiered'].get('ms_per_step'), 5)
+    if full.get('split_fp8'):
+        out['ms_per_step_split_fp8'] = _r(full['split_fp8'].get('ms_per_step'), 5)
     if full.get('staged_eval_bracket'):
         out['ms_per_step_staged_eval_bracket'] = _r(full['staged_eval_bracket'].get('ms_per_step'), 5)
     others = {}
@@ -916,6 +921,14 @@ def main():
             # the same workload on the library's default arithmetic (no tier), for the like-for-like figure
             nested['cfg3_untiered'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
                                                    dev, backend, lib, side=False, sustained=sustained, tier=False)
+        if world == 1 and headline == 'cfg3' and os.environ.get('NEFII_SPLIT_FP8', '0') != '1':
+            # ... with the split evaluator's correction products on block-scaled fp8 (RayTracing.split_fp8, opt-in)
+            os.environ['NEFII_SPLIT_FP8'] = '1'
+            try:
+                nested['cfg3_split_fp8'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
+                                                        dev, backend, lib, side=False, sustained=sustained)
+            finally:
+                os.environ.pop('NEFII_SPLIT_FP8', None)
         if world == 1 and headline == 'cfg3' and os.environ.get('NEFII_BRACKET_STAGED_EVAL', '0') != '1':
             # ... and with the opt-in staging of the secondary traces' bracket search (NEFII_BRACKET_STAGED_EVAL=1)
             os.environ['NEFII_BRACKET_STAGED_EVAL'] = '1'
@@ -1007,6 +1020,14 @@ def main():
         cancelled = result['config']['nonfinite_steps'] + sum(
             x['config']['nonfinite_steps'] for k, x in nested.items() if x and k != 'cfg5')
         result['invalid'] = cancelled > 0
+        f8 = nested.get('cfg3_split_fp8')
+        if f8 is not None:
+            result['split_fp8'] = {'ms_per_step': f8['ms_per_step'], 'ms_per_step_repeats': f8['ms_per_step_repeats'],
+                                   'value': f8['value'], 'frac': f8['roofline']['frac'],
+                                   'kernel_ms_per_step': f8['roofline']['kernel_ms_per_step'],
+                                   'nonfinite_steps': f8['config']['nonfinite_steps'],
+                                   'note': 'the same workload with RayTracing.split_fp8 on (opt-in: the split evaluator\'s two correction '
+                                           'products on v_mfma_scale_f32_16x16x128_f8f6f4; a third arithmetic, |sdf error| ~1e-5)'}
         se = nested.get('cfg3_staged_eval')
         if se is not None:
             result['staged_eval_bracket'] = {'ms_per_step': se['ms_per_step'], 'ms_per_step_repeats': se['ms_per_step_repeats'],

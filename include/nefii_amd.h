@@ -273,6 +273,14 @@ typedef struct nefii_tracer_params {
                                 staged search skips every sample its bound proves positive.  Hit masks, hit points and hit
                                 depths are those of unread_misses == 0 bit for bit.  What the Monte-Carlo renderer's secondary
                                 rays need (path_tracing_render.py: visibility and the radiance at secondary HITS). */
+    int32_t split_fp8;       /* ABI 15 - 1: the split-precision evaluations of the trace (every query the coarse pass and the tier do
+                                not take) run on the "16f" evaluator: the main product x_h w_h on fp16 MFMAs as before, the two
+                                correction products x_h w_l and x_l w_h on the block-scaled fp8 MFMA
+                                (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 operands, constant scales).  A THIRD arithmetic: max |sdf
+                                error| against fp64 ~1e-5 (1.6e-6 near the surface) where the fp16 split gives 5e-7 - values, not
+                                only schedules, change at that level (depths of converged rays within ~1e-5; DESIGN.md section
+                                4g).  Needs precision 2 and a 512-wide net with the fifth stream copy
+                                (nefii_sdf_fp8corr_supported); ignored otherwise.  0: off (default). */
 } nefii_tracer_params;
 #define NEFII_TRACE_COUNTERS 14  /* int32 counters per round, see nefii_trace_rays */
 
@@ -317,6 +325,12 @@ int nefii_sdf_eval(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf
  * bounding sphere, with a safety factor, is what a caller passes as nefii_tracer_params.coarse_tau. */
 int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream);
 int nefii_sdf_coarse_supported(const nefii_mlp *h_sdf);
+/* ABI 15 - the same points through the "16f" evaluator (nefii_tracer_params.split_fp8: correction products on block-scaled fp8);
+ * NEFII_E_UNSUPPORTED unless nefii_sdf_fp8corr_supported (512-wide hidden layers, reserved == 1, w_stream packed by this
+ * library version: the fifth copy of nefii_pack_sdf_stream - per wave and 128-deep chunk of each layer's 128-padded K eight 4-KiB
+ * units: four 32-deep k-steps of hi fragments, then per 16-feature tile [e4m3(w_l 2^10) 32 B | e4m3(w_h 2^-1) 32 B] per lane). */
+int nefii_sdf_eval_fp8corr(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream);
+int nefii_sdf_fp8corr_supported(const nefii_mlp *h_sdf);
 
 size_t nefii_trace_workspace_bytes(int64_t n_rays, const nefii_tracer_params *h_params);
 int nefii_trace_max_rounds(const nefii_tracer_params *h_params);

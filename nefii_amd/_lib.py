@@ -43,7 +43,7 @@ class TracerParams(ctypes.Structure):
                 ('precision', ctypes.c_int32), ('coarse_tau', ctypes.c_float), ('coarse_cap', ctypes.c_int32),
                 ('minsdf_group', ctypes.c_int32), ('small_round', ctypes.c_int32), ('trace_tier', ctypes.c_int32),
                 ('tier_kappa', ctypes.c_float), ('tier_gate', ctypes.c_float), ('minsdf_lipschitz', ctypes.c_float),
-                ('unread_misses', ctypes.c_int32)]
+                ('unread_misses', ctypes.c_int32), ('split_fp8', ctypes.c_int32)]
 
 
 class PackSource(ctypes.Structure):
@@ -112,6 +112,8 @@ SIGNATURES = {
     'nefii_sdf_eval': (I, [ctypes.POINTER(Mlp), P, I64, P, P]),
     'nefii_sdf_eval_coarse': (I, [ctypes.POINTER(Mlp), P, I64, P, P]),
     'nefii_sdf_coarse_supported': (I, [ctypes.POINTER(Mlp)]),
+    'nefii_sdf_eval_fp8corr': (I, [ctypes.POINTER(Mlp), P, I64, P, P]),
+    'nefii_sdf_fp8corr_supported': (I, [ctypes.POINTER(Mlp)]),
     'nefii_trace_workspace_bytes': (ctypes.c_size_t, [I64, ctypes.POINTER(TracerParams)]),
     'nefii_trace_max_rounds': (I, [ctypes.POINTER(TracerParams)]),
     'nefii_trace_rays': (I, [ctypes.POINTER(Mlp), ctypes.POINTER(TracerParams), P, P, P, I64, P, P, P, P, P, P,

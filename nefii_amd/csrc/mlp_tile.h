@@ -1910,6 +1910,316 @@ __device__ __forceinline__ void sdf_tile16d(const nefii_mlp &m, _Float16 *X, flo
     }
 }
 
+
+// ================================================================================================
+// "16f" (round 6): the split-precision evaluator with its two CORRECTION products on block-scaled fp8.
+//   x w ~ x_h w_h  +  q(x_h) q(w_l)  +  q(x_l) q(w_h),      q = OCP e4m3 with ONE constant power-of-two scale per operand kind
+// The main product stays on v_mfma_f32_16x16x32_f16; each correction product of a 128-deep chunk is ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 (4 x the K of the fp16 form in 2 x its cycles): 4 + 2 x 2 = 8 fp16-MFMA times per chunk and
+// (feature tile, query tile) instead of 12, and the fp8 form costs the power-limited part less energy per flop
+// (profiles/r06/fp8_probe.txt: a bare chunk loop 14.6 -> 10.0 ms).  The correction terms are 2^-11 of the product, so an e4m3
+// operand (2^-4 relative) leaves 2^-15: max |sdf error| against fp64 1.0e-5 (1.6e-6 within 0.02 of the surface; "16q": 5e-7;
+// tools/experiments/arith_emulation.py `fp8corr_fix`).  No data-dependent block scales: a low part is bounded by the ulp of its
+// high part and what falls below e4m3's range is negligible in absolute terms - the constants below, restored by the
+// instruction's scale operand.  512-wide nets only (FT = 4); the last layer's single column keeps fp16 for w_l x_h and does
+// q(x_l) w_h on the VALU (there is no fp16 x_l image).
+// Stream (nefii_pack_sdf_stream's fifth copy): per wave and 128-deep chunk of a layer's 128-padded K eight 4-KiB units - the
+// chunk's four 32-deep k-steps in hi fragments (as "16s"), then per feature tile [q(w_l) 32 B | q(w_h) 32 B] per lane, lane
+// (f = lane & 15, g = lane >> 4) holding k = 128 chunk + 32 g + 0..31 - one cursor, the same 4 register stages.
+// LDS: the fp16 hi image of "16q", and instead of its lo image two fp8 images (q(x_l), q(x_h)) of XP8 bytes per row.
+// ================================================================================================
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int F8_XH_E = -3, F8_WL_E = 10, F8_XL_E = 8, F8_WH_E = -1;       // stored value = operand x 2^E (operands carry x 16 / x 64)
+constexpr int F8_SCALE_HL = (127 - (F8_XH_E + F8_WL_E)) * 0x01010101;        // E8M0 byte (in every byte lane of the scale operand) that restores q(x_h) q(w_l): 2^-7
+constexpr int F8_SCALE_LH = (127 - (F8_XL_E + F8_WH_E)) * 0x01010101;        // ... and q(x_l) q(w_h): 2^-7
+constexpr int F8_SCALE_ONE = 0x7f7f7f7f;
+constexpr int XP8 = 592;                                                   // bytes per row of an fp8 image (16 B * 37)
+struct LdsF {
+    _Float16 Xh[64 * QGeo<4>::XP];
+    // order matters: a layer's 128-padded K reads past the end of a row - past the LAST row into what follows - and multiplies it
+    // by zero weights: q(x_l) bytes read as halves are finite (|x_l| 2^8 < 2^7: exponent field never all ones), any e4m3 byte the
+    // epilogue writes is finite, the tail is zero
+    unsigned char Fl[64 * XP8], Fh[64 * XP8];
+    _Float16 tail[128];
+};
+__device__ __forceinline__ int f8_pack4(float a, float b, float c, float d) {
+    const float lim = 448.f;
+    a = __builtin_fminf(__builtin_fmaxf(a, -lim), lim), b = __builtin_fminf(__builtin_fmaxf(b, -lim), lim);
+    c = __builtin_fminf(__builtin_fmaxf(c, -lim), lim), d = __builtin_fminf(__builtin_fmaxf(d, -lim), lim);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    return __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+}
+__device__ __forceinline__ float f8_scale(int e) { return __builtin_bit_cast(float, (127 + e) << 23); }
+// chunks (128-deep) of a layer in the fifth stream copy; 8 units each
+__host__ __device__ __forceinline__ int f_chunks(const nefii_layer &L) { return (L.k_x + L.k_e + 127) >> 7; }
+
+template <int QT>
+struct FAct {
+    i32x8 h[QT], l[QT];
+};
+template <int QT>
+__device__ __forceinline__ void fload_x8(FAct<QT> &st, const unsigned char *fh, const unsigned char *fl, int chunk) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const i32x4 *ph = reinterpret_cast<const i32x4 *>(fh + qt * 16 * XP8 + 128 * chunk);
+        const i32x4 *pl = reinterpret_cast<const i32x4 *>(fl + qt * 16 * XP8 + 128 * chunk);
+        const i32x4 h0 = ph[0], h1 = ph[1], l0 = pl[0], l1 = pl[1];
+        st.h[qt] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+        st.l[qt] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+// main step J (0..3) of a chunk: the hi x hi MFMAs of one 32-deep k-step, as "16s"; LOADX: also fetch the chunk's fp8 activations
+template <int QT, int J, bool LOADX>
+__device__ __forceinline__ void fstep_main(SStage<4> (&b)[4], SAct<QT> (&a)[2], FAct<QT> &x8, PCursor &cur, const _Float16 *ah,
+                                           const unsigned char *fh, const unsigned char *fl, int chunk, f32x4 (&acc)[4 * QT]) {
+    sload<4>(b[(J + 3) % 4], cur);
+    sload_a<QT, QGeo<4>::XP>(a[(J + 1) & 1], ah, 4 * chunk + J + 1);
+    if (LOADX) fload_x8<QT>(x8, fh, fl, chunk);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 &c = acc[ft * QT + qt];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(b[J].f[ft], a[J & 1].h[qt], c, 0, 0, 0);
+        }
+    // MFMAs lead; the unit's four fragment loads and the LDS reads (QT of the next k-step, with LOADX 4 QT more) are spread between them
+#define NEFII_FGROUP(i)                                                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x008, QT / 2, 0);                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x008, QT - QT / 2, 0);                                               \
+    __builtin_amdgcn_sched_group_barrier(0x100, (LOADX ? QT : 0) + (QT * ((i) + 1)) / 4 - (QT * (i)) / 4, 0);
+    NEFII_FGROUP(0)
+    NEFII_FGROUP(1)
+    NEFII_FGROUP(2)
+    NEFII_FGROUP(3)
+#undef NEFII_FGROUP
+    __builtin_amdgcn_sched_barrier(0);
+}
+// correction step of feature tile FTI: stage (4 + FTI) % 4 = FTI holds [q(w_l) | q(w_h)] of that tile
+template <int QT, int FTI>
+__device__ __forceinline__ void fstep_corr(SStage<4> (&b)[4], const FAct<QT> &x8, PCursor &cur, f32x4 (&acc)[4 * QT]) {
+    sload<4>(b[(FTI + 3) % 4], cur);
+    const i32x4 w0 = __builtin_bit_cast(i32x4, b[FTI].f[0]), w1 = __builtin_bit_cast(i32x4, b[FTI].f[1]);
+    const i32x4 w2 = __builtin_bit_cast(i32x4, b[FTI].f[2]), w3 = __builtin_bit_cast(i32x4, b[FTI].f[3]);
+    const i32x8 wl8 = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const i32x8 wh8 = __builtin_shufflevector(w2, w3, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        f32x4 &c = acc[FTI * QT + qt];
+        c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wl8, x8.h[qt], c, 0, 0, 0, F8_SCALE_HL, 0, F8_SCALE_ONE);
+        c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wh8, x8.l[qt], c, 0, 0, 0, F8_SCALE_LH, 0, F8_SCALE_ONE);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, QT, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int QT>
+__device__ __forceinline__ void fgemm(int chunks, SStage<4> (&b)[4], SAct<QT> (&a)[2], FAct<QT> &x8, PCursor &cur,
+                                      const _Float16 *ah, const unsigned char *fh, const unsigned char *fl, f32x4 (&acc)[4 * QT]) {
+    for (int c = 0; c < chunks; ++c) {
+        fstep_main<QT, 0, true>(b, a, x8, cur, ah, fh, fl, c, acc);
+        fstep_main<QT, 1, false>(b, a, x8, cur, ah, fh, fl, c, acc);
+        fstep_main<QT, 2, false>(b, a, x8, cur, ah, fh, fl, c, acc);
+        fstep_main<QT, 3, false>(b, a, x8, cur, ah, fh, fl, c, acc);
+        fstep_corr<QT, 0>(b, x8, cur, acc);
+        fstep_corr<QT, 1>(b, x8, cur, acc);
+        fstep_corr<QT, 2>(b, x8, cur, acc);
+        fstep_corr<QT, 3>(b, x8, cur, acc);
+    }
+}
+
+template <int QT, bool FAST>
+__device__ __forceinline__ void fepilogue(const f32x4 (&acc)[4 * QT], float bvec, float k16, int lane, int act,
+                                          half4 (&phi)[4 * QT], int (&p8h)[4 * QT], int (&p8l)[4 * QT]) {
+    const int bsrc = __builtin_bit_cast(int, bvec * A16_SCALE);
+    const float sxh = f8_scale(F8_XH_E), sxl = f8_scale(F8_XL_E);
+#pragma unroll
+    for (int ft = 0; ft < 4; ++ft) {
+        float4v bs;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            bs[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * ft + 4 * (lane >> 4) + k), bsrc));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const f32x4 &av = acc[ft * QT + qt];
+            float4v hs;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float zs = __builtin_fmaf(av[k], k16, bs[k]);
+                hs[k] = FAST ? softplus100_s16(zs) : act_fwd(zs * (1.f / A16_SCALE), act) * A16_SCALE;
+            }
+            const half4 hi = __builtin_convertvector(hs, half4);
+            const float4v hf = __builtin_convertvector(hi, float4v), lf = hs - hf;
+            phi[ft * QT + qt] = hi;
+            p8h[ft * QT + qt] = f8_pack4(hf[0] * sxh, hf[1] * sxh, hf[2] * sxh, hf[3] * sxh);
+            p8l[ft * QT + qt] = f8_pack4(lf[0] * sxl, lf[1] * sxl, lf[2] * sxl, lf[3] * sxl);
+        }
+    }
+}
+
+// stages 0..2 <- units 0..2 of the wave's stream (start of a workgroup); f8_stream: the fifth copy (host: f8_stream_offset)
+__device__ __forceinline__ void prime16f(const nefii_mlp &m, const void *f8_stream, SStage<4> (&b)[4], PCursor &cur) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    int G = 0;
+    for (int l = 0; l < m.n_layers - 1; ++l) G += 8 * f_chunks(m.layer[l]);
+    cur.bytes = (unsigned)G * 4096;
+    cur.base = reinterpret_cast<const half8 *>(f8_stream) + (size_t)wave * G * 256 + lane;
+    cur.off = 0;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) sload<4>(b[u], cur);
+}
+
+// One tile of 16 * QT queries (QT = 4 / 2) through the whole 512-wide SDF network; interface of sdf_tile16q
+template <int QT>
+__device__ __forceinline__ void sdf_tile16f(const nefii_mlp &m, LdsF &lds, float *raw, float *const *dest, SStage<4> (&b)[4],
+                                            PCursor &cur, const float *coarse_old = nullptr, int *audit = nullptr) {
+    constexpr int NW = 8, FT = 4, RT = QT / 2, XP = QGeo<4>::XP, EP = QGeo<4>::HW, EW = QGeo<4>::EW, RMAX = QGeo<4>::ROWS;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int NH = m.n_layers - 1;
+    const float inv_scale = 1.f / (W16_SCALE * A16_SCALE);
+    const float k16 = inv_scale * A16_SCALE;
+    const float sxh = f8_scale(F8_XH_E), sxl = f8_scale(F8_XL_E);
+    const int boff = 16 * FT * wave + (lane & (16 * FT - 1));
+    float bnext = m.layer[0].bias[boff];
+    {       // positional encoding of the queries: hi halves and the fp8 images of hi and lo
+        const int w0 = enc_width(m.enc_freqs[0]);
+        for (int i = threadIdx.x; i < 16 * QT * EW; i += 512) {
+            const int p = i / EW, c = i - p * EW;
+            const float val = c < w0 ? enc_value(raw + p * 9, c) : 0.f;
+            _Float16 hi, lo;
+            split16a(val, hi, lo);
+            lds.Xh[p * XP + EP + c] = hi;
+            lds.Fh[p * XP8 + EP + c] = (unsigned char)(f8_pack4((float)hi * sxh, 0.f, 0.f, 0.f) & 0xff);
+            lds.Fl[p * XP8 + EP + c] = (unsigned char)(f8_pack4((float)lo * sxl, 0.f, 0.f, 0.f) & 0xff);
+        }
+    }
+    __syncthreads();
+    const int qoff = (lane & 15) * XP + 8 * (lane >> 4), qoff8 = (lane & 15) * XP8 + 32 * (lane >> 4);
+    for (int l = 0; l < NH; ++l) {
+        const nefii_layer &L = m.layer[l];
+        const int chunks = f_chunks(L);
+        const _Float16 *ah = lds.Xh + qoff + (EP - L.k_x);
+        const unsigned char *fh = lds.Fh + qoff8 + (EP - L.k_x), *fl = lds.Fl + qoff8 + (EP - L.k_x);
+        const float *bp = m.layer[l + 1 < NH ? l + 1 : l].bias + boff;
+        asm volatile("" ::"s"(chunks), "v"(ah), "v"(fh), "v"(fl), "v"(bp));
+        __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0): known state for the waitcnt pass (see 16p)
+        __builtin_amdgcn_sched_barrier(0);
+        const float bvec = bnext;
+        f32x4 acc[FT * QT];
+#pragma unroll
+        for (int j = 0; j < FT * QT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+        SAct<QT> a[2];
+        FAct<QT> x8;
+        sload_a<QT, XP>(a[0], ah, 0);
+        fgemm<QT>(chunks, b, a, x8, cur, ah, fh, fl, acc);
+        bnext = *bp;
+        __builtin_amdgcn_sched_barrier(0);
+        // epilogue: bias, activation, split into the fp16 hi half and the fp8 images of hi and lo
+        half4 phi[FT * QT];
+        int p8h[FT * QT], p8l[FT * QT];
+        if (m.act == NEFII_ACT_SOFTPLUS100)
+            fepilogue<QT, true>(acc, bvec, k16, lane, m.act, phi, p8h, p8l);
+        else
+            fepilogue<QT, false>(acc, bvec, k16, lane, m.act, phi, p8h, p8l);
+        __syncthreads();
+        _Float16 *xh = lds.Xh + (EP - L.n_pad);
+        unsigned char *x8h = lds.Fh + (EP - L.n_pad), *x8l = lds.Fl + (EP - L.n_pad);
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+            const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int query = 16 * qt + (lane & 15);
+                *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                *reinterpret_cast<int *>(x8h + query * XP8 + f0) = p8h[ft * QT + qt];
+                *reinterpret_cast<int *>(x8l + query * XP8 + f0) = p8l[ft * QT + qt];
+            }
+        }
+        __syncthreads();
+    }
+    // last layer, column 0 only.  w_h x_h + w_l x_h on 32x32x16 fragments of the layer's own w_f16x3 (K split over the waves,
+    // as "16q"); the third term, w_h q(x_l), on the VALU from the fp8 image of x_l: thread (row = t & 63, part = t >> 6) sums its
+    // 64 k into the slot of (wave = part, row)
+    {
+        const int r = lane & 31, h = lane >> 5;
+        const nefii_layer &L = m.layer[NH];
+        const int NT = L.n_pad >> 5;
+        const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
+        const _Float16 *ah = lds.Xh + r * XP + 8 * h + (EP - L.k_x);
+        const int ksw = (L.k_x >> 4) / NW;
+        f32x16 acc2[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[rt][i] = 0.f;
+        for (int u = 0; u < ksw; ++u) {
+            const int s = wave * ksw + u;
+            const half8 wh = wl[(size_t)s * NT * 128], wlo = wl[(size_t)s * NT * 128 + 64];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const half8 xh8 = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP + 16 * s);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh8, acc2[rt], 0, 0, 0);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh8, acc2[rt], 0, 0, 0);
+            }
+        }
+        float third = 0.f;
+        {
+            const int row = threadIdx.x & 63, part = threadIdx.x >> 6;
+            if (row < 16 * QT) {
+                const int kpw = L.k_x / NW;                 // 64 for the 512-deep last layer
+                const unsigned char *xl = lds.Fl + row * XP8 + (EP - L.k_x) + part * kpw;
+                const _Float16 *wsrc = reinterpret_cast<const _Float16 *>(L.w_f16x3);
+                for (int k8 = 0; k8 < kpw; k8 += 8) {
+                    const int k = part * kpw + k8;
+                    // hi fragment of column n = 0: half8 index ((k >> 4) * NT * 2) * 64 + 32 * ((k >> 3) & 1), elements k & 7
+                    const half8 w8 = *reinterpret_cast<const half8 *>(wsrc + (((size_t)(k >> 4) * NT * 2) * 64 + 32 * ((k >> 3) & 1)) * 8);
+                    const int x0 = *reinterpret_cast<const int *>(xl + k8), x1 = *reinterpret_cast<const int *>(xl + k8 + 4);
+                    third = __builtin_fmaf((float)w8[0], __builtin_amdgcn_cvt_f32_fp8(x0, 0), third);
+                    third = __builtin_fmaf((float)w8[1], __builtin_amdgcn_cvt_f32_fp8(x0, 1), third);
+                    third = __builtin_fmaf((float)w8[2], __builtin_amdgcn_cvt_f32_fp8(x0, 2), third);
+                    third = __builtin_fmaf((float)w8[3], __builtin_amdgcn_cvt_f32_fp8(x0, 3), third);
+                    third = __builtin_fmaf((float)w8[4], __builtin_amdgcn_cvt_f32_fp8(x1, 0), third);
+                    third = __builtin_fmaf((float)w8[5], __builtin_amdgcn_cvt_f32_fp8(x1, 1), third);
+                    third = __builtin_fmaf((float)w8[6], __builtin_amdgcn_cvt_f32_fp8(x1, 2), third);
+                    third = __builtin_fmaf((float)w8[7], __builtin_amdgcn_cvt_f32_fp8(x1, 3), third);
+                }
+                third *= f8_scale(-F8_XL_E);
+            }
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) raw[wave * RMAX + 32 * rt + r] = acc2[rt][0];
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) < 16 * QT) raw[(threadIdx.x >> 6) * RMAX + (threadIdx.x & 63)] += third;
+        __syncthreads();
+        float dm = 0.f;
+        if (threadIdx.x < 32 * RT) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += raw[w * RMAX + threadIdx.x];
+            float *d = dest[threadIdx.x];
+            const float v = sum * inv_scale + L.bias[0];
+            if (d) *d = v;
+            if (coarse_old) {
+                const float o = coarse_old[threadIdx.x];
+                if (d && o == o) dm = __builtin_fabsf(o - v);
+            }
+        }
+        if (coarse_old && threadIdx.x < 128) {
+#pragma unroll
+            for (int s = 32; s > 0; s >>= 1) dm = __builtin_fmaxf(dm, __shfl_xor(dm, s));
+            if ((threadIdx.x & 63) == 0 && dm > 0.f) atomicMax(audit, __builtin_bit_cast(int, dm));
+        }
+        __syncthreads();
+    }
+}
+
 // accumulator element -> (row, col) of the 32 x n_pad output (32x32 C/D map: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); cdna_hip_programming.md section 3)
 #define NEFII_FOR_ACC(acc, ntw, BODY)                                                     \

@@ -1309,6 +1309,78 @@ __global__ __launch_bounds__(512, 2) void eval_kernel16q(Params P, nefii_mlp m, 
     }
 }
 
+// "16f" (mlp_tile.h, nefii_tracer_params.split_fp8): the same work lists and tile shapes as eval_kernel16q<QT, 4>, the correction
+// products on block-scaled fp8; f8_stream = the fifth copy of nefii_mlp.w_stream
+template <typename LDS>
+__device__ __forceinline__ void zero_lds_f(LDS &lds) {
+    uint32_t *p = reinterpret_cast<uint32_t *>(&lds);
+    for (int i = threadIdx.x; i < (int)(sizeof(LDS) / 4); i += blockDim.x) p[i] = 0u;
+    __syncthreads();
+}
+template <int QT>
+__global__ __launch_bounds__(512, 2) void eval_kernel16f(Params P, nefii_mlp m, int round, const void *f8_stream) {
+    NEFII_CLAIM_SIMD_2();
+    constexpr int RMAX = QGeo<4>::ROWS;
+    __shared__ LdsF lds;
+    __shared__ float raw[RMAX * 9];
+    __shared__ float *dest[RMAX];
+    __shared__ float old[RMAX];
+    const RoundWork W = round_work(P, round);
+    const int64_t total = W.total;
+    constexpr int ROWS = 16 * QT, BIG = RMAX, NCU = 256;      // (which instance takes which queries: as eval_kernel16q)
+    int64_t first = 0, n_tiles;
+    if (total <= small_round(P)) {
+        n_tiles = QT == 2 ? (total + 31) / 32 : 0;
+    } else {
+        const int64_t nbig = (total + BIG - 1) / BIG, whole = nbig / NCU * NCU, rem = nbig - whole;
+        const bool split = whole > 0 && rem > 0 && rem * (BIG / 32) <= NCU;
+        if (QT == 2) {
+            first = split ? whole * (BIG / 32) : 0;
+            n_tiles = split ? (total - whole * BIG + 31) / 32 : 0;
+        } else {
+            n_tiles = split ? whole : nbig;
+        }
+    }
+    if (blockIdx.x >= n_tiles) return;
+    zero_lds_f(lds);        // the 128-padded stream multiplies what follows a layer's own columns by zero weights: keep it finite
+    SStage<4> b[4];
+    PCursor cur;
+    prime16f(m, f8_stream, b, cur);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const bool audit = P.tau > 0.f;
+        decode_tile<ROWS>(P, first + tile, W, raw, dest, audit ? old : nullptr);
+        __syncthreads();
+        sdf_tile16f<QT>(m, lds, raw, dest, b, cur, audit ? old : nullptr, P.counters + round * NCNT + 8);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void sdf_points_kernel16f(nefii_mlp m, const float *__restrict__ x, int64_t n,
+                                                              float *__restrict__ out, const void *f8_stream) {
+    NEFII_CLAIM_SIMD_2();
+    constexpr int ROWS = QGeo<4>::ROWS, QT = ROWS / 16;
+    __shared__ LdsF lds;
+    __shared__ float raw[ROWS * 9];
+    __shared__ float *dest[ROWS];
+    const int64_t n_tiles = (n + ROWS - 1) / ROWS;
+    zero_lds_f(lds);
+    SStage<4> b[4];
+    PCursor cur;
+    prime16f(m, f8_stream, b, cur);
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tid = threadIdx.x;
+        if (tid < ROWS) {
+            const int64_t q = tile * ROWS + tid;
+            float *rw = raw + tid * 9;
+            const bool live = q < n;
+            rw[0] = live ? x[q * 3] : 0.f, rw[1] = live ? x[q * 3 + 1] : 0.f, rw[2] = live ? x[q * 3 + 2] : 0.f;
+            rw[3] = rw[4] = rw[5] = rw[6] = rw[7] = rw[8] = 0.f;
+            dest[tid] = live ? out + q : nullptr;
+        }
+        __syncthreads();
+        sdf_tile16f<QT>(m, lds, raw, dest, b, cur);
+    }
+}
+
 // the coarse evaluator (mlp_tile.h "16s") over the round's coarse list: one fp16 pass, 16 * QT queries per tile
 template <int FT, int ROWS>
 __device__ __forceinline__ void zero_lds_s(LdsS<FT, ROWS> &lds) {
@@ -2150,12 +2222,64 @@ extern "C" int nefii_trace_profile_launches(float *h_ms, int cap) {
     return n;
 }
 
-extern "C" size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf) {
-    if (!h_sdf || h_sdf->n_layers < 2 || h_sdf->n_layers > NEFII_MAX_LAYERS || !shape16p(h_sdf)) return 0;
+// bytes of the first four copies (the fifth - the "16f" evaluator's - follows them)
+static size_t stream_bytes_1to4(const nefii_mlp *h_sdf) {
     size_t units_vg = 0;
     if (vg_shape(h_sdf)) units_vg = (size_t)stream_steps(h_sdf) + vg_units_bwd(h_sdf);
     return (size_t)8 * (stream_steps(h_sdf) + stream_steps8(h_sdf) + units_vg) * 256 * sizeof(half8) +
            (size_t)8 * stream_steps_sp(h_sdf) * shape16p(h_sdf) * 64 * sizeof(half8);
+}
+// units per wave of the fifth copy (mlp_tile.h "16f": 8 per 128-deep chunk), 0 when the net does not take that evaluator
+int stream_steps_f8(const nefii_mlp *m) {
+    if (shape16p(m) != 4 || m->reserved != 1) return 0;
+    int G = 0;
+    for (int l = 0; l < m->n_layers - 1; ++l) G += 8 * f_chunks(m->layer[l]);
+    return G;
+}
+
+extern "C" size_t nefii_sdf_stream_bytes(const nefii_mlp *h_sdf) {
+    if (!h_sdf || h_sdf->n_layers < 2 || h_sdf->n_layers > NEFII_MAX_LAYERS || !shape16p(h_sdf)) return 0;
+    return stream_bytes_1to4(h_sdf) + (size_t)8 * stream_steps_f8(h_sdf) * 4096;
+}
+
+extern "C" int nefii_sdf_fp8corr_supported(const nefii_mlp *h_sdf) {
+    return h_sdf && h_sdf->w_stream && h_sdf->n_layers >= 2 && h_sdf->n_layers <= NEFII_MAX_LAYERS && stream_steps_f8(h_sdf) > 0;
+}
+
+// fifth copy.  Unit g of a wave: chunk c = (g - first unit of its layer) >> 3, j = & 7.  j < 4: the hi fragments of k-step 4 c + j
+// (as the single-pass copy).  j >= 4: feature tile ft = j - 4, 16-byte element i of the lane: part = i >> 1 (0: w_l, 1: w_h),
+// bytes 16 (i & 1) .. + 15 of the lane's 32: e4m3(W_part[n = 64 wave + 16 ft + (lane & 15)][k = 128 c + 32 (lane >> 4) + byte] x 2^E).
+__global__ void pack_sdf_stream_f8_kernel(nefii_mlp m, half8 *__restrict__ dst, int G) {
+    const int g = blockIdx.x, wave = blockIdx.y;
+    int l = 0, u = g;
+    while (u >= 8 * f_chunks(m.layer[l])) u -= 8 * f_chunks(m.layer[l]), ++l;
+    const half8 *w = reinterpret_cast<const half8 *>(m.layer[l].w_f16x3);
+    const int NT = m.layer[l].n_pad >> 5, K16 = (m.layer[l].k_x + m.layer[l].k_e) >> 4;
+    const int c = u >> 3, j = u & 7;
+    const int i = threadIdx.x >> 6, lane = threadIdx.x & 63, kg = lane >> 4;
+    half8 v;
+    for (int e = 0; e < 8; ++e) v[e] = (_Float16)0.f;
+    if (j < 4) {
+        const int s = 4 * c + j, n = 64 * wave + 16 * i + (lane & 15);
+        const int s16 = 2 * s + (kg >> 1), t = n >> 5, lane_src = (n & 31) + 32 * (kg & 1);
+        if (s16 < K16) v = w[(((size_t)s16 * NT + t) * 2) * 64 + lane_src];
+    } else {
+        const int ft = j - 4, part = i >> 1, n = 64 * wave + 16 * ft + (lane & 15), t = n >> 5;
+        const int k0 = 128 * c + 32 * kg + 16 * (i & 1), s16 = k0 >> 4;
+        const float sc = f8_scale(part == 0 ? F8_WL_E : F8_WH_E);
+        int out[4] = {0, 0, 0, 0};
+        if (s16 < K16) {
+            const half8 a = w[(((size_t)s16 * NT + t) * 2 + (part == 0 ? 1 : 0)) * 64 + (n & 31)];            // k0 .. k0 + 7
+            const half8 b = w[(((size_t)s16 * NT + t) * 2 + (part == 0 ? 1 : 0)) * 64 + (n & 31) + 32];       // k0 + 8 .. + 15
+            out[0] = f8_pack4((float)a[0] * sc, (float)a[1] * sc, (float)a[2] * sc, (float)a[3] * sc);
+            out[1] = f8_pack4((float)a[4] * sc, (float)a[5] * sc, (float)a[6] * sc, (float)a[7] * sc);
+            out[2] = f8_pack4((float)b[0] * sc, (float)b[1] * sc, (float)b[2] * sc, (float)b[3] * sc);
+            out[3] = f8_pack4((float)b[4] * sc, (float)b[5] * sc, (float)b[6] * sc, (float)b[7] * sc);
+        }
+        const i32x4 o4 = {out[0], out[1], out[2], out[3]};
+        v = __builtin_bit_cast(half8, o4);
+    }
+    dst[((size_t)wave * G + g) * 256 + threadIdx.x] = v;
 }
 
 extern "C" int nefii_sdf_coarse_supported(const nefii_mlp *h_sdf) {
@@ -2191,6 +2315,11 @@ extern "C" int nefii_pack_sdf_stream(const nefii_mlp *h_sdf, void *w_stream, voi
         hipLaunchKernelGGL(pack_sdf_stream_kernel, dim3(G, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, ft, 0);
         HIP_CHECK_LAUNCH();
         hipLaunchKernelGGL(pack_sdf_stream_bwd_kernel, dim3(Gb, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf, dst, Gw, G, ft);
+        HIP_CHECK_LAUNCH();
+    }
+    if (const int Gf = stream_steps_f8(h_sdf)) {
+        hipLaunchKernelGGL(pack_sdf_stream_f8_kernel, dim3(Gf, 8), dim3(256), 0, (hipStream_t)stream, *h_sdf,
+                           reinterpret_cast<half8 *>((char *)w_stream + stream_bytes_1to4(h_sdf)), Gf);
         HIP_CHECK_LAUNCH();
     }
     return 0;
@@ -2307,6 +2436,19 @@ extern "C" int nefii_sdf_eval_coarse(const nefii_mlp *h_sdf, const float *x, int
     return 0;
 }
 
+extern "C" int nefii_sdf_eval_fp8corr(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream) {
+    if (!h_sdf || !x || !sdf_out || n < 0) return NEFII_E_ARG;
+    if (!nefii_sdf_fp8corr_supported(h_sdf)) return NEFII_E_UNSUPPORTED;
+    for (int l = 0; l < h_sdf->n_layers; ++l)
+        if (!h_sdf->layer[l].w_f16x3) return NEFII_E_ARG;
+    if (n == 0) return 0;
+    const int64_t n_tiles = (n + 63) / 64;
+    hipLaunchKernelGGL(sdf_points_kernel16f, dim3((int)(n_tiles < 512 ? n_tiles : 512)), dim3(512), 0, (hipStream_t)stream, *h_sdf, x,
+                       n, sdf_out, (const void *)((const char *)h_sdf->w_stream + stream_bytes_1to4(h_sdf)));
+    HIP_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int nefii_sdf_eval(const nefii_mlp *h_sdf, const float *x, int64_t n, float *sdf_out, void *stream) {
     if (!h_sdf || h_sdf->n_layers < 1 || h_sdf->n_layers > NEFII_MAX_LAYERS) return NEFII_E_ARG;
     if (n <= 0) return 0;
@@ -2378,6 +2520,7 @@ struct TraceJob {
     int precision, rounds, adv_blocks, eval_blocks, eval_blocks_w;
     int pipelined;      // feature tiles per wave of the pipelined evaluator (4 / 2), 0: generic kernels
     int coarse;         // the coarse pass runs (its kernel is launched every round)
+    const void *f8;     // nefii_tracer_params.split_fp8 and the net has the fifth stream copy: the "16f" evaluator's stream, else null
     hipStream_t st;
     int32_t *counters;
 };
@@ -2424,6 +2567,9 @@ int prepare_job(TraceJob &J, const nefii_mlp *h_sdf, const nefii_tracer_params *
     // coarse pass: needs the single-pass stream (pipelined shapes, 16x16x32 layout), sample ids in 7 bits and ray ids in
     // the other 25 of a refine entry
     J.pipelined = h_params->precision == 2 ? fits16p(h_sdf) : 0;
+    if (h_params->split_fp8 < 0 || h_params->split_fp8 > 1) return NEFII_E_ARG;
+    J.f8 = (h_params->split_fp8 && J.pipelined == 4 && nefii_sdf_fp8corr_supported(h_sdf))
+               ? (const void *)((const char *)h_sdf->w_stream + stream_bytes_1to4(h_sdf)) : nullptr;
     J.coarse = h_params->coarse_tau > 0.f && J.pipelined && nefii_sdf_coarse_supported(h_sdf) &&
                n_rays < (1ll << 25) && h_params->n_steps <= 128;
     if (h_params->coarse_tau < 0.f || h_params->coarse_tau > 1.f) return NEFII_E_ARG;
@@ -2522,6 +2668,12 @@ int launch_round(const TraceJob &J, int r, bool profile) {
             const int64_t small_tiles = (J.P.n * 2 + 31) / 32 < 256 ? (J.P.n * 2 + 31) / 32 : 256;
             hipLaunchKernelGGL((eval_kernel16q<2, 2>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(512), 0, st, J.P,
                                *J.sdf, r);
+        } else if (J.precision == 2 && J.pipelined && J.sdf->reserved == 1 && J.f8) {
+            hipLaunchKernelGGL((eval_kernel16f<4>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r, J.f8);
+            HIP_CHECK_LAUNCH();
+            const int64_t small_tiles = (J.P.n * 2 + 31) / 32 < 256 ? (J.P.n * 2 + 31) / 32 : 256;
+            hipLaunchKernelGGL((eval_kernel16f<2>), dim3((int)(small_tiles < 1 ? 1 : small_tiles)), dim3(512), 0, st, J.P, *J.sdf,
+                               r, J.f8);
         } else if (J.precision == 2 && J.pipelined && J.sdf->reserved == 1) {
             hipLaunchKernelGGL((eval_kernel16q<4, 4>), dim3(J.eval_blocks_w), dim3(512), 0, st, J.P, *J.sdf, r);
             HIP_CHECK_LAUNCH();

@@ -99,6 +99,10 @@ class RayTracing(nn.Module):
         # runner's --bracket_staged_eval): bit-identical whenever L bounds the slope, config 3 -7 %, config 5 -13 %.
         self.bracket_staged_eval = os.environ.get('NEFII_BRACKET_STAGED_EVAL', '0') == '1'
         self.minsdf_lipschitz_override = None
+        # The split evaluator's two correction products on block-scaled fp8 MFMAs (nefii_tracer_params.split_fp8, ABI 15):
+        # a third arithmetic (|sdf error| ~1e-5 against the fp16 split's 5e-7) for every split-precision evaluation of the trace;
+        # like the tier a per-MODEL switch, off by default (NEFII_SPLIT_FP8=1; 512-wide nets only, ignored elsewhere).
+        self.split_fp8 = os.environ.get('NEFII_SPLIT_FP8', '0') == '1'
         self.retraced_calls = 0       # synchronous traces repeated because their online audit found a bound violated (forward)
 
     @staticmethod
@@ -247,7 +251,7 @@ class RayTracing(nn.Module):
                                             small_round=self.small_round_for(n_rays, self.concurrent),
                                             trace_tier=self.tier_for(), tier_kappa=self.tier_kappa,
                                             tier_gate=self.tier_gate, minsdf_lipschitz=lip,
-                                            unread_misses=0 if self.miss_search else 1)
+                                            unread_misses=0 if self.miss_search else 1, split_fp8=self.split_fp8)
             res = ops.trace_rays(net.packed(f16x3=self.precision.startswith('f16x3')), params, origins, dirs,
                                  object_mask.reshape(-1), self._lin, steps, want_counters=self.collect_counters,
                                  rounds_state=state,

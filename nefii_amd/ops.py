@@ -438,17 +438,24 @@ def sdf_value_grad(pm, x, want_feat=False):
     return out, feat, grad
 
 
-def sdf_eval(pm, x, coarse=False):
+def sdf_eval(pm, x, coarse=False, fp8=False):
     """implicit_network(x)[:, 0] with the tracer's split-precision tile evaluator (needs PackedMLP(f16x3=True));
-    coarse=True: with its single-pass (one fp16 MFMA per product) evaluator instead."""
+    coarse=True: with its single-pass (one fp16 MFMA per product) evaluator instead; fp8=True: with the "16f" evaluator
+    (correction products on block-scaled fp8, nefii_tracer_params.split_fp8)."""
     lib = _lib.lib()
     x = x.contiguous()
     n = x.shape[0]
     out = torch.empty(n, device=x.device, dtype=torch.float32)
     if n > 0:
         fn, name = (lib.nefii_sdf_eval_coarse, 'nefii_sdf_eval_coarse') if coarse else (lib.nefii_sdf_eval, 'nefii_sdf_eval')
+        if fp8:
+            fn, name = lib.nefii_sdf_eval_fp8corr, 'nefii_sdf_eval_fp8corr'
         _lib.check(fn(ctypes.byref(pm.struct), _ptr(x), n, _ptr(out), _stream()), name)
     return out
+
+
+def fp8corr_supported(pm):
+    return bool(pm.f16x3 and pm.w_stream is not None and _lib.lib().nefii_sdf_fp8corr_supported(ctypes.byref(pm.struct)))
 
 
 def coarse_supported(pm):
@@ -526,8 +533,10 @@ PRECISIONS = {'f32': 0, 'f16x3': 1, 'f16x3w': 2}
 
 
 def make_tracer_params(cfg, training, precision='f32', bisect_levels=3, coarse_tau=0.0, coarse_cap=0, minsdf_group=0,
-                       small_round=0, trace_tier=0, tier_kappa=0.0, tier_gate=0.0, minsdf_lipschitz=0.0, unread_misses=0):
+                       small_round=0, trace_tier=0, tier_kappa=0.0, tier_gate=0.0, minsdf_lipschitz=0.0, unread_misses=0,
+                       split_fp8=0):
     p = TracerParams()
+    p.split_fp8 = 1 if split_fp8 else 0
     p.unread_misses = 1 if unread_misses else 0
     p.minsdf_lipschitz = float(minsdf_lipschitz) if coarse_tau > 0.0 else 0.0
     p.trace_tier = 1 if (trace_tier and coarse_tau > 0.0) else 0

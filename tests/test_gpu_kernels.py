@@ -1117,6 +1117,99 @@ def test_tracer_staged_bracket_search_adversarial_bumps():
     assert audited > 0 and probes > 0, (audited, probes)
 
 
+@pytest.mark.parametrize('case', ['conf512-trained', 'conf512-frame', 'conf512-bowl', 'physg512-smooth', 'physg512-bumpy'])
+def test_sdf_eval_fp8corr_vs_fp64(case):
+    """nefii_sdf_eval_fp8corr (ABI 15, mlp_tile.h "16f": the split evaluator with its correction products on block-scaled fp8
+    MFMAs) against the fp64 oracle, beside the fp16 split evaluator on the same points: a THIRD arithmetic between the split
+    (5e-7) and the single-pass (tau ~ 1e-3) ones - max |error| bounded at 4e-5 over the bounding sphere and 6e-6 within 0.02 of
+    the surface (measured ~1e-5 / ~2e-6; the CPU emulation tools/experiments/arith_emulation.py `fp8corr_fix` predicted 1.0e-5 /
+    1.6e-6), ragged sizes included; and the net shapes without the fifth stream copy refuse loudly."""
+    import ctypes
+    from nefii_amd import _lib
+    name, geo = case.split('-')
+    mc = syn.model_conf({'physg512': 'physg', 'conf512': 'conf'}[name])
+    sd = syn.make_state_dict(mc, seed=2, bumpy={'bumpy': 0.004}.get(geo, 0.0),
+                             scene={'bowl': 'bowl_dense', 'trained': 'bowl_trained', 'frame': 'frame_trained'}.get(geo))
+    pm = build_sdf(mc, sd, f16x3=True)
+    assert ops.fp8corr_supported(pm)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    for n in (1, 63, 64, 65, 4097, 20000):
+        x = ball_points(n, 5 + n)
+        ref = nets.sdf_forward(sd64, mc['implicit_network'], x.double())[:, 0]
+        xd = x.to(DEV)
+        f8 = ops.sdf_eval(pm, xd, fp8=True).cpu().double()
+        sp = ops.sdf_eval(pm, xd).cpu().double()
+        e8, es = (f8 - ref).abs(), (sp - ref).abs()
+        near = ref.abs() < 0.02
+        if n == 20000:
+            print('[fp8corr %s] max |err| vs fp64: fp8 corrections %.2e (near the surface %.2e, rms %.2e), fp16 split %.2e' % (
+                case, e8.max(), e8[near].max() if near.any() else 0.0, e8.pow(2).mean().sqrt(), es.max()))
+            assert e8.max().item() > es.max().item()            # it IS another arithmetic (the kernel that ran is the fp8 one)
+        assert torch.isfinite(f8).all()
+        assert e8.max().item() < 4e-5, (case, n, e8.max().item())
+        if near.any():
+            assert e8[near].max().item() < 6e-6, (case, n, e8[near].max().item())
+    # a 256-wide net (conf_neus.conf) has no fifth copy: the entry point refuses, the tracer parameter is ignored
+    mcn = syn.model_conf('neus')
+    pmn = build_sdf(mcn, syn.make_state_dict(mcn, seed=2), f16x3=True)
+    assert not ops.fp8corr_supported(pmn)
+    out = torch.empty(64, device=DEV)
+    x64 = ball_points(64, 3).to(DEV)
+    rc = _lib.lib().nefii_sdf_eval_fp8corr(ctypes.byref(pmn.struct), x64.data_ptr(), 64, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == -3, rc        # NEFII_E_UNSUPPORTED
+
+
+@pytest.mark.parametrize('case', ['conf512-trained', 'conf512-frame', 'physg512-bumpy'])
+def test_tracer_split_fp8_against_the_fp16_split(case):
+    """nefii_tracer_params.split_fp8: every split-precision evaluation of a trace on the "16f" evaluator.  Against the same trace
+    on the fp16 split evaluator (training and eval mode, coarse pass + staged searches + tier on, primary and secondary-like
+    rays): no hit-mask flip beyond the knife-edge allowance, depths of rays that hit both ways within 1e-4 (median < 2e-6), the
+    same evaluation counts within 1 %, the coarse audit inside its bound; and against the oracle's trace through compare_trace's
+    own bounds."""
+    name, geo = case.split('-')
+    mc = syn.model_conf({'physg512': 'physg', 'conf512': 'conf'}[name])
+    sd = syn.make_state_dict(mc, seed=2, bumpy={'bumpy': 0.004}.get(geo, 0.0),
+                             scene={'trained': 'bowl_trained', 'frame': 'frame_trained'}.get(geo))
+    pm = build_sdf(mc, sd, f16x3=True)
+    pm32 = build_sdf(mc, sd)
+    tau = ops.calibrate_coarse_tau(pm)
+    lip = ops.calibrate_lipschitz(lambda x: ops.sdf_value_grad(pm32, x)[2], DEV)
+    o, d, om, steps = _trace_batch(6000, 51, spread=0.6 if geo in ('trained', 'frame') else 0.45)
+    sdf = lambda x: nets.sdf_forward(sd, mc['implicit_network'], x)[:, 0]
+    for training in (True, False):
+        kw = dict(coarse_tau=tau, pm=pm, trace_tier=1, minsdf_lipschitz=lip)
+        a = run_gpu_trace(mc, sd, o, d, om, training, steps, 'f16x3w', **kw)
+        b = run_gpu_trace(mc, sd, o, d, om, training, steps, 'f16x3w', split_fp8=1, **kw)
+        ha, hb = a[1].bool(), b[1].bool()
+        flips = int((ha != hb).sum())
+        both = ha & hb
+        dd = (a[2] - b[2]).abs()[both]
+        ca, cb = a[3].cpu().long(), b[3].cpu().long()
+        ea, eb = ops.algorithmic_evals(ca, 100).sum().item(), ops.algorithmic_evals(cb, 100).sum().item()
+        aud = float(cb[:, 8].to(torch.int32).contiguous().view(torch.float32).max())
+        print('[split_fp8 %s %s] %d rays: hit-mask flips %d, |d depth| of rays hit both ways max %.2e median %.2e (> 1e-5: %.4f), '
+              'algorithmic evaluations %d / %d, coarse audit %.2e (tau %.2e)' % (
+                  case, 'train' if training else 'eval', ha.numel(), flips, dd.max().item() if dd.numel() else 0.0,
+                  dd.median().item() if dd.numel() else 0.0, (dd > 1e-5).float().mean().item() if dd.numel() else 0.0, ea, eb, aud, tau))
+        # the tier's class of effect (DESIGN 4f / 4g): values move at the 1e-5 level, so a percent of the rays end a few 1e-5 away and a
+        # handful of knife-edge rays take another path to a neighbouring crossing (measured: 0.7-4 % beyond 1e-5, max 4e-3)
+        assert flips <= 2, flips
+        assert dd.median().item() < 3e-6 and (dd > 1e-5).float().mean().item() < 0.06 and (dd > 1e-3).float().mean().item() < 2e-3
+        assert dd.max().item() < 2e-2
+        assert abs(ea - eb) <= 0.01 * ea
+        assert aud < tau
+        assert not torch.equal(a[2], b[2])          # the parameter is honoured: another arithmetic ran
+        if not training:
+            ref = tracer.trace(sdf, o, d, om, mc['ray_tracer'], False)
+            rh = ref['hit']
+            flips_o = int((hb.cpu() != rh).sum())
+            eo = (b[2].cpu() - ref['dists']).abs()[hb.cpu() & rh]
+            print('[split_fp8 %s eval vs oracle] hit-mask flips %d, |d depth| median %.2e, within 1e-5: %.4f, max %.2e' % (
+                case, flips_o, eo.median().item(), (eo < 1e-5).float().mean().item(), eo.max().item()))
+            assert flips_o <= max(1, int(0.004 * rh.numel()))
+            assert eo.median().item() < 3e-6 and (eo < 1e-5).float().mean().item() > 0.93
+
+
 def test_pack_mlp_equals_the_per_layer_packers():
     """nefii_pack_mlp (every layer and every fragment form in ONE launch: what PackedMLP.pack runs) against the per-layer
     entry points the header still exports - nefii_pack_linear (f32 fragments, transpose, padded bias), nefii_pack_linear_f16x3

@@ -32,7 +32,7 @@ def test_struct_layout_matches_header():
     # nefii_layer: 4 x int32 + 4 pointers; nefii_mlp: 8 x int32 + 12 layers
     assert ctypes.sizeof(_lib.Layer) == 16 + 5 * 8
     assert ctypes.sizeof(_lib.Mlp) == 40 + 12 * ctypes.sizeof(_lib.Layer)
-    assert ctypes.sizeof(_lib.TracerParams) == 76         # 3 floats + 7 int32 + coarse_tau + coarse_cap + minsdf_group + small_round + trace_tier + tier_kappa + tier_gate + minsdf_lipschitz + unread_misses
+    assert ctypes.sizeof(_lib.TracerParams) == 80         # 3 floats + 7 int32 + coarse_tau + coarse_cap + minsdf_group + small_round + trace_tier + tier_kappa + tier_gate + minsdf_lipschitz + unread_misses + split_fp8
     assert ctypes.sizeof(_lib.RowBlock) == 32             # 2 pointers + cols + src_row_stride + fill + reserved
     assert ctypes.sizeof(_lib.PackSource) == 48           # 2 pointers + 6 int32 + scale + skip_f32
 
@@ -96,7 +96,10 @@ def test_sdf_stream_size():
                                        # + the single-pass (coarse) copy: hi fragments only, one 32-deep k-step of the
                                        # wave's 4 (2) feature tiles per 4 KiB (2 KiB) unit, K padded to 128
                                        ('physg', 512, 1, 8 * ((4 + 32 * 3 + 36 + 32 * 3) + (8 + 32 * 3 + 40 + 32 * 3)) * 4096
-                                        + 8 * (4 + 16 * 3 + 20 + 16 * 3) * 4096),
+                                        + 8 * (4 + 16 * 3 + 20 + 16 * 3) * 4096
+                                        # + the fifth copy (ABI 15, the "16f" evaluator: correction products on block-scaled fp8):
+                                        # eight 4-KiB units per 128-deep chunk of every layer's 128-padded K
+                                        + 8 * 8 * (1 + 4 * 3 + 5 + 4 * 3) * 4096),
                                        ('physg', 64, 1, 0),
                                        ('neus', None, 0, 0),
                                        ('neus', None, 1, 8 * (4 + 8 * 3 + 12 + 8 * 3) * 4096 + 8 * (4 + 8 * 3 + 12 + 8 * 3) * 2048)]:

@@ -28,7 +28,7 @@ def main():
     dev = torch.device('cuda', 0)
     torch.set_num_threads(16)
     rows = []
-    fp8 = os.environ.get('NEFII_BUDGET_FP8', '0') == '1'
+    fp8 = os.environ.get('NEFII_BUDGET_FP8', '1') == '1'
     variants = [('f32', dict(mlp='f32', tracer='f32', tier=False)), ('+split', dict(mlp='f32', tracer='f16x3w', tier=False)),
                 ('+fp16mlp', dict(mlp='f16x3', tracer='f16x3w', tier=False)), ('+tier', dict(mlp='f16x3', tracer='f16x3w', tier=True))]
     if fp8:
