@@ -174,7 +174,8 @@ def parity_of(workload, ref, device, tier, tweak=None):
         m.ray_tracer.minsdf_steps_override = over
     if ref['uniforms'] is not None:
         m.uniforms_override = ref['uniforms']
-    m.ray_tracer.trace_tier = bool(tier)      # the arithmetic the timed steps run (a per-run switch)
+    m.ray_tracer.trace_tier = bool(tier)      # the arithmetic the timed steps run (per-run switches)
+    m.ray_tracer.split_fp8 = bench_fp8()
     if tweak is not None:
         tweak(m)
     with torch.no_grad():
@@ -216,6 +217,7 @@ def parity_of(workload, ref, device, tier, tweak=None):
     parity['sample'] = 'the first %d pixels of the workload (%d primary rays), forward only, the oracle\'s draws replayed' % (
         pp, pp * R_)
     parity['trace_tier'] = bool(m.ray_tracer.trace_tier)
+    parity['split_fp8'] = bool(m.ray_tracer.split_fp8)
     return parity
 
 
@@ -225,8 +227,14 @@ def bench_tier():
     return os.environ.get('NEFII_TRACE_TIER', '1') != '0'
 
 
+def bench_fp8():
+    """The split evaluator's correction products on block-scaled fp8 (RayTracing.split_fp8): like the tier a per-run switch,
+    off by default in the library, ON in the benchmark unless NEFII_SPLIT_FP8=0 (512-wide SDF nets; ignored by the others)."""
+    return os.environ.get('NEFII_SPLIT_FP8', '1') != '0'
+
+
 def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side=True, scaling=None, sustained=None,
-                 power=False, tier=None):
+                 power=False, tier=None, fp8=None):
     """Time `steps` training steps of WORKLOADS[name] (every rank), then measure the roofline terms in un-timed extra
     steps.  Returns the result dict on rank 0, None elsewhere."""
     import ctypes
@@ -251,6 +259,7 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     model.freeze_geometry()
     model.train()
     model.ray_tracer.trace_tier = bench_tier() if tier is None else bool(tier)
+    model.ray_tracer.split_fp8 = bench_fp8() if fp8 is None else bool(fp8)
     # weak scaling (default): global batch = num_pixels * world; --scaling strong: the config's own global batch (config 4:
     # 8192 pixels) - either way the contiguous per-rank slice of the global patch list (scene_dataset.py:268-279)
     strong = (scaling or getattr(args, 'scaling', 'weak')) == 'strong'
@@ -530,7 +539,10 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
         # without the search and one with it, both measured here
         'ms_per_step_min_sdf_on_reporting_iterations': None if ms_skip is None else (49.0 * ms_skip + ms_per_step) / 50.0,
         'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-        'dtype': 'f16x3' if split else 'f32', 'data': 'synthetic',
+        # arithmetic of the dominant kernels: f16x3 = split precision on three fp16 MFMAs per product; f16+fp8x2 = its two correction
+        # products on block-scaled fp8 MFMAs (RayTracing.split_fp8 on a 512-wide net); the single-pass evaluator is f16 in both
+        'dtype': ('f16+fp8x2' if (model.ray_tracer.split_fp8 and model.implicit_network.specs[0].n_out == 512) else 'f16x3') if split else 'f32',
+        'data': 'synthetic',
         'config': {'workload': '%s: %s, %s model, num_pixels=%d per GPU%s, 128 SG lobes, %s, frozen geometry, '
                                'fwd+IDRLoss+bwd+2xAdam'
                                % (name + (' (strong scaling: global batch split over the ranks)' if strong else ''),
@@ -590,6 +602,7 @@ def run_render(name, args, frames, rank, world, dev, backend):
     model = model.to(dev).eval()
     model.freeze_geometry()
     model.ray_tracer.trace_tier = bench_tier()
+    model.ray_tracer.split_fp8 = bench_fp8()
     H, W = w['image_hw']
     rows = min(H, args.frame_rows) if args.frame_rows > 0 else H
     row0 = (H - rows) // 2              # a band through the middle of the frame (through the object)
@@ -621,12 +634,13 @@ def run_render(name, args, frames, rank, world, dev, backend):
     level = w['memory_capacity_level'] - int(math.floor(math.log2(world)))
     return {'metric': 'render rays/sec (full-frame novel-view render, eval mode)', 'value': rays * frames / elapsed,
             'unit': 'rays/s', 'n_gpus': world, 'steps': frames, 'warmup': 0, 'ms_per_step': elapsed / frames * 1e3,
-            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f16x3', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f16+fp8x2' if model.ray_tracer.split_fp8 else 'f16x3', 'data': 'synthetic',
             'config': {'workload': '%s: conf.conf model at full width on the non-convex stand-in, %d x %d pixels x %d rays per '
                                    'pixel, chunks of %d pixels dealt round-robin over %d rank(s) and gathered on rank 0'
                                    % (name, rows, W, w['num_rays'], (1 << level) // w['num_rays'], world),
                        'primary_rays_per_frame': rays, 'trace_tier': bool(model.ray_tracer.tier_for()),
-                       'bracket_staged_eval': bool(model.ray_tracer.bracket_staged_eval),
+                       'bracket_staged_eval': bool(model.ray_tracer.bracket_staged_eval), 'split_fp8': bool(model.ray_tracer.split_fp8),
                        # (a band through the object is dearer per pixel than the frame's average: no extrapolation from it)
                        'seconds_per_800x800_frame': elapsed / frames if rows == H else None,
                        'hit_pixel_fraction': out['network_object_mask'].float().mean().item(),
@@ -790,9 +804,9 @@ def compact_line(full):
                          'trace_tier': pa.get('trace_tier')}
     out['ms_per_step_without_dead_min_sdf_search'] = _r(full.get('ms_per_step_without_dead_min_sdf_search'), 5)
     if full.get('untiered'):
-        out['ms_per_step_untiered'] = _r(full['untiered'].get('ms_per_step'), 5)
-    if full.get('split_fp8'):
-        out['ms_per_step_split_fp8'] = _r(full['split_fp8'].get('ms_per_step'), 5)
+        out['ms_per_step_library_defaults'] = _r(full['untiered'].get('ms_per_step'), 5)
+    if full.get('no_split_fp8'):
+        out['ms_per_step_no_split_fp8'] = _r(full['no_split_fp8'].get('ms_per_step'), 5)
     if full.get('staged_eval_bracket'):
         out['ms_per_step_staged_eval_bracket'] = _r(full['staged_eval_bracket'].get('ms_per_step'), 5)
     others = {}
@@ -917,18 +931,14 @@ def main():
         # BASELINE's 8-GPU training config as it is defined: the global 8192-pixel batch split over the ranks
         nested['cfg4'] = run_workload('cfg4', args, max(1, min(args.steps, 10)), min(args.warmup, 2), rank, world, dev, backend,
                                       lib, side=False, scaling='strong' if world > 1 else 'weak', sustained=sustained)
-        if world == 1 and headline == 'cfg3' and bench_tier():
-            # the same workload on the library's default arithmetic (no tier), for the like-for-like figure
+        if world == 1 and headline == 'cfg3' and (bench_tier() or bench_fp8()):
+            # the same workload on the LIBRARY's default arithmetic (no tier, fp16 split evaluator: every value the split evaluator's)
             nested['cfg3_untiered'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
-                                                   dev, backend, lib, side=False, sustained=sustained, tier=False)
-        if world == 1 and headline == 'cfg3' and os.environ.get('NEFII_SPLIT_FP8', '0') != '1':
-            # ... with the split evaluator's correction products on block-scaled fp8 (RayTracing.split_fp8, opt-in)
-            os.environ['NEFII_SPLIT_FP8'] = '1'
-            try:
-                nested['cfg3_split_fp8'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
-                                                        dev, backend, lib, side=False, sustained=sustained)
-            finally:
-                os.environ.pop('NEFII_SPLIT_FP8', None)
+                                                   dev, backend, lib, side=False, sustained=sustained, tier=False, fp8=False)
+        if world == 1 and headline == 'cfg3' and bench_fp8():
+            # ... without the fp8 correction products (RayTracing.split_fp8 off: the fp16 split evaluator of rounds 2-5), tier as the headline
+            nested['cfg3_no_fp8'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
+                                                 dev, backend, lib, side=False, sustained=sustained, fp8=False)
         if world == 1 and headline == 'cfg3' and os.environ.get('NEFII_BRACKET_STAGED_EVAL', '0') != '1':
             # ... and with the opt-in staging of the secondary traces' bracket search (NEFII_BRACKET_STAGED_EVAL=1)
             os.environ['NEFII_BRACKET_STAGED_EVAL'] = '1'
@@ -1020,14 +1030,14 @@ def main():
         cancelled = result['config']['nonfinite_steps'] + sum(
             x['config']['nonfinite_steps'] for k, x in nested.items() if x and k != 'cfg5')
         result['invalid'] = cancelled > 0
-        f8 = nested.get('cfg3_split_fp8')
+        f8 = nested.get('cfg3_no_fp8')
         if f8 is not None:
-            result['split_fp8'] = {'ms_per_step': f8['ms_per_step'], 'ms_per_step_repeats': f8['ms_per_step_repeats'],
-                                   'value': f8['value'], 'frac': f8['roofline']['frac'],
-                                   'kernel_ms_per_step': f8['roofline']['kernel_ms_per_step'],
-                                   'nonfinite_steps': f8['config']['nonfinite_steps'],
-                                   'note': 'the same workload with RayTracing.split_fp8 on (opt-in: the split evaluator\'s two correction '
-                                           'products on v_mfma_scale_f32_16x16x128_f8f6f4; a third arithmetic, |sdf error| ~1e-5)'}
+            result['no_split_fp8'] = {'ms_per_step': f8['ms_per_step'], 'ms_per_step_repeats': f8['ms_per_step_repeats'],
+                                      'value': f8['value'], 'frac': f8['roofline']['frac'],
+                                      'kernel_ms_per_step': f8['roofline']['kernel_ms_per_step'],
+                                      'nonfinite_steps': f8['config']['nonfinite_steps'],
+                                      'note': 'the same workload with RayTracing.split_fp8 off: the fp16 split evaluator (3 fp16 MFMAs per '
+                                              'product) of rounds 2-5, tier as in the headline'}
         se = nested.get('cfg3_staged_eval')
         if se is not None:
             result['staged_eval_bracket'] = {'ms_per_step': se['ms_per_step'], 'ms_per_step_repeats': se['ms_per_step_repeats'],
@@ -1042,8 +1052,8 @@ def main():
                                   'value': unt['value'], 'frac': unt['roofline']['frac'],
                                   'kernel_ms_per_step': unt['roofline']['kernel_ms_per_step'],
                                   'nonfinite_steps': unt['config']['nonfinite_steps'],
-                                  'note': 'the same workload with RayTracing.trace_tier off (the library default): every sphere-'
-                                          'tracing value is the split evaluator\'s'}
+                                  'note': 'the same workload on the LIBRARY defaults: RayTracing.trace_tier off and split_fp8 off - every '
+                                          'sphere-tracing value is the fp16 split evaluator\'s'}
         if cancelled:
             result['invalid_reason'] = '%d training step(s) produced a non-finite loss or gradient and were cancelled' % cancelled
         write_full(result, args.full_out)

@@ -78,7 +78,7 @@ def test_compact_line_of_a_canned_full_record():
     back = _check(bench.compact_line(full), full)
     # frac is what the kernels executed; the credited (reference-count) figure rides beside it under its own name
     assert back['roofline']['frac'] == pytest.approx(0.2791, rel=1e-3) and back['roofline']['frac_credited'] == pytest.approx(0.5059)
-    assert back['config']['trace_tier'] is True and back['ms_per_step_untiered'] == pytest.approx(169.1)
+    assert back['config']['trace_tier'] is True and back['ms_per_step_library_defaults'] == pytest.approx(169.1)
     assert back['parity']['flips'] == 0 and back['others']['cfg4_ms_per_step'] == pytest.approx(2.4)
 
 

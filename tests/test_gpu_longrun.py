@@ -187,9 +187,9 @@ def test_config2_trains_like_the_oracle_for_250_steps():
 
 
 def test_config3_shrunk_trains_like_the_oracle():
-    """Run twice on the HIP side against ONE oracle run (the oracle's 40 steps are the test's four minutes): untiered, and with
-    RayTracing.trace_tier forced on - the tiered sphere tracing on the TRAINED stand-in (what bench.py times), held to the
-    untiered bounds.  The MC configuration (conf.conf model at full width, MC direct + indirect, secondary rays traced every step) shrunk to
+    """Run three times on the HIP side against ONE oracle run (the oracle's 40 steps are the test's four minutes): untiered, with
+    RayTracing.trace_tier forced on - the tiered sphere tracing on the TRAINED stand-in -, and with RayTracing.split_fp8 on top (what
+    bench.py times), all held to the untiered bounds.  The MC configuration (conf.conf model at full width, MC direct + indirect, secondary rays traced every step) shrunk to
     8 pixels x 32 rays, 40 steps with the sampler's draws injected on both sides: the loss curves stay together.  (Loose by
     nature: as roughness trains, GGX-sampled directions move and grazing secondary hits flip on one side first - a discrete
     event on one of ~130 hit rays moves the loss by most of a percent; the per-step gradients are held to 3e-3 in
@@ -233,7 +233,7 @@ def test_config3_shrunk_trains_like_the_oracle():
         ref_curve.append(lo['sg_rgb_loss'].item())
     assert out['_ray_hit'].float().mean().item() > 0.3, 'the shrunk batch should look at the object'
     # ---- HIP path
-    for tier in (False, True):
+    for tier, fp8 in ((False, False), (True, False), (True, True)):
         m = IDRNetwork(conf.from_dict(mc))
         m.load_state_dict(sd, strict=True)
         m = m.to(DEV)
@@ -241,6 +241,7 @@ def test_config3_shrunk_trains_like_the_oracle():
         m.train()
         m.secondary_miss_search = True
         m.ray_tracer.trace_tier = bool(tier)
+        m.ray_tracer.split_fp8 = bool(fp8)           # (round 6: the split evaluator's correction products on block-scaled fp8)
         m.ray_tracer.collect_counters = True
         loss = IDRLoss(**lc)
         prm = [p for p in m.parameters() if p.requires_grad]
@@ -263,7 +264,7 @@ def test_config3_shrunk_trains_like_the_oracle():
         assert (int(m.ray_tracer.counter_sum[:, 9].sum().item()) > 0) == bool(tier)        # the tier ran exactly when asked for
         worst = max(abs(a - b) / max(abs(b), 1e-6) for a, b in zip(curve, ref_curve))
         print('[longrun cfg3 shrunk%s] %d steps: sg_rgb loss %.4f -> %.4f (oracle) / %.4f (gpu), worst relative difference %.2e'
-              % (', tier' if tier else '', STEPS, ref_curve[0], ref_curve[-1], curve[-1], worst))
+              % ((', tier' if tier else '') + (' + fp8 corrections' if fp8 else ''), STEPS, ref_curve[0], ref_curve[-1], curve[-1], worst))
         assert ref_curve[-1] < ref_curve[0]
         assert worst < 5e-2, worst
         assert abs(curve[-1] - ref_curve[-1]) < 3e-2 * ref_curve[-1]
