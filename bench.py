@@ -229,8 +229,9 @@ def bench_tier():
 
 def bench_fp8():
     """The split evaluator's correction products on block-scaled fp8 (RayTracing.split_fp8): like the tier a per-run switch,
-    off by default in the library, ON in the benchmark unless NEFII_SPLIT_FP8=0 (512-wide SDF nets; ignored by the others)."""
-    return os.environ.get('NEFII_SPLIT_FP8', '1') != '0'
+    off by default in the library - and in the benchmark (NEFII_SPLIT_FP8=1 turns it on): on config 2 it takes the parity figure to
+    6.4e-4, past the 5e-4 line of the error budget.  The headline's line carries its figure as ms_per_step_split_fp8."""
+    return os.environ.get('NEFII_SPLIT_FP8', '0') == '1'
 
 
 def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side=True, scaling=None, sustained=None,
@@ -412,6 +413,8 @@ def run_workload(name, args, steps, warmup, rank, world, dev, backend, lib, side
     if prec == 'f16x3w' and pm.w_stream is not None:
         # 512- / 256-wide nets: the pipelined stream kernels (mlp_tile.h "16q": 16x16x32 MFMA; "16p": 32x32x16)
         kname = 'eval_kernel16q' if pm.struct.reserved == 1 else 'eval_kernel16p'
+        if model.ray_tracer.split_fp8 and ops.fp8corr_supported(pm):
+            kname = 'eval_kernel16f'        # (mlp_tile.h "16f": correction products on block-scaled fp8)
         if model.ray_tracer.coarse:
             coarse_tau = model.implicit_network.coarse_tau(model.ray_tracer.object_bounding_sphere)
             if coarse_tau > 0:
@@ -805,8 +808,8 @@ def compact_line(full):
     out['ms_per_step_without_dead_min_sdf_search'] = _r(full.get('ms_per_step_without_dead_min_sdf_search'), 5)
     if full.get('untiered'):
         out['ms_per_step_library_defaults'] = _r(full['untiered'].get('ms_per_step'), 5)
-    if full.get('no_split_fp8'):
-        out['ms_per_step_no_split_fp8'] = _r(full['no_split_fp8'].get('ms_per_step'), 5)
+    if full.get('split_fp8'):
+        out['ms_per_step_split_fp8'] = _r(full['split_fp8'].get('ms_per_step'), 5)
     if full.get('staged_eval_bracket'):
         out['ms_per_step_staged_eval_bracket'] = _r(full['staged_eval_bracket'].get('ms_per_step'), 5)
     others = {}
@@ -935,10 +938,10 @@ def main():
             # the same workload on the LIBRARY's default arithmetic (no tier, fp16 split evaluator: every value the split evaluator's)
             nested['cfg3_untiered'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
                                                    dev, backend, lib, side=False, sustained=sustained, tier=False, fp8=False)
-        if world == 1 and headline == 'cfg3' and bench_fp8():
-            # ... without the fp8 correction products (RayTracing.split_fp8 off: the fp16 split evaluator of rounds 2-5), tier as the headline
-            nested['cfg3_no_fp8'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
-                                                 dev, backend, lib, side=False, sustained=sustained, fp8=False)
+        if world == 1 and headline == 'cfg3' and not bench_fp8():
+            # ... with the split evaluator's correction products on block-scaled fp8 (RayTracing.split_fp8, opt-in: DESIGN 4g)
+            nested['cfg3_split_fp8'] = run_workload('cfg3', args, max(1, min(args.steps, 10)), min(args.warmup, 3), rank, world,
+                                                    dev, backend, lib, side=False, sustained=sustained, fp8=True)
         if world == 1 and headline == 'cfg3' and os.environ.get('NEFII_BRACKET_STAGED_EVAL', '0') != '1':
             # ... and with the opt-in staging of the secondary traces' bracket search (NEFII_BRACKET_STAGED_EVAL=1)
             os.environ['NEFII_BRACKET_STAGED_EVAL'] = '1'
@@ -1030,14 +1033,14 @@ def main():
         cancelled = result['config']['nonfinite_steps'] + sum(
             x['config']['nonfinite_steps'] for k, x in nested.items() if x and k != 'cfg5')
         result['invalid'] = cancelled > 0
-        f8 = nested.get('cfg3_no_fp8')
+        f8 = nested.get('cfg3_split_fp8')
         if f8 is not None:
-            result['no_split_fp8'] = {'ms_per_step': f8['ms_per_step'], 'ms_per_step_repeats': f8['ms_per_step_repeats'],
-                                      'value': f8['value'], 'frac': f8['roofline']['frac'],
-                                      'kernel_ms_per_step': f8['roofline']['kernel_ms_per_step'],
-                                      'nonfinite_steps': f8['config']['nonfinite_steps'],
-                                      'note': 'the same workload with RayTracing.split_fp8 off: the fp16 split evaluator (3 fp16 MFMAs per '
-                                              'product) of rounds 2-5, tier as in the headline'}
+            result['split_fp8'] = {'ms_per_step': f8['ms_per_step'], 'ms_per_step_repeats': f8['ms_per_step_repeats'],
+                                   'value': f8['value'], 'frac': f8['roofline']['frac'],
+                                   'kernel_ms_per_step': f8['roofline']['kernel_ms_per_step'],
+                                   'nonfinite_steps': f8['config']['nonfinite_steps'],
+                                   'note': 'the same workload with RayTracing.split_fp8 on (opt-in: the split evaluator\'s two correction '
+                                           'products on v_mfma_scale_f32_16x16x128_f8f6f4; a third arithmetic, |sdf error| ~1e-5)'}
         se = nested.get('cfg3_staged_eval')
         if se is not None:
             result['staged_eval_bracket'] = {'ms_per_step': se['ms_per_step'], 'ms_per_step_repeats': se['ms_per_step_repeats'],

@@ -33,7 +33,7 @@ def main():
                 ('+fp16mlp', dict(mlp='f16x3', tracer='f16x3w', tier=False)), ('+tier', dict(mlp='f16x3', tracer='f16x3w', tier=True))]
     if fp8:
         variants.append(('+fp8corr', dict(mlp='f16x3', tracer='f16x3w', tier=True, fp8=True)))
-    for wl, pp in (('cfg3', 128), ('cfg4', 128), ('cfg5', 64)):
+    for wl, pp in (('cfg2', 512), ('cfg3', 128), ('cfg4', 128), ('cfg5', 64)):
         ref = bench.oracle_reference(wl, pp)
         for name, v in variants:
             os.environ['NEFII_MLP_PRECISION'] = v['mlp']
