@@ -205,6 +205,37 @@ def test_config_shrunk_in_pixels_vs_oracle(wl):
             want = want[:, 0] if k == 'normal_values' else want.mean(1)
             assert rel_l2(multi[k], want) < 1e-5, k
         assert torch.equal(multi['network_object_mask'], out['network_object_mask'].reshape(S, R).all(1))
+    # ---- '-tier' / '-fp8': where does the looser gradient bound come from?  ("justified or tightened")
+    # The same forward + loss + backward on both sides with the rays that drew ANOTHER Monte-Carlo sample (a neighbouring lobe of
+    # the SG mixture, a secondary ray hitting on one side only: mc_flagged_rays) taken out of the colour terms on BOTH sides: what
+    # is left is the arithmetic's own effect on the gradients - moved hit points - and it has to meet the UNTIERED bound.  The
+    # rest of the looser bound is those 20-30 rays being other samples of the integrand, not an error of it.
+    if tier and mc_shading:
+        flagged, n_dir, n_vis = mc_flagged_rays(out, ref, m.last_ray_hit, ref['_ray_hit'])
+        keep = ~flagged
+        for p_ in m.parameters():
+            p_.grad = None
+        for v in sdo.values():
+            v.grad = None
+        m.ray_tracer._calls = 0
+        out2 = gpu_forward_with_per_ray_draws(m, to_dev(flat), uniforms)
+        ref2 = Ro.forward(flat, steps1, uniforms, steps2)
+        out2['object_mask'] = out2['object_mask'] & keep.to(DEV)
+        ref2['object_mask'] = ref2['object_mask'] & keep
+        IDRLoss(**lc)(out2, {'rgb': gt_flat.to(DEV)})['loss'].backward()
+        orr.idr_loss(ref2, gt_flat, lc)['loss'].backward()
+        worst_same, worst_name = 0.0, None
+        for name, p_ in m.named_parameters():
+            gref = sdo[name].grad
+            if gref is not None and gref.norm() > 0:
+                r_ = rel_l2(p_.grad, gref)
+                if r_ > worst_same:
+                    worst_same, worst_name = r_, name
+        untiered = {'cfg3': 3e-3, 'cfg4': 6e-3}[wl] if 'dense' not in bound_key else 6e-3
+        print('[%s] gradients with the %d rays that drew another sample (%d lobe / %d secondary flag) out of the colour terms on both '
+              'sides: worst %.2e (%s) - all rays: %.2e; untiered bound %.1e' % (bound_key, int(flagged.sum()), n_dir, n_vis, worst_same,
+                                                                              worst_name, worst, untiered))
+        assert worst_same < untiered, (bound_key, worst_name, worst_same)
 
 
 @pytest.mark.parametrize('wl', ['cfg3', 'cfg4'])
