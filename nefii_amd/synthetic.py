@@ -355,6 +355,47 @@ def add_sdf_dent(model, sd, center, width=0.01, depth=0.02, sharp=40.0, value_sc
     return sd
 
 
+def add_sdf_ripple(model, sd, amplitude=0.05, band=5, value_scale=0.3):
+    """ADVERSARIAL geometry, the global kind (tests only): sdf'(x) = value_scale * sdf(x) + amplitude * sum_i sin(2^band x_i) on a network
+    with spare hidden units (the zero-padded 'bowl') - a high-frequency corrugation everywhere, |grad| up to value_scale + sqrt(3)
+    amplitude 2^band (2.8 + 0.3 for the defaults), which a random sample of the bounding sphere DOES see.  One layer-0 unit
+    sp(amplitude * sum_i sin(2^band x_i) + 1) on the positional-encoding columns (exactly linear: its argument stays above 0.2), carried
+    like add_sdf_dent's unit and added by the last layer.  In place; returns sd."""
+    ic = model['implicit_network']
+    shapes = sdf_layer_dims(ic, int(model['feature_vector_size']))
+    nl = len(shapes)
+    skip = tuple(ic.get('skip_in', ()))
+    assert 0 <= band < int(ic.get('multires', 0)) and 3.0 * amplitude < 0.75
+    key = 'implicit_network.lin%d.%s'
+    spare = [torch.nonzero(sd[key % (l, 'weight_g')].reshape(-1) == 0).flatten().tolist() for l in range(nl - 1)]
+    assert all(len(sp) >= 1 for sp in spare), 'add_sdf_ripple needs spare hidden units (scene "bowl")'
+
+    def put(l, row, cols_vals, bias):
+        v = torch.zeros(shapes[l][1])
+        for col, val in cols_vals:
+            v[col] = val
+        sd[key % (l, 'weight_v')][row] = v
+        sd[key % (l, 'weight_g')][row] = v.norm()
+        sd[key % (l, 'bias')][row] = bias
+
+    # encoding columns: x (3), then per band k: sin (3), cos (3)  (embedder.py:21-31)
+    prev = spare[0][-1]         # (the last spare row: add_sdf_dent takes the first ones - both can be applied to one net)
+    put(0, prev, [(3 + 6 * band + i, amplitude) for i in range(3)], 1.0)
+    carried = 1
+    for l in range(1, nl - 1):
+        r = spare[l][-1]
+        put(l, r, [(prev, math.sqrt(2.0) if l in skip else 1.0)], 1.0)
+        prev, carried = r, carried + 1
+    L = nl - 1
+    v, g = sd[key % (L, 'weight_v')], sd[key % (L, 'weight_g')]
+    eff = v[0] * (g[0] / v[0].norm()) * value_scale
+    eff[prev] = math.sqrt(2.0) if L in skip else 1.0
+    sd[key % (L, 'weight_v')][0] = eff
+    sd[key % (L, 'weight_g')][0] = eff.norm()
+    sd[key % (L, 'bias')][0] = sd[key % (L, 'bias')][0] * value_scale - carried
+    return sd
+
+
 def look_at_origin_pose(cam_pos):
     """OpenCV-style cam-to-world (x right, y down, z forward) looking at the origin."""
     c = np.asarray(cam_pos, dtype=np.float64)

@@ -1083,38 +1083,45 @@ def test_tracer_staged_bracket_search_adversarial_dent():
 
 
 def test_tracer_staged_bracket_search_adversarial_bumps():
-    """a high-frequency term with |grad| up to ~3 everywhere (N(0, sigma) weights on the sin / cos columns of
-    the first layer).  This one the calibration SEES (the steepness is global): with L as shipped the staged bracket search of
-    eval-mode traces is bit-identical and the audit silent - primary rays and secondary-like rays from their hit points."""
-    mc = syn.model_conf('physg')
-    sd = syn.make_state_dict(mc, seed=3, bumpy=0.012)
+    """a high-frequency term with |grad| up to ~3 EVERYWHERE (syn.add_sdf_ripple: 0.05 sum_i sin(32 x_i) on the
+    zero-padded bowl scaled to an under-estimated distance, |grad| 0.3 + up to 2.8: a corrugated field with islands and pockets - sphere
+    tracing does not converge and a quarter of the rays reach the bracket search).  This steepness the calibration SEES (it is
+    global): with L as shipped the staged bracket search of eval-mode traces and the staged min-SDF search of training-mode ones are
+    bit-identical with a silent audit; primary rays and secondary-like rays from their hit points."""
+    mc = syn.model_conf('conf')
+    sd = syn.make_state_dict(mc, seed=0, scene='bowl')
+    syn.add_sdf_ripple(mc, sd, amplitude=0.05, band=5, value_scale=0.3)
     pm = build_sdf(mc, sd, f16x3=True)
     pm32 = build_sdf(mc, sd)
     tau = ops.calibrate_coarse_tau(pm)
     gmax = ops.calibrate_lipschitz(lambda x: ops.sdf_value_grad(pm32, x)[2], DEV, safety=1.0)
     lip = ops.calibrate_lipschitz(lambda x: ops.sdf_value_grad(pm32, x)[2], DEV)
     print('[adversarial bumps] largest |grad| found %.2f, L as shipped %.2f, tau %.2e' % (gmax, lip, tau))
-    assert gmax > 2.0, gmax
-    o, d, om, steps = _trace_batch(6000, 41)
+    assert 2.0 < gmax < 6.0, gmax
+    o, d, om, steps = _trace_batch(6000, 41, spread=0.6)
     plain = run_gpu_trace(mc, sd, o, d, om, True, steps, 'f16x3w', pm=pm)
     hp = plain[0][plain[1].bool()][:4000]
     w2 = torch.nn.functional.normalize(torch.randn(hp.shape[0], 3, generator=torch.Generator().manual_seed(9)), dim=1).to(DEV)
     nrm = torch.nn.functional.normalize(ops.sdf_value_grad(pm32, hp)[2], dim=1)
     w2 = torch.where((w2 * nrm).sum(1, keepdim=True) < 0, -w2, w2)
-    audited = probes = 0
+    audited = probes = bracket_searches = 0
     for what, (oo, dd, mm) in (('primary', (o, d, om)), ('secondary', (hp.cpu(), w2.cpu(), torch.ones(hp.shape[0], dtype=torch.bool)))):
         for training in (False, True):
             base = run_gpu_trace(mc, sd, oo, dd, mm, training, steps, 'f16x3w', coarse_tau=tau, pm=pm)
             got = run_gpu_trace(mc, sd, oo, dd, mm, training, steps, 'f16x3w', coarse_tau=tau, pm=pm, minsdf_lipschitz=lip)
-            for k in range(3):
-                assert torch.equal(got[k], base[k]), (what, training, k)
             c = got[3].cpu().long()
-            assert c[:, 12].max() == 0, (what, training)
+            viol = got[3][:, 12].cpu().contiguous().view(torch.float32).max().item()
+            same = all(torch.equal(got[k], base[k]) for k in range(3))
             audited += c[:, 11].sum().item()
             probes += c[:, 13].sum().item()
-            print('[adversarial bumps %s %s] %d dense searches, %d second-stage samples audited, %d of them probes of skipped samples' % (
-                what, 'train' if training else 'eval', c[:, 6].sum().item(), c[:, 11].sum().item(), c[:, 13].sum().item()))
-    assert audited > 0 and probes > 0, (audited, probes)
+            if not training:
+                bracket_searches += c[:, 6].sum().item()
+            print('[adversarial bumps %s %s] %d dense searches, %d second-stage samples audited, %d of them probes of skipped samples; '
+                  'bit-identical %s, audit %.2e' % (what, 'train' if training else 'eval', c[:, 6].sum().item(), c[:, 11].sum().item(),
+                                                    c[:, 13].sum().item(), same, viol))
+            assert same or viol > 0, (what, training)        # never a silent difference
+            assert same, 'L as shipped (1.5 x the largest gradient found) was violated on a field whose steepness is global'
+    assert audited > 0 and probes > 0 and bracket_searches > 0, (audited, probes, bracket_searches)
 
 
 @pytest.mark.parametrize('case', ['conf512-trained', 'conf512-frame', 'conf512-bowl', 'physg512-smooth', 'physg512-bumpy'])

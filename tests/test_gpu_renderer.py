@@ -1080,7 +1080,9 @@ def test_step2_training_recovers_a_rendered_target(name, hidden, num_rays, iters
                 for (name, p), (_, q) in zip(student.named_parameters(), shadow.named_parameters()):
                     if q.grad is not None:
                         assert torch.isfinite(p.grad).all(), (it, name)
-                        assert rel_l2(p.grad, q.grad) < 1e-3, (it, name, rel_l2(p.grad, q.grad))
+                        # (+ 1e-9 absolute: the global specular parameter's gradient passes through zero as it trains - seen at -4.0e-8,
+                        # where the float atomics' summation order alone is 1.3e-10 = 3e-3 of it)
+                        assert (p.grad - q.grad).norm().item() < 1e-3 * q.grad.norm().item() + 1e-9, (it, name, rel_l2(p.grad, q.grad))
         first, last = sum(losses[:12]) / 12, sum(losses[-12:]) / 12
         assert last < drop * first and all(l == l for l in losses), (graph, first, last)
         for opt in (step.idr_optimizer, step.sg_optimizer):
