@@ -1921,8 +1921,8 @@ __device__ __forceinline__ void sdf_tile16d(const nefii_mlp &m, _Float16 *X, flo
 // operand (2^-4 relative) leaves 2^-15: max |sdf error| against fp64 1.0e-5 (1.6e-6 within 0.02 of the surface; "16q": 5e-7;
 // tools/experiments/arith_emulation.py `fp8corr_fix`).  No data-dependent block scales: a low part is bounded by the ulp of its
 // high part and what falls below e4m3's range is negligible in absolute terms - the constants below, restored by the
-// instruction's scale operand.  512-wide nets only (FT = 4); the last layer's single column keeps fp16 for w_l x_h and does
-// q(x_l) w_h on the VALU (there is no fp16 x_l image).
+// instruction's scale operand.  512-wide nets only (FT = 4); the last layer's single column is the fp16 split of "16q": behind the
+// last hidden layer the epilogue writes an fp16 lo image over the two fp8 images, which nothing reads any more in that tile.
 // Stream (nefii_pack_sdf_stream's fifth copy): per wave and 128-deep chunk of a layer's 128-padded K eight 4-KiB units - the
 // chunk's four 32-deep k-steps in hi fragments (as "16s"), then per feature tile [q(w_l) 32 B | q(w_h) 32 B] per lane, lane
 // (f = lane & 15, g = lane >> 4) holding k = 128 chunk + 32 g + 0..31 - one cursor, the same 4 register stages.
@@ -2119,38 +2119,62 @@ __device__ __forceinline__ void sdf_tile16f(const nefii_mlp &m, LdsF &lds, float
         fgemm<QT>(chunks, b, a, x8, cur, ah, fh, fl, acc);
         bnext = *bp;
         __builtin_amdgcn_sched_barrier(0);
-        // epilogue: bias, activation, split into the fp16 hi half and the fp8 images of hi and lo
-        half4 phi[FT * QT];
-        int p8h[FT * QT], p8l[FT * QT];
-        if (m.act == NEFII_ACT_SOFTPLUS100)
-            fepilogue<QT, true>(acc, bvec, k16, lane, m.act, phi, p8h, p8l);
-        else
-            fepilogue<QT, false>(acc, bvec, k16, lane, m.act, phi, p8h, p8l);
-        __syncthreads();
-        _Float16 *xh = lds.Xh + (EP - L.n_pad);
-        unsigned char *x8h = lds.Fh + (EP - L.n_pad), *x8l = lds.Fl + (EP - L.n_pad);
+        // epilogue: bias, activation, split into the fp16 hi half and the fp8 images of hi and lo - or, behind the LAST hidden layer,
+        // into fp16 hi and lo: the last layer's single column is computed in the fp16 split (below), and the two fp8 images, which
+        // nothing reads any more in this tile, hold its lo image meanwhile (same 75 KB)
+        if (l < NH - 1) {
+            half4 phi[FT * QT];
+            int p8h[FT * QT], p8l[FT * QT];
+            if (m.act == NEFII_ACT_SOFTPLUS100)
+                fepilogue<QT, true>(acc, bvec, k16, lane, m.act, phi, p8h, p8l);
+            else
+                fepilogue<QT, false>(acc, bvec, k16, lane, m.act, phi, p8h, p8l);
+            __syncthreads();
+            _Float16 *xh = lds.Xh + (EP - L.n_pad);
+            unsigned char *x8h = lds.Fh + (EP - L.n_pad), *x8l = lds.Fl + (EP - L.n_pad);
 #pragma unroll
-        for (int ft = 0; ft < FT; ++ft) {
-            const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
+            for (int ft = 0; ft < FT; ++ft) {
+                const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const int query = 16 * qt + (lane & 15);
-                *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
-                *reinterpret_cast<int *>(x8h + query * XP8 + f0) = p8h[ft * QT + qt];
-                *reinterpret_cast<int *>(x8l + query * XP8 + f0) = p8l[ft * QT + qt];
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int query = 16 * qt + (lane & 15);
+                    *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                    *reinterpret_cast<int *>(x8h + query * XP8 + f0) = p8h[ft * QT + qt];
+                    *reinterpret_cast<int *>(x8l + query * XP8 + f0) = p8l[ft * QT + qt];
+                }
+            }
+        } else {
+            half4 phi[FT * QT], plo[FT * QT];
+            if (m.act == NEFII_ACT_SOFTPLUS100)
+                qepilogue<QT, FT, true>(acc, bvec, k16, lane, m.act, phi, plo);
+            else
+                qepilogue<QT, FT, false>(acc, bvec, k16, lane, m.act, phi, plo);
+            __syncthreads();
+            _Float16 *xh = lds.Xh + (EP - L.n_pad), *xl = reinterpret_cast<_Float16 *>(lds.Fl) + (EP - L.n_pad);
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) {
+                const int f0 = 16 * FT * wave + 16 * ft + 4 * (lane >> 4);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int query = 16 * qt + (lane & 15);
+                    *reinterpret_cast<half4 *>(xh + query * XP + f0) = phi[ft * QT + qt];
+                    *reinterpret_cast<half4 *>(xl + query * XP + f0) = plo[ft * QT + qt];
+                }
             }
         }
         __syncthreads();
     }
-    // last layer, column 0 only.  w_h x_h + w_l x_h on 32x32x16 fragments of the layer's own w_f16x3 (K split over the waves,
-    // as "16q"); the third term, w_h q(x_l), on the VALU from the fp8 image of x_l: thread (row = t & 63, part = t >> 6) sums its
-    // 64 k into the slot of (wave = part, row)
+    // last layer, column 0 only: the fp16 split of "16q" (w_h x_h + w_l x_h + w_h x_l on 32x32x16 fragments of the layer's own w_f16x3,
+    // K split over the waves) - the x_l image sits where the fp8 images were.  (A geometric-init net has an all-positive last layer:
+    // an e4m3 x_l there gave errors that do not cancel - 5.8e-6 near the surface instead of 1.5e-6.)
     {
+        static_assert(sizeof(lds.Fl) + sizeof(lds.Fh) >= sizeof(_Float16) * 64 * QGeo<4>::XP, "the lo image must fit the two fp8 images");
         const int r = lane & 31, h = lane >> 5;
         const nefii_layer &L = m.layer[NH];
         const int NT = L.n_pad >> 5;
         const half8 *wl = reinterpret_cast<const half8 *>(L.w_f16x3) + lane;
         const _Float16 *ah = lds.Xh + r * XP + 8 * h + (EP - L.k_x);
+        const _Float16 *al = reinterpret_cast<const _Float16 *>(lds.Fl) + r * XP + 8 * h + (EP - L.k_x);
         const int ksw = (L.k_x >> 4) / NW;
         f32x16 acc2[RT];
 #pragma unroll
@@ -2163,32 +2187,10 @@ __device__ __forceinline__ void sdf_tile16f(const nefii_mlp &m, LdsF &lds, float
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
                 const half8 xh8 = *reinterpret_cast<const half8 *>(ah + rt * 32 * XP + 16 * s);
+                const half8 xl8 = *reinterpret_cast<const half8 *>(al + rt * 32 * XP + 16 * s);
                 acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh8, acc2[rt], 0, 0, 0);
                 acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh8, acc2[rt], 0, 0, 0);
-            }
-        }
-        float third = 0.f;
-        {
-            const int row = threadIdx.x & 63, part = threadIdx.x >> 6;
-            if (row < 16 * QT) {
-                const int kpw = L.k_x / NW;                 // 64 for the 512-deep last layer
-                const unsigned char *xl = lds.Fl + row * XP8 + (EP - L.k_x) + part * kpw;
-                const _Float16 *wsrc = reinterpret_cast<const _Float16 *>(L.w_f16x3);
-                for (int k8 = 0; k8 < kpw; k8 += 8) {
-                    const int k = part * kpw + k8;
-                    // hi fragment of column n = 0: half8 index ((k >> 4) * NT * 2) * 64 + 32 * ((k >> 3) & 1), elements k & 7
-                    const half8 w8 = *reinterpret_cast<const half8 *>(wsrc + (((size_t)(k >> 4) * NT * 2) * 64 + 32 * ((k >> 3) & 1)) * 8);
-                    const int x0 = *reinterpret_cast<const int *>(xl + k8), x1 = *reinterpret_cast<const int *>(xl + k8 + 4);
-                    third = __builtin_fmaf((float)w8[0], __builtin_amdgcn_cvt_f32_fp8(x0, 0), third);
-                    third = __builtin_fmaf((float)w8[1], __builtin_amdgcn_cvt_f32_fp8(x0, 1), third);
-                    third = __builtin_fmaf((float)w8[2], __builtin_amdgcn_cvt_f32_fp8(x0, 2), third);
-                    third = __builtin_fmaf((float)w8[3], __builtin_amdgcn_cvt_f32_fp8(x0, 3), third);
-                    third = __builtin_fmaf((float)w8[4], __builtin_amdgcn_cvt_f32_fp8(x1, 0), third);
-                    third = __builtin_fmaf((float)w8[5], __builtin_amdgcn_cvt_f32_fp8(x1, 1), third);
-                    third = __builtin_fmaf((float)w8[6], __builtin_amdgcn_cvt_f32_fp8(x1, 2), third);
-                    third = __builtin_fmaf((float)w8[7], __builtin_amdgcn_cvt_f32_fp8(x1, 3), third);
-                }
-                third *= f8_scale(-F8_XL_E);
+                acc2[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl8, acc2[rt], 0, 0, 0);
             }
         }
         if (h == 0) {
@@ -2196,8 +2198,15 @@ __device__ __forceinline__ void sdf_tile16f(const nefii_mlp &m, LdsF &lds, float
             for (int rt = 0; rt < RT; ++rt) raw[wave * RMAX + 32 * rt + r] = acc2[rt][0];
         }
         __syncthreads();
-        if ((threadIdx.x & 63) < 16 * QT) raw[(threadIdx.x >> 6) * RMAX + (threadIdx.x & 63)] += third;
-        __syncthreads();
+        // the lo image has overwritten bytes that the NEXT tile's 128-padded first layer multiplies by zero weights before anything
+        // rewrites them: the pad columns [576, 592) of every fp8 row and the 48 bytes behind them (the next row's first columns; past
+        // the last row of Fl that is the head of Fh, past Fh the tail) - fp16 bits read as e4m3 may be NaN: zero them
+        if (threadIdx.x < 128) {
+            unsigned char *img = (threadIdx.x >> 6) ? lds.Fh : lds.Fl;
+            i32x4 *z = reinterpret_cast<i32x4 *>(img + (threadIdx.x & 63) * XP8 + 576);
+            const i32x4 zero = {0, 0, 0, 0};
+            z[0] = zero, z[1] = zero, z[2] = zero, z[3] = zero;
+        }
         float dm = 0.f;
         if (threadIdx.x < 32 * RT) {
             float sum = 0.f;
