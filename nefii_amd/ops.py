@@ -515,7 +515,7 @@ def calibrate_lipschitz(grad_fn, device, radius=1.0, n=65536, safety=LIPSCHITZ_S
 
 
 def algorithmic_evals(counters, n_steps):
-    """SDF evaluations the reference's recurrences need for the rounds in `counters` [..., rounds, 13] (_lib.TRACE_COUNTERS
+    """SDF evaluations the reference's recurrences need for the rounds in `counters` [..., rounds, 14] (_lib.TRACE_COUNTERS
     columns; what frac_credited credits): singles (0) + tiered singles taken (9 - 10) + n_steps per dense search entered (6)
     + bisection steps consumed (3)."""
     c = counters.long()
